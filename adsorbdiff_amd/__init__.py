@@ -1,0 +1,4 @@
+"""MI355X-native denoising-diffusion sampling path of AdsorbDiff (PaiNN score model +
+reverse-SDE stepper) behind a C ABI.  See DESIGN.md / INTEGRATION.md."""
+
+__version__ = "0.1.0"

@@ -1,0 +1,293 @@
+"""PaiNN denoising score model — host-side mirror of the reference module.
+
+Drop-in for ``adsorbdiff.models.painn.painn_denoising.PaiNN`` (reference:
+adsorbdiff/models/painn/painn_denoising.py:51-495): same constructor
+signature, same ``state_dict`` key names/shapes (so reference checkpoints
+load), same ``forward(data) -> (forces[N,3], forces2[N,3])`` contract.  The
+sub-modules below are *parameter containers only*: all arithmetic under
+``forward`` runs in the HIP library (``adsorbdiff_amd/csrc``) through the C ABI
+declared in ``include/adsorbdiff_hip.h``.  There is no eager / CPU fallback:
+``forward`` raises if the tensors are not on a ROCm device or the library is
+missing.
+
+Construction order and initialisers follow the reference so that
+``torch.manual_seed(s); PaiNN(...)`` yields bit-identical weights to the
+reference under the same seed (checked by oracle/make_golden.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Union
+
+import torch
+from torch import nn
+
+from .scaling import ScaleFactor, load_scales_compat
+
+
+class ScaledSiLU(nn.Module):
+    """silu(x)/0.6 — parameter-free placeholder so Sequential indices match the
+    reference (``x_proj.0 / x_proj.2``; reference: gemnet_oc/layers/base_layers.py:65-72)."""
+
+    scale_factor = 1 / 0.6
+
+    def forward(self, x):
+        return torch.nn.functional.silu(x) * self.scale_factor
+
+
+class AtomEmbedding(nn.Module):
+    """Reference: gemnet_oc/layers/embedding_block.py:15-43 (table [num_elements, H], U(-sqrt3, sqrt3))."""
+
+    def __init__(self, emb_size: int, num_elements: int) -> None:
+        super().__init__()
+        self.emb_size = emb_size
+        self.embeddings = nn.Embedding(num_elements, emb_size)
+        nn.init.uniform_(self.embeddings.weight, a=-math.sqrt(3), b=math.sqrt(3))
+
+
+class GaussianBasis(nn.Module):
+    """Holds the ``offset`` buffer (checkpoint key ``radial_basis.rbf.offset``)."""
+
+    def __init__(self, start: float, stop: float, num_gaussians: int) -> None:
+        super().__init__()
+        self.register_buffer("offset", torch.linspace(start, stop, num_gaussians))
+        self.coeff = -0.5 / ((stop - start) / (num_gaussians - 1)) ** 2
+
+
+class PolynomialEnvelope(nn.Module):
+    def __init__(self, exponent: int) -> None:
+        super().__init__()
+        self.p = float(exponent)
+        self.a = -(self.p + 1) * (self.p + 2) / 2
+        self.b = self.p * (self.p + 2)
+        self.c = -self.p * (self.p + 1) / 2
+
+
+class RadialBasis(nn.Module):
+    """Gaussian x polynomial-envelope basis hyper-parameters
+    (reference: gemnet_oc/layers/radial_basis.py:171-245).  Only the
+    gaussian/polynomial combination used by the denoiser configs is built."""
+
+    def __init__(self, num_radial: int, cutoff: float, rbf: Dict, envelope: Dict) -> None:
+        super().__init__()
+        if rbf.get("name", "gaussian").lower() != "gaussian":
+            raise ValueError("only the gaussian radial basis is implemented on the HIP path")
+        if envelope.get("name", "polynomial").lower() != "polynomial":
+            raise ValueError("only the polynomial envelope is implemented on the HIP path")
+        self.inv_cutoff = 1 / cutoff
+        self.envelope = PolynomialEnvelope(int(envelope.get("exponent", 5)))
+        self.rbf = GaussianBasis(0.0, 1.0, num_radial)
+
+
+class PaiNNMessage(nn.Module):
+    """Parameters of reference PaiNNMessage (painn_denoising.py:498-528)."""
+
+    def __init__(self, hidden_channels: int, num_rbf: int) -> None:
+        super().__init__()
+        self.x_proj = nn.Sequential(
+            nn.Linear(hidden_channels, hidden_channels),
+            ScaledSiLU(),
+            nn.Linear(hidden_channels, hidden_channels * 3),
+        )
+        self.rbf_proj = nn.Linear(num_rbf, hidden_channels * 3)
+        self.x_layernorm = nn.LayerNorm(hidden_channels)
+        for lin in (self.x_proj[0], self.x_proj[2], self.rbf_proj):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.fill_(0)
+        self.x_layernorm.reset_parameters()
+
+
+class PaiNNUpdate(nn.Module):
+    """Parameters of reference PaiNNUpdate (painn_denoising.py:575-599)."""
+
+    def __init__(self, hidden_channels: int) -> None:
+        super().__init__()
+        self.vec_proj = nn.Linear(hidden_channels, hidden_channels * 2, bias=False)
+        self.xvec_proj = nn.Sequential(
+            nn.Linear(hidden_channels * 2, hidden_channels),
+            ScaledSiLU(),
+            nn.Linear(hidden_channels, hidden_channels * 3),
+        )
+        nn.init.xavier_uniform_(self.vec_proj.weight)
+        for lin in (self.xvec_proj[0], self.xvec_proj[2]):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.fill_(0)
+
+
+class GatedEquivariantBlock(nn.Module):
+    """Parameters of reference GatedEquivariantBlock (painn_denoising.py:654-686)."""
+
+    def __init__(self, hidden_channels: int, out_channels: int) -> None:
+        super().__init__()
+        self.out_channels = out_channels
+        self.vec1_proj = nn.Linear(hidden_channels, hidden_channels, bias=False)
+        self.vec2_proj = nn.Linear(hidden_channels, out_channels, bias=False)
+        self.update_net = nn.Sequential(
+            nn.Linear(hidden_channels * 2, hidden_channels),
+            ScaledSiLU(),
+            nn.Linear(hidden_channels, out_channels * 2),
+        )
+
+    def reset_parameters(self) -> None:
+        nn.init.xavier_uniform_(self.vec1_proj.weight)
+        nn.init.xavier_uniform_(self.vec2_proj.weight)
+        for lin in (self.update_net[0], self.update_net[2]):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.fill_(0)
+
+
+class PaiNNOutput(nn.Module):
+    """Two gated-equivariant blocks H -> H/2 -> 1 (reference: painn_denoising.py:626-650)."""
+
+    def __init__(self, hidden_channels: int) -> None:
+        super().__init__()
+        self.output_network = nn.ModuleList(
+            [
+                GatedEquivariantBlock(hidden_channels, hidden_channels // 2),
+                GatedEquivariantBlock(hidden_channels // 2, 1),
+            ]
+        )
+        for layer in self.output_network:
+            layer.reset_parameters()
+
+
+class PaiNN(nn.Module):
+    """See module docstring.  ``num_atoms, bond_feat_dim, num_targets`` are accepted
+    and ignored exactly like the reference (models/base.py:22-28)."""
+
+    def __init__(
+        self,
+        num_atoms: Optional[int] = None,
+        bond_feat_dim: Optional[int] = None,
+        num_targets: Optional[int] = None,
+        hidden_channels: int = 512,
+        num_layers: int = 6,
+        num_rbf: int = 128,
+        cutoff: float = 12.0,
+        max_neighbors: int = 50,
+        rbf: Dict[str, str] = {"name": "gaussian"},
+        envelope: Dict[str, Union[str, int]] = {"name": "polynomial", "exponent": 5},
+        regress_forces: bool = True,
+        direct_forces: bool = True,
+        use_pbc: bool = True,
+        otf_graph: bool = True,
+        num_elements: int = 83,
+        scale_file: Optional[Union[str, Dict[str, float]]] = None,
+        so3_denoising: bool = False,
+        energy_encoding=None,
+        sampling: bool = False,
+    ) -> None:
+        super().__init__()
+        self.num_atoms, self.bond_feat_dim, self.num_targets = num_atoms, bond_feat_dim, num_targets
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self.num_rbf = num_rbf
+        self.cutoff = cutoff
+        self.max_neighbors = max_neighbors
+        self.regress_forces = regress_forces
+        self.direct_forces = direct_forces
+        self.otf_graph = otf_graph
+        self.use_pbc = use_pbc
+        self.so3_denoising = so3_denoising
+        self.sampling = sampling
+        self.num_elements = num_elements
+        self.symmetric_edge_symmetrization = False
+        if not (regress_forces and direct_forces):
+            raise ValueError("the denoiser runs with regress_forces=direct_forces=True (painn_so3.yml)")
+        if not (use_pbc and otf_graph):
+            raise ValueError("the HIP path builds the periodic graph on the fly (use_pbc=otf_graph=True)")
+
+        self.atom_emb = AtomEmbedding(hidden_channels, num_elements)
+        self.radial_basis = RadialBasis(num_rbf, cutoff, dict(rbf), dict(envelope))
+        # Frozen and unused by the PaiNN forward (SURVEY.md §8a "unused-but-present");
+        # present only so reference checkpoints load.  The reference fills it with
+        # its ATOMIC_RADII table (in pm); the values never reach an output.
+        self.atom_radii = nn.Parameter(torch.zeros(101), requires_grad=False)
+
+        self.message_layers = nn.ModuleList()
+        self.update_layers = nn.ModuleList()
+        if energy_encoding == "scalar":
+            # computed-then-discarded by the reference forward (painn_denoising.py:428-434)
+            self.energy_embedding = nn.Linear(1, hidden_channels)
+            self.concat_lin = nn.Sequential(nn.Linear(hidden_channels, hidden_channels), ScaledSiLU())
+        for i in range(num_layers):
+            self.message_layers.append(PaiNNMessage(hidden_channels, num_rbf))
+            self.update_layers.append(PaiNNUpdate(hidden_channels))
+            setattr(self, "upd_out_scalar_scale_%d" % i, ScaleFactor())
+
+        self.out_energy = nn.Sequential(
+            nn.Linear(hidden_channels, hidden_channels // 2),
+            ScaledSiLU(),
+            nn.Linear(hidden_channels // 2, 1),
+        )
+        self.out_forces = PaiNNOutput(hidden_channels)
+        if self.so3_denoising:
+            self.out_forces2 = PaiNNOutput(hidden_channels)
+        self.inv_sqrt_2 = 1 / math.sqrt(2.0)
+
+        for lin in (self.out_energy[0], self.out_energy[2]):
+            nn.init.xavier_uniform_(lin.weight)
+            lin.bias.data.fill_(0)
+        load_scales_compat(self, scale_file)
+
+        self._engine = None  # created lazily on first forward (device-resident packed weights)
+        self._engine_key = None
+
+    # ------------------------------------------------------------------ API
+    @property
+    def num_params(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    def no_weight_decay(self) -> list:
+        """Reference: adsorbdiff/models/base.py:128-135."""
+        return [
+            name
+            for name, _ in self.named_parameters()
+            if "embedding" in name or "frequencies" in name or "bias" in name
+        ]
+
+    def __repr__(self) -> str:
+        return (
+            f"{self.__class__.__name__}(hidden_channels={self.hidden_channels}, "
+            f"num_layers={self.num_layers}, num_rbf={self.num_rbf}, "
+            f"max_neighbors={self.max_neighbors}, cutoff={self.cutoff})"
+        )
+
+    def scale_factors(self):
+        """Effective per-layer multipliers (1.0 where a ScaleFactor is unfitted,
+        reference: scale_factor.py:166-167)."""
+        out = []
+        for i in range(self.num_layers):
+            sf = getattr(self, "upd_out_scalar_scale_%d" % i)
+            out.append(float(sf.scale_factor) if sf.fitted else 1.0)
+        return out
+
+    def engine(self, device=None):
+        """The device-side engine (packed weights + workspaces) for this module."""
+        from .engine import PaiNNEngine
+
+        if device is None:
+            device = self.atom_emb.embeddings.weight.device
+        key = (str(device), self._weights_version())
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = PaiNNEngine(self, device)
+            self._engine_key = key
+        return self._engine
+
+    def _weights_version(self):
+        # re-pack when any parameter tensor was swapped or modified in place
+        # (EMA store/copy_to/restore, load_state_dict)
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(
+            (b.data_ptr(), b._version) for b in self.buffers()
+        )
+
+    def forward(self, data):
+        """data: pos[N,3] f32, atomic_numbers[N], batch[N] i64, natoms[B] i64, cell[B,3,3] f32
+        -> (forces[N,3], forces2[N,3]) if so3_denoising else forces[N,3]."""
+        eng = self.engine(data.pos.device)
+        f1, f2 = eng.forward(data)
+        if not self.so3_denoising:
+            return f1
+        return f1, f2
