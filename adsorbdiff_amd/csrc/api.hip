@@ -1,0 +1,347 @@
+// C ABI of libadsorbdiff_hip.so: handle life-cycle, grow-only workspaces, and the launch
+// sequence of one PaiNN denoiser forward (reference: painn_denoising.py:402-481).
+#include <stdarg.h>
+#include <string.h>
+
+#include <new>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void adf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* adf_last_error(void) { return g_err; }
+extern "C" const char* adf_version(void) { return "adsorbdiff_hip 0.1.0 (gfx950)"; }
+
+template <typename T>
+static int32_t dev_alloc(T** p, size_t count) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) return ADF_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        (void)hipGetLastError();
+        adf_set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return ADF_EOOM;
+    }
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* out) {
+    if (!hp || !out) { adf_set_error("null argument"); return ADF_EINVAL; }
+    if (hp->hidden_channels % ADF_SLICE_CH != 0 || hp->hidden_channels < 128 || hp->hidden_channels > 1024) {
+        adf_set_error("hidden_channels=%d must be a multiple of %d in [128,1024]", hp->hidden_channels, ADF_SLICE_CH);
+        return ADF_EINVAL;
+    }
+    if (hp->num_rbf % 2 != 0 || hp->num_rbf > 128 || hp->num_rbf < 2) {
+        adf_set_error("num_rbf=%d must be even and <= 128", hp->num_rbf);
+        return ADF_EINVAL;
+    }
+    if (hp->max_neighbors < 1 || hp->max_neighbors > ADF_MAX_K) {
+        adf_set_error("max_neighbors=%d must be in [1,%d]", hp->max_neighbors, ADF_MAX_K);
+        return ADF_EINVAL;
+    }
+    if (hp->num_layers < 1 || hp->num_layers > 16 || hp->num_heads < 1 || hp->num_heads > 2) {
+        adf_set_error("num_layers must be in [1,16], num_heads in [1,2]");
+        return ADF_EINVAL;
+    }
+    adf_painn* h = new (std::nothrow) adf_painn();
+    if (!h) { adf_set_error("host allocation failed"); return ADF_EOOM; }
+    memset(h, 0, sizeof(*h));
+    h->hp = *hp;
+    ADF_HIP_CHECK(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    ADF_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = prop.multiProcessorCount;
+    const int H = hp->hidden_channels, R = hp->num_rbf, L = hp->num_layers;
+    int32_t st = dev_alloc(&h->rbf_pack, (size_t)L * (H / ADF_SLICE_CH) * R * 192);
+    if (st == ADF_OK) st = dev_alloc(&h->rbf_bias_pack, (size_t)L * (H / ADF_SLICE_CH) * 192);
+    if (st == ADF_OK) st = dev_alloc(&h->flags, 4);
+    if (st != ADF_OK) { adf_painn_destroy(h); return st; }
+    *out = h;
+    return ADF_OK;
+}
+
+static void free_workspaces(adf_painn* h) {
+    void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->gcount, h->gptr, h->gcursor, h->e_meta, h->e_geom,
+                    h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->nbr_cnt = h->nbr_src = h->nbr_shift = h->gcount = h->gptr = h->gcursor = nullptr;
+    h->e_meta = nullptr; h->e_geom = nullptr;
+    h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = nullptr;
+    h->capN = h->capB = h->capE = 0;
+}
+
+extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
+    if (!h) return ADF_OK;
+    free_workspaces(h);
+    if (h->rbf_pack) (void)hipFree(h->rbf_pack);
+    if (h->rbf_bias_pack) (void)hipFree(h->rbf_bias_pack);
+    if (h->flags) (void)hipFree(h->flags);
+    delete h;
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const void* const* w,
+                                         const float* scale_factors, void* stream) {
+    if (!h || !w || !scale_factors) { adf_set_error("null argument"); return ADF_EINVAL; }
+    const int L = h->hp.num_layers;
+    const int expect = 2 + ADF_WEIGHTS_PER_LAYER * L + ADF_WEIGHTS_PER_HEAD * h->hp.num_heads;
+    if (n_weights != expect) {
+        adf_set_error("expected %d weight tensors, got %d", expect, n_weights);
+        return ADF_EINVAL;
+    }
+    for (int i = 0; i < n_weights; ++i)
+        if (!w[i]) { adf_set_error("weight %d is null", i); return ADF_EINVAL; }
+    auto f = [&](int i) { return reinterpret_cast<const float*>(w[i]); };
+    h->emb = f(0);
+    h->rbf_offset = f(1);
+    int k = 2;
+    for (int l = 0; l < L; ++l) {
+        adf_layer_weights& lw = h->layer[l];
+        lw.ln_w = f(k++); lw.ln_b = f(k++); lw.xp0_w = f(k++); lw.xp0_b = f(k++); lw.xp2_w = f(k++); lw.xp2_b = f(k++);
+        lw.rbf_w = f(k++); lw.rbf_b = f(k++); lw.vp_w = f(k++); lw.xv0_w = f(k++); lw.xv0_b = f(k++);
+        lw.xv2_w = f(k++); lw.xv2_b = f(k++);
+        h->scale[l] = scale_factors[l];
+    }
+    for (int hd = 0; hd < h->hp.num_heads; ++hd)
+        for (int b = 0; b < 2; ++b) {
+            adf_block_weights& bw = h->head[hd][b];
+            bw.vec1_w = f(k++); bw.vec2_w = f(k++); bw.un0_w = f(k++); bw.un0_b = f(k++); bw.un2_w = f(k++);
+            bw.un2_b = f(k++);
+        }
+    ADF_TRY(adf_pack_rbf(h, (hipStream_t)stream));
+    h->weights_set = true;
+    return ADF_OK;
+}
+
+// grow-only workspaces for N atoms in B systems
+static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
+    if (N <= h->capN && B <= h->capB) return ADF_OK;
+    const int64_t capN = N > h->capN ? N : h->capN;
+    const int64_t capB = B > h->capB ? B : h->capB;
+    // synchronise before freeing buffers that enqueued work may still use
+    ADF_HIP_CHECK(hipDeviceSynchronize());
+    free_workspaces(h);
+    const int64_t H = h->hp.hidden_channels, K = h->hp.max_neighbors;
+    const int64_t G = (capN + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
+    // symmetrised edges: every directed top-K entry (j -> i) survives at most once (j < i, or a
+    // self image with a negative shift) and is then doubled: E <= 2*N*K.
+    const int64_t capE = 2 * capN * K;
+    int32_t st = ADF_OK;
+#define ALLOC(field, count) if (st == ADF_OK) st = dev_alloc(&h->field, (size_t)(count))
+    ALLOC(nbr_cnt, capN);
+    ALLOC(nbr_src, capN * K);
+    ALLOC(nbr_shift, capN * K);
+    ALLOC(gcount, G + 1);
+    ALLOC(gptr, G + 1);
+    ALLOC(gcursor, G + 1 + capB);
+    ALLOC(e_meta, capE);
+    ALLOC(e_geom, capE);
+    ALLOC(x, capN * H);
+    ALLOC(vecA, capN * 3 * H);
+    ALLOC(vecB, capN * 3 * H);
+    ALLOC(y, capN * H);
+    ALLOC(xh, capN * 3 * H);
+    ALLOC(vv, capN * 6 * H);
+    ALLOC(cat, capN * 2 * H);
+    ALLOC(dot, capN * H);
+    ALLOC(sys, capB * 16);
+#undef ALLOC
+    if (st != ADF_OK) { free_workspaces(h); return st; }
+    h->capN = capN; h->capB = capB; h->capE = capE;
+    return ADF_OK;
+}
+
+static int32_t check_batch(const adf_painn* h, const adf_batch* b) {
+    if (!h || !b) { adf_set_error("null argument"); return ADF_EINVAL; }
+    if (b->num_atoms <= 0 || b->num_systems <= 0) { adf_set_error("empty batch"); return ADF_EINVAL; }
+    if (!b->pos || !b->cell || !b->batch || !b->atom_offset) { adf_set_error("null batch array"); return ADF_EINVAL; }
+    for (int k = 0; k < 3; ++k)
+        if (b->reps[k] < 0 || b->reps[k] > 16) { adf_set_error("reps[%d]=%d out of range", k, b->reps[k]); return ADF_EINVAL; }
+    return ADF_OK;
+}
+
+static int32_t read_flags(adf_painn* h, hipStream_t s) {
+    int32_t f[4];
+    ADF_HIP_CHECK(hipMemcpyAsync(f, h->flags, sizeof(f), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    if (f[0]) { adf_set_error("a centre atom has more than %d in-cutoff candidates", ADF_MAX_CAND); return ADF_EOVERFLOW; }
+    if (f[2]) { adf_set_error("edge buffer overflow"); return ADF_EOVERFLOW; }
+    if (f[1]) { adf_set_error("An image has no neighbors"); return ADF_ENONEIGHBOR; }
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_graph_build(adf_painn_t h, const adf_batch* b, void* stream, int64_t* num_edges) {
+    ADF_TRY(check_batch(h, b));
+    ADF_TRY(ensure_capacity(h, b->num_atoms, b->num_systems));
+    hipStream_t s = (hipStream_t)stream;
+    ADF_TRY(adf_graph_build_impl(h, b, s));
+    if (num_edges) {
+        const int G = (b->num_atoms + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
+        int32_t e = 0;
+        ADF_HIP_CHECK(hipMemcpyAsync(&e, h->gptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        ADF_TRY(read_flags(h, s));
+        *num_edges = e;
+    }
+    return ADF_OK;
+}
+
+__global__ void adf_export_edges_kernel(const int32_t* gptr, const adf_edge_meta* em, const float4* eg, int G,
+                                        int32_t* src, int32_t* dst, float* dist, float* vec, long long cap) {
+    const int g = blockIdx.x;
+    if (g >= G) return;
+    for (int e = gptr[g] + threadIdx.x; e < gptr[g + 1]; e += blockDim.x) {
+        if (e >= cap) continue;
+        if (src) src[e] = em[e].src;
+        if (dst) dst[e] = g * ADF_GROUP_NODES + em[e].dstl;
+        const float4 q = eg[e];
+        if (dist) dist[e] = q.w;
+        if (vec) { vec[3 * (size_t)e] = q.x; vec[3 * (size_t)e + 1] = q.y; vec[3 * (size_t)e + 2] = q.z; }
+    }
+}
+
+__global__ void adf_export_shift_kernel(const int32_t* nbr_shift, int32_t* out, long long n, int r0, int r1, int r2) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = nbr_shift[i];
+    const int n2 = 2 * r2 + 1, n1 = 2 * r1 + 1;
+    const int ia = c / (n1 * n2), rem = c - ia * (n1 * n2);
+    out[3 * i] = ia - r0;
+    out[3 * i + 1] = rem / n2 - r1;
+    out[3 * i + 2] = rem % n2 - r2;
+}
+
+extern "C" int32_t adf_graph_export(adf_painn_t h, int32_t* nbr_count, int32_t* nbr_src, int32_t* nbr_shift,
+                                    int64_t edge_capacity, int32_t* edge_src, int32_t* edge_dst, float* edge_dist,
+                                    float* edge_vec, int64_t* num_edges, void* stream) {
+    if (!h || h->lastN <= 0) { adf_set_error("no graph built"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t N = h->lastN, K = h->hp.max_neighbors;
+    const int G = (int)((N + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES);
+    if (nbr_count) ADF_HIP_CHECK(hipMemcpyAsync(nbr_count, h->nbr_cnt, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, s));
+    if (nbr_src) ADF_HIP_CHECK(hipMemcpyAsync(nbr_src, h->nbr_src, sizeof(int32_t) * N * K, hipMemcpyDeviceToDevice, s));
+    if (nbr_shift)
+        hipLaunchKernelGGL(adf_export_shift_kernel, dim3((unsigned)((N * K + 255) / 256)), dim3(256), 0, s, h->nbr_shift,
+                           nbr_shift, (long long)(N * K), h->last_reps[0], h->last_reps[1], h->last_reps[2]);
+    if (edge_src || edge_dst || edge_dist || edge_vec)
+        hipLaunchKernelGGL(adf_export_edges_kernel, dim3(G), dim3(256), 0, s, h->gptr, h->e_meta, h->e_geom, G, edge_src,
+                           edge_dst, edge_dist, edge_vec, (long long)edge_capacity);
+    ADF_HIP_CHECK(hipGetLastError());
+    int32_t e = 0;
+    ADF_HIP_CHECK(hipMemcpyAsync(&e, h->gptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    if (num_edges) *num_edges = e;
+    return ADF_OK;
+}
+
+static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const float* vec, float* x_out,
+                             float* vec_out, hipStream_t s) {
+    const int H = h->hp.hidden_channels;
+    const adf_layer_weights& w = h->layer[l];
+    // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
+    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
+    ADF_TRY(adf_launch_gemm(h->y, H, w.xp0_w, H, w.xp0_b, h->cat, H, N, H, H, 1, s));
+    ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+    return adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, s);
+}
+
+static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hipStream_t s) {
+    const int H = h->hp.hidden_channels;
+    const adf_layer_weights& w = h->layer[l];
+    ADF_TRY(adf_launch_gemm(vec, H, w.vp_w, H, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
+    ADF_TRY(adf_nodewise_update_prep(h->vv, x, h->cat, h->dot, N, H, s));
+    ADF_TRY(adf_launch_gemm(h->cat, 2 * H, w.xv0_w, 2 * H, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
+    ADF_TRY(adf_launch_gemm(h->y, H, w.xv2_w, H, w.xv2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+    return adf_nodewise_update_apply(h->xh, h->dot, h->vv, x, vec, h->scale[l], N, H, s);
+}
+
+extern "C" int32_t adf_painn_message_layer(adf_painn_t h, int32_t layer, int32_t N, const float* x, const float* vec,
+                                           float* x_out, float* vec_out, void* stream) {
+    if (!h || !h->weights_set || layer < 0 || layer >= h->hp.num_layers || N != h->lastN) {
+        adf_set_error("message_layer: bad handle/layer, or N differs from the built graph");
+        return ADF_EINVAL;
+    }
+    return message_layer(h, layer, N, x, vec, x_out, vec_out, (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_painn_update_layer(adf_painn_t h, int32_t layer, int32_t N, float* x, float* vec, void* stream) {
+    if (!h || !h->weights_set || layer < 0 || layer >= h->hp.num_layers) {
+        adf_set_error("update_layer: bad handle/layer");
+        return ADF_EINVAL;
+    }
+    ADF_TRY(ensure_capacity(h, N, 1));
+    return update_layer(h, layer, N, x, vec, (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f1, float* f2, void* stream) {
+    ADF_TRY(check_batch(h, b));
+    if (!h->weights_set) { adf_set_error("weights not set"); return ADF_EINVAL; }
+    if (!b->atomic_numbers || !f1 || (h->hp.num_heads == 2 && !f2)) { adf_set_error("null argument"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const int N = b->num_atoms;
+    ADF_TRY(ensure_capacity(h, N, b->num_systems));
+    ADF_TRY(adf_graph_build_impl(h, b, s));
+    ADF_TRY(adf_nodewise_embed(h, b->atomic_numbers, N, h->x, h->vecA, s));
+    float* vin = h->vecA;
+    float* vout = h->vecB;
+    for (int l = 0; l < h->hp.num_layers; ++l) {
+        ADF_TRY(message_layer(h, l, N, h->x, vin, h->x, vout, s));
+        ADF_TRY(update_layer(h, l, N, h->x, vout, s));
+        float* t = vin; vin = vout; vout = t;
+    }
+    ADF_TRY(adf_head_forward(h, 0, N, h->x, vin, f1, s));
+    if (h->hp.num_heads == 2) ADF_TRY(adf_head_forward(h, 1, N, h->x, vin, f2, s));
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_check_flags(adf_painn_t h, void* stream) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    return read_flags(h, (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_sde_init_placement(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                                          const float* noise, void* stream) {
+    ADF_TRY(check_batch(h, b));
+    if (!pos || !tags || !noise) { adf_set_error("null argument"); return ADF_EINVAL; }
+    return adf_stepper_init(h, b, pos, tags, noise, (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_sde_step(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                                const int32_t* fixed, const float* f1, const float* f2, const adf_step_coef* coef,
+                                const float* z_tr, const float* z_rot, int32_t early_stop_count, int32_t* state,
+                                float* dcom, float* drot, void* stream) {
+    ADF_TRY(check_batch(h, b));
+    if (!pos || !tags || !f1 || !f2 || !coef || !state) { adf_set_error("null argument"); return ADF_EINVAL; }
+    ADF_TRY(ensure_capacity(h, b->num_atoms, b->num_systems));
+    return adf_stepper_step(h, b, pos, tags, fixed, f1, f2, coef, z_tr, z_rot, early_stop_count, state, dcom, drot,
+                            (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream) {
+    if (!h || !out || h->lastN <= 0) { adf_set_error("no forward has run"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t N = h->lastN, H = h->hp.hidden_channels, R = h->hp.num_rbf, L = h->hp.num_layers;
+    const int G = (int)((N + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES);
+    int32_t e = 0;
+    ADF_HIP_CHECK(hipMemcpyAsync(&e, h->gptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t E = e;
+    out->num_edges = E;
+    out->num_atoms = N;
+    // E*(3H*4 + 12 + 8) + N*(3H*4 + 3H*4) + N*(H*4 + 3H*4)
+    out->message_bytes_per_layer = E * (3 * H * 4 + 12 + 8) + N * (3 * H * 4 + 3 * H * 4) + N * (H * 4 + 3 * H * 4);
+    // per layer: node side 30 H^2 N, edge side 2 R 3H E; heads: per head 2*(3N*H*H + 3N*H*H/2 + N*2H*H + N*H*H
+    //            + 3N*(H/2)^2 + N*H*H/2)
+    const int64_t head = 2 * (3 * N * H * H + 3 * N * H * H / 2 + N * 2 * H * H + N * H * H + 3 * N * (H / 2) * (H / 2) +
+                              N * H * H / 2);
+    out->dense_flops = L * (30 * H * H * N + 2 * R * 3 * H * E) + h->hp.num_heads * head;
+    return ADF_OK;
+}

@@ -1,0 +1,101 @@
+// Internal declarations shared by the HIP translation units of libadsorbdiff_hip.so.
+// gfx950 (MI355X) only: 64-wide wavefronts, f32 MFMA 32x32x2, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/adsorbdiff_hip.h"
+
+#define ADF_GROUP_NODES 32      // target nodes per message-kernel work item
+#define ADF_SLICE_CH 64         // channels per message-kernel slice (x3 parts = 192 MFMA columns)
+#define ADF_MAX_CAND 4096       // in-cutoff candidates per centre held in LDS by the top-K kernel
+#define ADF_MAX_K 128
+
+void adf_set_error(const char* fmt, ...);
+
+#define ADF_HIP_CHECK(expr)                                                             \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            adf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                          __FILE__, __LINE__);                                          \
+            return (_e == hipErrorOutOfMemory) ? ADF_EOOM : ADF_EHIP;                   \
+        }                                                                               \
+    } while (0)
+
+#define ADF_TRY(expr)                     \
+    do {                                  \
+        int32_t _s = (expr);              \
+        if (_s != ADF_OK) return _s;      \
+    } while (0)
+
+struct adf_layer_weights {
+    const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
+    const float *vp_w, *xv0_w, *xv0_b, *xv2_w, *xv2_b;
+};
+struct adf_block_weights {
+    const float *vec1_w, *vec2_w, *un0_w, *un0_b, *un2_w, *un2_b;
+};
+
+// packed edge record, grouped by target-node group (see graph.hip)
+struct adf_edge_meta {
+    int32_t src;    // global source atom
+    int32_t dstl;   // target atom index inside its group (0..ADF_GROUP_NODES-1)
+};
+
+struct adf_painn {
+    adf_painn_hparams hp;
+    int device;
+    bool weights_set;
+    const float* emb;
+    const float* rbf_offset;
+    adf_layer_weights layer[16];
+    adf_block_weights head[2][2];
+    float scale[16];
+    // message-kernel image of rbf_proj: [layer][slice][R][192] and bias [layer][slice][192]
+    float* rbf_pack;
+    float* rbf_bias_pack;
+    // concatenated head projections (vec1|vec2 of block 0 for every head): [(H + H/2) * heads, H]
+    float* head_vproj_pack;
+
+    // ---- grow-only workspaces
+    int64_t capN, capB, capE;
+    int32_t* nbr_cnt;    // [N]
+    int32_t* nbr_src;    // [N*K]
+    int32_t* nbr_shift;  // [N*K]  index into the lexicographic shift table
+    int32_t* gcount;     // [G+1] edges per target group
+    int32_t* gptr;       // [G+1] exclusive scan
+    int32_t* gcursor;    // [G]
+    adf_edge_meta* e_meta;  // [capE]
+    float4* e_geom;         // [capE] (ux,uy,uz,d): unit vector target->source, distance
+    int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}
+    float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
+    float *hx, *hv, *hcat, *hy, *hv2;                  // head buffers
+    float* sys;          // [B*16] per-system scratch of the stepper
+    // last graph
+    int64_t lastN, lastB;
+    int32_t last_reps[3];
+    int num_cus;
+};
+
+// ---- kernels' host launchers (each enqueues on `s`, returns ADF_*)
+int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
+                        int M, int N, int K, int act_ssilu, hipStream_t s);
+int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
+int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
+                         float* x_out, float* vec_out, hipStream_t s);
+int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
+int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, float* vec, hipStream_t s);
+int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s);
+int32_t adf_nodewise_update_prep(const float* vv, const float* x, float* cat, float* dot, int N, int H, hipStream_t s);
+int32_t adf_nodewise_update_apply(const float* h3, const float* dot, const float* vv, float* x, float* vec,
+                                  float scale, int N, int H, hipStream_t s);
+int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const float* vec, float* out, hipStream_t s);
+int32_t adf_stepper_init(adf_painn* h, const adf_batch* b, float* pos, const int32_t* tags, const float* noise,
+                         hipStream_t s);
+int32_t adf_stepper_step(adf_painn* h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                         const float* f1, const float* f2, const adf_step_coef* coef, const float* z_tr,
+                         const float* z_rot, int32_t early_stop_count, int32_t* state, float* dcom, float* drot,
+                         hipStream_t s);

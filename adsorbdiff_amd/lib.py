@@ -1,0 +1,108 @@
+"""ctypes binding of libadsorbdiff_hip.so (the C ABI in include/adsorbdiff_hip.h).
+
+This is the stub a reference maintainer would add.  There is
+no fallback: if the library is missing or a call fails, an exception is
+raised — ``RuntimeError`` for out-of-memory / HIP errors (so that
+``ml_diffuse``'s split-and-retry contract works, reference
+relaxation/ml_relaxation.py:146-165) and ``ValueError`` for an image without
+neighbours (reference painn_denoising.py:370-375).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+ADF_OK, ADF_EINVAL, ADF_EOOM, ADF_ENONEIGHBOR, ADF_EHIP, ADF_EOVERFLOW = 0, 1, 2, 3, 4, 5
+
+EXPORTS = (
+    "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_check_flags",
+    "adf_graph_export", "adf_painn_forward", "adf_painn_message_layer", "adf_painn_update_layer",
+    "adf_sde_init_placement", "adf_sde_step", "adf_get_counters", "adf_last_error", "adf_version",
+)
+
+
+class Hparams(C.Structure):
+    _fields_ = [
+        ("hidden_channels", C.c_int32), ("num_layers", C.c_int32), ("num_rbf", C.c_int32),
+        ("num_elements", C.c_int32), ("max_neighbors", C.c_int32), ("envelope_exponent", C.c_int32),
+        ("num_heads", C.c_int32), ("cutoff", C.c_float),
+    ]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [
+        ("num_systems", C.c_int32), ("num_atoms", C.c_int32), ("pos", C.c_void_p), ("cell", C.c_void_p),
+        ("atomic_numbers", C.c_void_p), ("batch", C.c_void_p), ("atom_offset", C.c_void_p), ("reps", C.c_int32 * 3),
+    ]
+
+
+class StepCoef(C.Structure):
+    _fields_ = [
+        ("coef_tr", C.c_float), ("rot_pre", C.c_float), ("rot_dt", C.c_float), ("rot_g2", C.c_float),
+        ("noise_tr", C.c_float), ("noise_rot", C.c_float),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("num_edges", C.c_int64), ("num_atoms", C.c_int64), ("message_bytes_per_layer", C.c_int64),
+        ("dense_flops", C.c_int64),
+    ]
+
+
+_LIB = None
+
+
+def lib_path() -> Path:
+    return Path(__file__).resolve().parent / "libadsorbdiff_hip.so"
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} not found: build it with `python -m adsorbdiff_amd.build` "
+            "(the HIP path has no CPU fallback)"
+        )
+    lib = C.CDLL(str(path))
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    lib.adf_last_error.restype = C.c_char_p
+    lib.adf_version.restype = C.c_char_p
+    sigs = {
+        "adf_painn_create": [C.POINTER(Hparams), C.POINTER(vp)],
+        "adf_painn_destroy": [vp],
+        "adf_painn_set_weights": [vp, i32, C.POINTER(vp), C.POINTER(C.c_float), vp],
+        "adf_graph_build": [vp, C.POINTER(BatchDesc), vp, C.POINTER(i64)],
+        "adf_check_flags": [vp, vp],
+        "adf_graph_export": [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.POINTER(i64), vp],
+        "adf_painn_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp],
+        "adf_painn_message_layer": [vp, i32, i32, vp, vp, vp, vp, vp],
+        "adf_painn_update_layer": [vp, i32, i32, vp, vp, vp],
+        "adf_sde_init_placement": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp],
+        "adf_sde_step": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, vp, C.POINTER(StepCoef), vp, vp, i32, vp, vp, vp, vp],
+        "adf_get_counters": [vp, C.POINTER(Counters), vp],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = i32
+    _LIB = lib
+    return lib
+
+
+def check(status: int) -> None:
+    """Translate a status code into the exception the reference's callers expect."""
+    if status == ADF_OK:
+        return
+    msg = load().adf_last_error().decode("utf-8", "replace")
+    if status == ADF_ENONEIGHBOR:
+        raise ValueError(msg)
+    if status == ADF_EOOM:
+        raise RuntimeError(f"HIP out of memory: {msg}")
+    if status == ADF_EINVAL:
+        raise ValueError(f"adsorbdiff_hip: invalid argument: {msg}")
+    raise RuntimeError(f"adsorbdiff_hip error {status}: {msg}")

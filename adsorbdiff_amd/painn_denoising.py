@@ -263,17 +263,25 @@ class PaiNN(nn.Module):
         return out
 
     def engine(self, device=None):
-        """The device-side engine (packed weights + workspaces) for this module."""
+        """The device-side engine (C-ABI handle + workspaces) bound to this module's weights."""
         from .engine import PaiNNEngine
 
         if device is None:
             device = self.atom_emb.embeddings.weight.device
-        key = (str(device), self._weights_version())
-        if self._engine is None or self._engine_key != key:
-            if self._engine is not None:
-                self._engine.close()
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self._engine is not None and self._engine.device != device:
+            self._engine.close()
+            self._engine = None
+        version = self._weights_version()
+        if self._engine is None:
             self._engine = PaiNNEngine(self, device)
-            self._engine_key = key
+            self._engine_key = version
+        elif self._engine_key != version:
+            # parameters were swapped or modified in place (EMA copy_to/restore, load_state_dict)
+            self._engine.bind_weights()
+            self._engine_key = version
         return self._engine
 
     def _weights_version(self):

@@ -1,0 +1,124 @@
+"""Trainer-like object for sampling — the part of the reference's ``DenoisingTrainer`` that the
+stepper touches (reference: adsorbdiff/trainers/sde_denoising_trainer.py:539-652, 750-813, and
+denoising_torch.py:38,491-500): ``predict_denoising(batch, per_image=False)``,
+``_unwrapped_model``, ``ema``, ``scaler``, ``device``, ``config["model_attributes"]`` and
+``run_relaxations`` (the ``run-relaxations`` task entry, tasks/task.py:90-100).
+
+Training (``train/validate/_compute_loss``), datasets, logging and checkpoint *writing* are out
+of scope; ``load_checkpoint`` reads the reference's checkpoint layout
+(base_trainer.py:456-533) so trained weights can be sampled with.
+"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from typing import Iterable, Optional
+
+import torch
+
+from .ml_relaxation import ml_diffuse
+from .painn_denoising import PaiNN
+from .scaling import ensure_fitted
+
+
+def check_traj_files(batch, traj_dir) -> bool:
+    """Resume rule of the sampler: a batch is skipped iff every <traj_dir>/<sid>.traj exists
+    (reference: utils/utils.py:968-973)."""
+    if traj_dir is None:
+        return False
+    traj_dir = Path(traj_dir)
+    return all((traj_dir / f"{sid}.traj").exists() for sid in batch.sid)
+
+
+class DenoisingTrainer:
+    def __init__(self, model: PaiNN, device="cuda:0", config: Optional[dict] = None, ema=None, relax_loader=None):
+        self.device = torch.device(device)
+        self.model = model.to(self.device)
+        self.ema = ema
+        self.scaler = None  # fp32 path; the reference's --amp autocast is not offered
+        self.relax_loader = relax_loader
+        self.config = config or {}
+        self.config.setdefault("model_attributes", {})
+        self.config["model_attributes"].setdefault("so3_denoising", bool(model.so3_denoising))
+        self.config.setdefault("task", {})
+        self.config.setdefault("optim", {})
+
+    @property
+    def _unwrapped_model(self):
+        module = self.model
+        while hasattr(module, "module"):  # DDP / OCPDataParallel wrappers
+            module = module.module
+        return module
+
+    # ---------------------------------------------------------------- inference
+    def _forward_denoising(self, batch):
+        """Reference: sde_denoising_trainer.py:539-553."""
+        if not self.config["model_attributes"].get("so3_denoising", False):
+            return {"positions": self.model(batch.to(self.device))}
+        out1, out2 = self.model(batch.to(self.device))
+        return {"positions": out1, "positions_free": out2}
+
+    @torch.no_grad()
+    def predict_denoising(self, data_loader, per_image: bool = True, results_file=None, disable_tqdm: bool = False):
+        """Only the ``per_image=False`` form the stepper uses (reference :555-652)."""
+        if per_image:
+            raise NotImplementedError("per_image=True (result-file writer) is outside the sampling path")
+        ensure_fitted(self._unwrapped_model, warn=True)
+        self.model.eval()
+        if self.ema:
+            self.ema.store()
+            self.ema.copy_to()
+        try:
+            out = self._forward_denoising(data_loader)
+            predictions = {"positions": out["positions"].detach()}
+            if "positions_free" in out:
+                predictions["positions_free"] = out["positions_free"].detach()
+        finally:
+            if self.ema:
+                self.ema.restore()
+        return predictions
+
+    # ---------------------------------------------------------------- checkpoint ingest
+    def load_checkpoint(self, checkpoint_path: str) -> None:
+        """Reads ``state_dict`` (with 0-2 ``module.`` prefixes) from a reference checkpoint
+        (base_trainer.py:456-533).  ``ema`` shadow parameters, if present, are applied directly."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu")
+        sd = ckpt.get("state_dict", ckpt)
+        clean = {}
+        for k, v in sd.items():
+            while k.startswith("module."):
+                k = k[len("module."):]
+            clean[k] = v
+        missing, unexpected = self._unwrapped_model.load_state_dict(clean, strict=False)
+        for k in missing:
+            logging.warning(f"checkpoint is missing key {k}")
+        for k in unexpected:
+            logging.warning(f"checkpoint has unexpected key {k}")
+        ema = ckpt.get("ema")
+        if ema and "shadow_params" in ema:
+            params = [p for p in self._unwrapped_model.parameters() if p.requires_grad]
+            with torch.no_grad():
+                for p, s in zip(params, ema["shadow_params"]):
+                    p.copy_(s.to(p.device))
+
+    # ---------------------------------------------------------------- sampling entry
+    def run_relaxations(self, batches: Optional[Iterable] = None):
+        """``--mode run-relaxations`` (reference :750-813): for every batch of the relax loader not
+        already finished on disk, run the diffusion sampler.  Returns the list of sampled batches."""
+        self.model.eval()
+        task = self.config["task"]
+        params = self.config["optim"].get("denoising_pos_params", {})
+        traj_dir = task.get("relax_opt", {}).get("traj_dir", None)
+        out = []
+        for batch in (batches if batches is not None else self.relax_loader):
+            if check_traj_files(batch, traj_dir):
+                logging.info(f"Skipping batch: {batch.sid}")
+                continue
+            out.append(
+                ml_diffuse(
+                    batch=batch, model=self, denoising_pos_params=params, traj_dir=traj_dir,
+                    save_full_traj=task.get("save_full_traj", True), device=str(self.device),
+                    transform=None,
+                )
+            )
+        return out

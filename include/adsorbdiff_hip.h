@@ -1,0 +1,191 @@
+/*
+ * adsorbdiff_hip.h — C ABI of libadsorbdiff_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the denoising-diffusion sampling hot path of AdsorbDiff.
+ * The reference has no FFI of its own (it is pure Python on top of PyTorch /
+ * torch_scatter); each entry point below replaces the Python-level interface
+ * named in its comment (paths relative to the reference tree).  The Python
+ * binding that a maintainer adds is a ctypes stub — see INTEGRATION.md and
+ * adsorbdiff_amd/lib.py.
+ *
+ * Conventions
+ *   - every function returns an int32 status: ADF_OK, or an ADF_E* code; the
+ *     message of the last failure on the calling thread is adf_last_error().
+ *     ADF_EOOM is what the host shim turns into RuntimeError so that
+ *     ml_diffuse's split-the-batch-and-retry contract keeps working
+ *     (relaxation/ml_relaxation.py:146-165); ADF_ENONEIGHBOR becomes the
+ *     ValueError of painn_denoising.py:370-375.
+ *   - all array arguments are caller-owned DEVICE pointers, row-major, float32
+ *     or int32 as named; `stream` is a hipStream_t passed as void*.
+ *   - a handle is bound to the device that was current at adf_painn_create and
+ *     is NOT thread-safe.  Work is enqueued on `stream`; nothing synchronises
+ *     unless stated.
+ */
+#ifndef ADSORBDIFF_HIP_H
+#define ADSORBDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADF_OK 0
+#define ADF_EINVAL 1      /* invalid argument / unsupported hyper-parameter        */
+#define ADF_EOOM 2        /* device allocation failed                             */
+#define ADF_ENONEIGHBOR 3 /* an image has no neighbours (painn_denoising.py:370)  */
+#define ADF_EHIP 4        /* HIP runtime error                                    */
+#define ADF_EOVERFLOW 5   /* candidate list of one centre exceeded its capacity   */
+
+typedef struct adf_painn* adf_painn_t;
+
+/* Hyper-parameters of the PaiNN denoiser: the constructor arguments of
+ * adsorbdiff.models.painn.painn_denoising.PaiNN (painn_denoising.py:57-81)
+ * that reach the arithmetic. */
+typedef struct {
+    int32_t hidden_channels;   /* H, multiple of 64                              */
+    int32_t num_layers;
+    int32_t num_rbf;           /* R, even, <= 128                                */
+    int32_t num_elements;      /* rows of the atom embedding table               */
+    int32_t max_neighbors;     /* K of the strict top-K neighbour cap, <= 128    */
+    int32_t envelope_exponent; /* p of the polynomial envelope                   */
+    int32_t num_heads;         /* 2 when so3_denoising else 1                    */
+    float cutoff;              /* Angstrom                                       */
+} adf_painn_hparams;
+
+/* Order of the weight table handed to adf_painn_set_weights (all float32,
+ * torch.nn.Linear layout [out, in]; names are the reference state_dict keys):
+ *   0  atom_emb.embeddings.weight              [num_elements, H]
+ *   1  radial_basis.rbf.offset                 [R]
+ *   then per layer l (13 entries, base 2 + 13*l):
+ *    +0  message_layers.l.x_layernorm.weight   [H]
+ *    +1  message_layers.l.x_layernorm.bias     [H]
+ *    +2  message_layers.l.x_proj.0.weight      [H, H]
+ *    +3  message_layers.l.x_proj.0.bias        [H]
+ *    +4  message_layers.l.x_proj.2.weight      [3H, H]
+ *    +5  message_layers.l.x_proj.2.bias        [3H]
+ *    +6  message_layers.l.rbf_proj.weight      [3H, R]
+ *    +7  message_layers.l.rbf_proj.bias        [3H]
+ *    +8  update_layers.l.vec_proj.weight       [2H, H]
+ *    +9  update_layers.l.xvec_proj.0.weight    [H, 2H]
+ *    +10 update_layers.l.xvec_proj.0.bias      [H]
+ *    +11 update_layers.l.xvec_proj.2.weight    [3H, H]
+ *    +12 update_layers.l.xvec_proj.2.bias      [3H]
+ *   then per head h in {out_forces, out_forces2}, per block b in {0,1} (6 entries):
+ *    +0 output_network.b.vec1_proj.weight  +1 vec2_proj.weight
+ *    +2 update_net.0.weight  +3 update_net.0.bias  +4 update_net.2.weight  +5 update_net.2.bias
+ */
+#define ADF_WEIGHTS_PER_LAYER 13
+#define ADF_WEIGHTS_PER_HEAD 12
+
+/* Replaces constructing the model (painn_denoising.py:57-148). */
+int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* out);
+int32_t adf_painn_destroy(adf_painn_t h);
+
+/* (Re)bind the weights.  Pointers are device pointers that stay owned by the
+ * caller and must outlive their use; rbf_proj is re-packed into the library's
+ * own layout.  scale_factors: HOST array [num_layers], the effective
+ * upd_out_scalar_scale_l multipliers (1.0 when unfitted; scale_factor.py:166). */
+int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const void* const* weights,
+                              const float* scale_factors, void* stream);
+
+/* Describes one batch of independent adsorbate+slab systems (the fields of the
+ * PyG Batch the reference's forward reads).  All device. */
+typedef struct {
+    int32_t num_systems;          /* B                                            */
+    int32_t num_atoms;            /* N                                            */
+    const float* pos;             /* [N,3]                                        */
+    const float* cell;            /* [B,3,3]  rows = lattice vectors              */
+    const int32_t* atomic_numbers;/* [N]                                          */
+    const int32_t* batch;         /* [N] system index, non-decreasing             */
+    const int32_t* atom_offset;   /* [B+1] prefix sum of natoms                   */
+    int32_t reps[3];              /* periodic images per lattice direction (host) */
+} adf_batch;
+
+/* Replaces BaseModel.generate_graph + PaiNN.generate_graph_values
+ * (models/base.py:33-123, painn_denoising.py:353-400): periodic radius graph,
+ * strict top-K, symmetrisation.  The graph stays in the handle.  *num_edges
+ * (HOST, may be NULL) forces a stream sync when non-NULL. */
+int32_t adf_graph_build(adf_painn_t h, const adf_batch* b, void* stream, int64_t* num_edges);
+
+/* Read the device-side error flags of the last graph build (candidate overflow,
+ * empty image).  Synchronises the stream.  adf_painn_forward does not check
+ * them itself so that a sampling loop stays free of host round trips. */
+int32_t adf_check_flags(adf_painn_t h, void* stream);
+
+/* Copy the handle's current graph out (parity tests).  Directed top-K stage in
+ * the reference's candidate order: nbr_count[N], nbr_src[N*K], nbr_shift[N*K*3].
+ * Symmetrised stage (grouped by target, order within a group unspecified):
+ * edge_src/edge_dst [cap], edge_dist [cap], edge_vec [cap*3]; returns E in
+ * *num_edges.  Any pointer may be NULL.  Synchronises the stream. */
+int32_t adf_graph_export(adf_painn_t h, int32_t* nbr_count, int32_t* nbr_src, int32_t* nbr_shift,
+                         int64_t edge_capacity, int32_t* edge_src, int32_t* edge_dst, float* edge_dist,
+                         float* edge_vec, int64_t* num_edges, void* stream);
+
+/* Replaces PaiNN.forward(data) (painn_denoising.py:402-481): graph build + 6
+ * message/update layers + the two gated-equivariant heads.  f1,f2: [N,3]
+ * (f2 may be NULL when num_heads == 1). */
+int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f1, float* f2, void* stream);
+
+/* Unit-testable pieces of the forward on the handle's current graph
+ * (PaiNNMessage.forward, painn_denoising.py:530-567, fused with the residual
+ * of :443-445):  x_out = (x + dx)/sqrt2 [N,H],  vec_out = vec + dvec [N,3,H]. */
+int32_t adf_painn_message_layer(adf_painn_t h, int32_t layer, int32_t num_atoms, const float* x,
+                                const float* vec, float* x_out, float* vec_out, void* stream);
+/* PaiNNUpdate.forward + residual + ScaleFactor (painn_denoising.py:447-451,601-623), in place. */
+int32_t adf_painn_update_layer(adf_painn_t h, int32_t layer, int32_t num_atoms, float* x, float* vec,
+                               void* stream);
+
+/* Per-step schedule scalars, computed by the host with the reference's own
+ * 0-dim tensor arithmetic (denoising_torch.py:237-293) so that the products
+ * round exactly as there:
+ *   dcom = coef_tr * s_tr                      (+ noise_tr  * z_tr   in SDE mode)
+ *   drot = ((rot_pre * s_rot) * rot_dt) * rot_g2 (+ noise_rot * z_rot in SDE mode)
+ * ODE: coef_tr = 0.5*g_tr^2*dt, rot_pre = 0.5.  SDE: coef_tr = g_tr^2*dt, rot_pre = 1,
+ * noise_tr = g_tr*sqrt(dt), noise_rot = g_rot*sqrt(dt). */
+typedef struct {
+    float coef_tr;
+    float rot_pre;
+    float rot_dt;
+    float rot_g2;
+    float noise_tr;
+    float noise_rot;
+} adf_step_coef;
+
+/* Replaces the initial random placement (denoising_torch.py:215-232).
+ * noise: [B,3] uniform [0,1) drawn by the host from the CPU generator. */
+int32_t adf_sde_init_placement(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                               const float* noise, void* stream);
+
+/* Replaces one iteration of Denoiser.reverse_sde_sampling_rot after the model
+ * call (denoising_torch.py:263-353 incl. DiffTorchCalc :491-500): zero f2 on
+ * fixed atoms, per-system adsorbate means, ODE/SDE update, COM wrap, rigid
+ * rotation+translation of the adsorbate, cumulative early-stop counter.
+ * z_tr,z_rot: [B,3] standard normals (SDE only, else NULL).  state: device
+ * int32[4] = {cumulative converged-step count, frozen flag, all-converged flag
+ * of the step in flight, steps applied}; the caller initialises it to
+ * {0,0,1,0}.  Once the count reaches `early_stop_count` (>0) that step and all
+ * later ones leave pos untouched, which is the reference's `break`
+ * (denoising_torch.py:312-320).  dcom,drot: optional [B,3] outputs. */
+int32_t adf_sde_step(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                     const int32_t* fixed, const float* f1, const float* f2, const adf_step_coef* coef,
+                     const float* z_tr, const float* z_rot, int32_t early_stop_count, int32_t* state,
+                     float* dcom, float* drot, void* stream);
+
+/* Counters of the last adf_painn_forward: algorithmic bytes of the message
+ * kernel, dense FLOPs, padded/real edge rows (bench.py roofline). */
+typedef struct {
+    int64_t num_edges;
+    int64_t num_atoms;
+    int64_t message_bytes_per_layer;  /* SURVEY.md §8d formula on the real E, N */
+    int64_t dense_flops;              /* node + edge GEMM flops of one forward  */
+} adf_counters;
+int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream);
+
+const char* adf_last_error(void);
+const char* adf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADSORBDIFF_HIP_H */

@@ -240,23 +240,30 @@ def main():
                                          params, noise, record=rec)
         return pos, rec
 
-    # amplify the two heads so the per-step updates are O(0.1 A) and the wrap/rotation paths are exercised
-    with torch.no_grad():
-        for head in (ref_s.out_forces, ref_s.out_forces2):
-            head.output_network[1].update_net[2].weight.mul_(100.0)
-            head.output_network[1].update_net[2].bias.add_(0.2)
-    sd_s2 = {k: v.clone() for k, v in ref_s.state_dict().items()}
-    for mode, ode, T, nb_, seed in (("ode5", True, 5, 4, 123), ("sde3", False, 3, 3, 321), ("ode_early", True, 40, 1, 7)):
+    # Head gain per fixture.  ode5/sde3: large scores (raw |dcom| of tens of A at sigma=10, wrapped
+    # into the cell, rotations of several rad) -> exercises wrap + rotation, but free-running
+    # trajectories are chaotic, so tests use them step by step (teacher forcing on pos_log).
+    # ode8: mild scores (|dcom| <~ 0.5 A per step) -> end-to-end trajectory comparison.
+    # ode_early: tiny scores -> |dcom| < 1e-3 from the first step -> cumulative early stop at 10.
+    base_sd = {k: v.clone() for k, v in ref_s.state_dict().items()}
+
+    def set_gain(gain, bias):
+        ref_s.load_state_dict(base_sd)
+        with torch.no_grad():
+            for head in (ref_s.out_forces, ref_s.out_forces2):
+                head.output_network[1].update_net[2].weight.mul_(gain)
+                head.output_network[1].update_net[2].bias.mul_(gain).add_(bias)
+        return {k: v.clone() for k, v in ref_s.state_dict().items()}
+
+    for mode, ode, T, nb_, seed, gain, bias in (
+        ("ode5", True, 5, 4, 123, 100.0, 0.2),
+        ("sde3", False, 3, 3, 321, 100.0, 0.2),
+        ("ode8", True, 8, 4, 99, 0.2, 0.0),
+        ("ode_early", True, 40, 1, 7, 1e-2, 0.0),
+    ):
         params = dict(num_steps=T, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=ode)
-        sdx = sd_s2
+        sdx = set_gain(gain, bias)
         model = ref_s
-        if mode == "ode_early":
-            # tiny scores -> |dcom|<1e-3 from the first step -> cumulative early stop after 10 steps
-            with torch.no_grad():
-                for head in (ref_s.out_forces, ref_s.out_forces2):
-                    head.output_network[1].update_net[2].weight.mul_(1e-4)
-                    head.output_network[1].update_net[2].bias.mul_(1e-4)
-            sdx = {k: v.clone() for k, v in ref_s.state_dict().items()}
         bt = make_batch(nb_, n_slab=36, n_ads=4, seed=50 + nb_)
         pos_in = bt.pos.clone()
         pos_r, log_r = run_ref(bt.clone(), params, seed, model)
@@ -267,7 +274,10 @@ def main():
               "per-step", ["%.1e" % e for e in step_err[:6]],
               "max|dcom|=%.2f max|drot|=%.2f" % (max(r["dcom"].abs().max().item() for r in rec_o),
                                                  max(r["drot"].abs().max().item() for r in rec_o)))
-        assert step_err[0] < 5e-6 and err < 2e-4, (step_err, err)
+        chaotic = mode in ("ode5", "sde3")  # free-running drift is amplification of 1e-7 rounding there
+        assert step_err[0] < 5e-6 and err < (5e-3 if chaotic else 2e-5), (step_err, err)
+        if mode == "ode8":
+            assert 0.05 < max(r["dcom"].abs().max().item() for r in rec_o) < 1.5
         if mode == "ode_early":
             assert len(log_r) == 10 and len(rec_o) == 9, (len(log_r), len(rec_o))
         fxs = dict(pos_in=pos_in, pos_final=pos_r, pos_log=torch.stack(log_r), num_steps=T, ode=int(ode), seed=seed,
