@@ -19,6 +19,58 @@ void adf_set_error(const char* fmt, ...) {
 extern "C" const char* adf_last_error(void) { return g_err; }
 extern "C" const char* adf_version(void) { return "adsorbdiff_hip 0.1.0 (gfx950)"; }
 
+// ---- HIP-event profiling: pairs of events on the launch stream around kernel groups
+void adf_prof_begin(adf_painn* h, int cat, hipStream_t s) {
+    if (!h->prof_on) return;
+    if (h->prof_used + 2 > h->prof_ev->size()) {
+        for (int i = 0; i < 512; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            h->prof_ev->push_back(e);
+        }
+    }
+    h->prof_cat->push_back(cat);
+    (void)hipEventRecord((*h->prof_ev)[h->prof_used], s);
+    h->prof_used += 1;
+}
+void adf_prof_end(adf_painn* h, hipStream_t s) {
+    if (!h->prof_on || (h->prof_used & 1) == 0) return;
+    (void)hipEventRecord((*h->prof_ev)[h->prof_used], s);
+    h->prof_used += 1;
+}
+
+extern "C" int32_t adf_profile_enable(adf_painn_t h, int32_t on) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    h->prof_on = on != 0;
+    h->prof_used = 0;
+    h->prof_cat->clear();
+    ADF_HIP_CHECK(hipMemset(h->kcount, 0, sizeof(unsigned long long)));
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, int64_t* message_ksteps, void* stream) {
+    if (!h || !ms || !count) { adf_set_error("null argument"); return ADF_EINVAL; }
+    ADF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    if (message_ksteps) {
+        unsigned long long k = 0;
+        ADF_HIP_CHECK(hipMemcpy(&k, h->kcount, sizeof(k), hipMemcpyDeviceToHost));
+        ADF_HIP_CHECK(hipMemset(h->kcount, 0, sizeof(k)));
+        *message_ksteps = (int64_t)k;
+    }
+    for (int c = 0; c < ADF_PROF_NCAT; ++c) { ms[c] = 0.f; count[c] = 0; }
+    const size_t pairs = h->prof_used / 2;
+    for (size_t i = 0; i < pairs; ++i) {
+        float t = 0.f;
+        ADF_HIP_CHECK(hipEventElapsedTime(&t, (*h->prof_ev)[2 * i], (*h->prof_ev)[2 * i + 1]));
+        const int c = (*h->prof_cat)[i];
+        ms[c] += t;
+        count[c] += 1;
+    }
+    h->prof_used = 0;
+    h->prof_cat->clear();
+    return ADF_OK;
+}
+
 template <typename T>
 static int32_t dev_alloc(T** p, size_t count) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -55,6 +107,8 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     if (!h) { adf_set_error("host allocation failed"); return ADF_EOOM; }
     memset(h, 0, sizeof(*h));
     h->hp = *hp;
+    h->prof_ev = new std::vector<hipEvent_t>();
+    h->prof_cat = new std::vector<int>();
     ADF_HIP_CHECK(hipGetDevice(&h->device));
     hipDeviceProp_t prop;
     ADF_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
@@ -63,18 +117,21 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     int32_t st = dev_alloc(&h->rbf_pack, (size_t)L * (H / ADF_SLICE_CH) * R * 192);
     if (st == ADF_OK) st = dev_alloc(&h->rbf_bias_pack, (size_t)L * (H / ADF_SLICE_CH) * 192);
     if (st == ADF_OK) st = dev_alloc(&h->flags, 4);
+    if (st == ADF_OK) st = dev_alloc(&h->kcount, 1);
+    if (st == ADF_OK && hipMemset(h->kcount, 0, sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;
     if (st != ADF_OK) { adf_painn_destroy(h); return st; }
     *out = h;
     return ADF_OK;
 }
 
 static void free_workspaces(adf_painn* h) {
-    void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->gcount, h->gptr, h->gcursor, h->e_meta, h->e_geom,
-                    h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys};
+    void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
+                    h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    h->nbr_cnt = h->nbr_src = h->nbr_shift = h->gcount = h->gptr = h->gcursor = nullptr;
-    h->e_meta = nullptr; h->e_geom = nullptr;
+    h->nbr_cnt = h->nbr_src = h->nbr_shift = h->deg = h->nptr = h->cursor = h->img_cnt = h->e_src = nullptr;
+    h->scan_tmp = nullptr; h->scan_tmp_bytes = 0;
+    h->e_geom = nullptr;
     h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = nullptr;
     h->capN = h->capB = h->capE = 0;
 }
@@ -85,6 +142,9 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->rbf_pack) (void)hipFree(h->rbf_pack);
     if (h->rbf_bias_pack) (void)hipFree(h->rbf_bias_pack);
     if (h->flags) (void)hipFree(h->flags);
+    if (h->kcount) (void)hipFree(h->kcount);
+    if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
+    delete h->prof_cat;
     delete h;
     return ADF_OK;
 }
@@ -131,7 +191,6 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
     ADF_HIP_CHECK(hipDeviceSynchronize());
     free_workspaces(h);
     const int64_t H = h->hp.hidden_channels, K = h->hp.max_neighbors;
-    const int64_t G = (capN + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
     // symmetrised edges: every directed top-K entry (j -> i) survives at most once (j < i, or a
     // self image with a negative shift) and is then doubled: E <= 2*N*K.
     const int64_t capE = 2 * capN * K;
@@ -140,21 +199,34 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
     ALLOC(nbr_cnt, capN);
     ALLOC(nbr_src, capN * K);
     ALLOC(nbr_shift, capN * K);
-    ALLOC(gcount, G + 1);
-    ALLOC(gptr, G + 1);
-    ALLOC(gcursor, G + 1 + capB);
-    ALLOC(e_meta, capE);
+    ALLOC(deg, capN + 1);
+    ALLOC(nptr, capN + 1);
+    ALLOC(cursor, capN);
+    ALLOC(img_cnt, capB);
+    ALLOC(e_src, capE);
     ALLOC(e_geom, capE);
+    if (st == ADF_OK) {
+        h->scan_tmp_bytes = adf_scan_temp_bytes(capN + 1);
+        unsigned char* tmp = nullptr;
+        st = dev_alloc(&tmp, h->scan_tmp_bytes + 16);
+        h->scan_tmp = tmp;
+    }
     ALLOC(x, capN * H);
-    ALLOC(vecA, capN * 3 * H);
-    ALLOC(vecB, capN * 3 * H);
+    ALLOC(vecA, (capN + 1) * 3 * H);
+    ALLOC(vecB, (capN + 1) * 3 * H);
     ALLOC(y, capN * H);
-    ALLOC(xh, capN * 3 * H);
+    ALLOC(xh, (capN + 1) * 3 * H);   // + one all-zero row: gather target of padded edge rows
     ALLOC(vv, capN * 6 * H);
     ALLOC(cat, capN * 2 * H);
     ALLOC(dot, capN * H);
     ALLOC(sys, capB * 16);
 #undef ALLOC
+    if (st == ADF_OK) {
+        hipError_t e1 = hipMemset(h->vecA, 0, sizeof(float) * (size_t)(capN + 1) * 3 * H);
+        hipError_t e2 = hipMemset(h->vecB, 0, sizeof(float) * (size_t)(capN + 1) * 3 * H);
+        hipError_t e3 = hipMemset(h->xh, 0, sizeof(float) * (size_t)(capN + 1) * 3 * H);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) st = ADF_EHIP;
+    }
     if (st != ADF_OK) { free_workspaces(h); return st; }
     h->capN = capN; h->capB = capB; h->capE = capE;
     return ADF_OK;
@@ -185,23 +257,22 @@ extern "C" int32_t adf_graph_build(adf_painn_t h, const adf_batch* b, void* stre
     hipStream_t s = (hipStream_t)stream;
     ADF_TRY(adf_graph_build_impl(h, b, s));
     if (num_edges) {
-        const int G = (b->num_atoms + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
         int32_t e = 0;
-        ADF_HIP_CHECK(hipMemcpyAsync(&e, h->gptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        ADF_HIP_CHECK(hipMemcpyAsync(&e, h->nptr + b->num_atoms, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         ADF_TRY(read_flags(h, s));
         *num_edges = e;
     }
     return ADF_OK;
 }
 
-__global__ void adf_export_edges_kernel(const int32_t* gptr, const adf_edge_meta* em, const float4* eg, int G,
+__global__ void adf_export_edges_kernel(const int32_t* nptr, const int32_t* e_src, const float4* eg, int N,
                                         int32_t* src, int32_t* dst, float* dist, float* vec, long long cap) {
-    const int g = blockIdx.x;
-    if (g >= G) return;
-    for (int e = gptr[g] + threadIdx.x; e < gptr[g + 1]; e += blockDim.x) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    for (int e = nptr[n] + (threadIdx.x & 63); e < nptr[n + 1]; e += 64) {
         if (e >= cap) continue;
-        if (src) src[e] = em[e].src;
-        if (dst) dst[e] = g * ADF_GROUP_NODES + em[e].dstl;
+        if (src) src[e] = e_src[e];
+        if (dst) dst[e] = n;
         const float4 q = eg[e];
         if (dist) dist[e] = q.w;
         if (vec) { vec[3 * (size_t)e] = q.x; vec[3 * (size_t)e + 1] = q.y; vec[3 * (size_t)e + 2] = q.z; }
@@ -225,20 +296,29 @@ extern "C" int32_t adf_graph_export(adf_painn_t h, int32_t* nbr_count, int32_t* 
     if (!h || h->lastN <= 0) { adf_set_error("no graph built"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const int64_t N = h->lastN, K = h->hp.max_neighbors;
-    const int G = (int)((N + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES);
     if (nbr_count) ADF_HIP_CHECK(hipMemcpyAsync(nbr_count, h->nbr_cnt, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, s));
     if (nbr_src) ADF_HIP_CHECK(hipMemcpyAsync(nbr_src, h->nbr_src, sizeof(int32_t) * N * K, hipMemcpyDeviceToDevice, s));
     if (nbr_shift)
         hipLaunchKernelGGL(adf_export_shift_kernel, dim3((unsigned)((N * K + 255) / 256)), dim3(256), 0, s, h->nbr_shift,
                            nbr_shift, (long long)(N * K), h->last_reps[0], h->last_reps[1], h->last_reps[2]);
     if (edge_src || edge_dst || edge_dist || edge_vec)
-        hipLaunchKernelGGL(adf_export_edges_kernel, dim3(G), dim3(256), 0, s, h->gptr, h->e_meta, h->e_geom, G, edge_src,
-                           edge_dst, edge_dist, edge_vec, (long long)edge_capacity);
+        hipLaunchKernelGGL(adf_export_edges_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, h->nptr, h->e_src,
+                           h->e_geom, (int)N, edge_src, edge_dst, edge_dist, edge_vec, (long long)edge_capacity);
     ADF_HIP_CHECK(hipGetLastError());
     int32_t e = 0;
-    ADF_HIP_CHECK(hipMemcpyAsync(&e, h->gptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(&e, h->nptr + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     ADF_HIP_CHECK(hipStreamSynchronize(s));
     if (num_edges) *num_edges = e;
+    return ADF_OK;
+}
+
+// Row N of xh / vecA / vecB is the all-zero gather target of padded edge rows (message.hip); rows
+// beyond the current N may hold data of an earlier, larger batch, so it is re-zeroed per forward.
+static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
+    const size_t row = (size_t)3 * h->hp.hidden_channels;
+    ADF_HIP_CHECK(hipMemsetAsync(h->xh + (size_t)N * row, 0, sizeof(float) * row, s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->vecA + (size_t)N * row, 0, sizeof(float) * row, s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->vecB + (size_t)N * row, 0, sizeof(float) * row, s));
     return ADF_OK;
 }
 
@@ -247,20 +327,28 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
     const int H = h->hp.hidden_channels;
     const adf_layer_weights& w = h->layer[l];
     // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
+    adf_prof_begin(h, ADF_PROF_NODE, s);
     ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
     ADF_TRY(adf_launch_gemm(h->y, H, w.xp0_w, H, w.xp0_b, h->cat, H, N, H, H, 1, s));
     ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
-    return adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, s);
+    adf_prof_end(h, s);
+    adf_prof_begin(h, ADF_PROF_MESSAGE, s);
+    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, s);
+    adf_prof_end(h, s);
+    return st;
 }
 
 static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hipStream_t s) {
     const int H = h->hp.hidden_channels;
     const adf_layer_weights& w = h->layer[l];
+    adf_prof_begin(h, ADF_PROF_NODE, s);
     ADF_TRY(adf_launch_gemm(vec, H, w.vp_w, H, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
     ADF_TRY(adf_nodewise_update_prep(h->vv, x, h->cat, h->dot, N, H, s));
     ADF_TRY(adf_launch_gemm(h->cat, 2 * H, w.xv0_w, 2 * H, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
     ADF_TRY(adf_launch_gemm(h->y, H, w.xv2_w, H, w.xv2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
-    return adf_nodewise_update_apply(h->xh, h->dot, h->vv, x, vec, h->scale[l], N, H, s);
+    const int32_t st = adf_nodewise_update_apply(h->xh, h->dot, h->vv, x, vec, h->scale[l], N, H, s);
+    adf_prof_end(h, s);
+    return st;
 }
 
 extern "C" int32_t adf_painn_message_layer(adf_painn_t h, int32_t layer, int32_t N, const float* x, const float* vec,
@@ -269,7 +357,14 @@ extern "C" int32_t adf_painn_message_layer(adf_painn_t h, int32_t layer, int32_t
         adf_set_error("message_layer: bad handle/layer, or N differs from the built graph");
         return ADF_EINVAL;
     }
-    return message_layer(h, layer, N, x, vec, x_out, vec_out, (hipStream_t)stream);
+    // the kernel gathers row N of `vec` for padded edge rows: run on the internal (N+1)-row buffers
+    hipStream_t s = (hipStream_t)stream;
+    const size_t bytes = sizeof(float) * (size_t)N * 3 * h->hp.hidden_channels;
+    ADF_TRY(zero_pad_rows(h, N, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->vecA, vec, bytes, hipMemcpyDeviceToDevice, s));
+    ADF_TRY(message_layer(h, layer, N, x, h->vecA, x_out, h->vecB, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(vec_out, h->vecB, bytes, hipMemcpyDeviceToDevice, s));
+    return ADF_OK;
 }
 
 extern "C" int32_t adf_painn_update_layer(adf_painn_t h, int32_t layer, int32_t N, float* x, float* vec, void* stream) {
@@ -288,7 +383,10 @@ extern "C" int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f
     hipStream_t s = (hipStream_t)stream;
     const int N = b->num_atoms;
     ADF_TRY(ensure_capacity(h, N, b->num_systems));
+    adf_prof_begin(h, ADF_PROF_GRAPH, s);
     ADF_TRY(adf_graph_build_impl(h, b, s));
+    adf_prof_end(h, s);
+    ADF_TRY(zero_pad_rows(h, N, s));
     ADF_TRY(adf_nodewise_embed(h, b->atomic_numbers, N, h->x, h->vecA, s));
     float* vin = h->vecA;
     float* vout = h->vecB;
@@ -297,8 +395,10 @@ extern "C" int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f
         ADF_TRY(update_layer(h, l, N, h->x, vout, s));
         float* t = vin; vin = vout; vout = t;
     }
+    adf_prof_begin(h, ADF_PROF_HEADS, s);
     ADF_TRY(adf_head_forward(h, 0, N, h->x, vin, f1, s));
     if (h->hp.num_heads == 2) ADF_TRY(adf_head_forward(h, 1, N, h->x, vin, f2, s));
+    adf_prof_end(h, s);
     return ADF_OK;
 }
 
@@ -321,17 +421,19 @@ extern "C" int32_t adf_sde_step(adf_painn_t h, const adf_batch* b, float* pos, c
     ADF_TRY(check_batch(h, b));
     if (!pos || !tags || !f1 || !f2 || !coef || !state) { adf_set_error("null argument"); return ADF_EINVAL; }
     ADF_TRY(ensure_capacity(h, b->num_atoms, b->num_systems));
-    return adf_stepper_step(h, b, pos, tags, fixed, f1, f2, coef, z_tr, z_rot, early_stop_count, state, dcom, drot,
-                            (hipStream_t)stream);
+    adf_prof_begin(h, ADF_PROF_STEPPER, (hipStream_t)stream);
+    const int32_t st = adf_stepper_step(h, b, pos, tags, fixed, f1, f2, coef, z_tr, z_rot, early_stop_count, state,
+                                        dcom, drot, (hipStream_t)stream);
+    adf_prof_end(h, (hipStream_t)stream);
+    return st;
 }
 
 extern "C" int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream) {
     if (!h || !out || h->lastN <= 0) { adf_set_error("no forward has run"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const int64_t N = h->lastN, H = h->hp.hidden_channels, R = h->hp.num_rbf, L = h->hp.num_layers;
-    const int G = (int)((N + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES);
     int32_t e = 0;
-    ADF_HIP_CHECK(hipMemcpyAsync(&e, h->gptr + G, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(&e, h->nptr + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     ADF_HIP_CHECK(hipStreamSynchronize(s));
     const int64_t E = e;
     out->num_edges = E;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/adsorbdiff_hip.h"
 
@@ -39,12 +40,6 @@ struct adf_block_weights {
     const float *vec1_w, *vec2_w, *un0_w, *un0_b, *un2_w, *un2_b;
 };
 
-// packed edge record, grouped by target-node group (see graph.hip)
-struct adf_edge_meta {
-    int32_t src;    // global source atom
-    int32_t dstl;   // target atom index inside its group (0..ADF_GROUP_NODES-1)
-};
-
 struct adf_painn {
     adf_painn_hparams hp;
     int device;
@@ -65,11 +60,14 @@ struct adf_painn {
     int32_t* nbr_cnt;    // [N]
     int32_t* nbr_src;    // [N*K]
     int32_t* nbr_shift;  // [N*K]  index into the lexicographic shift table
-    int32_t* gcount;     // [G+1] edges per target group
-    int32_t* gptr;       // [G+1] exclusive scan
-    int32_t* gcursor;    // [G]
-    adf_edge_meta* e_meta;  // [capE]
-    float4* e_geom;         // [capE] (ux,uy,uz,d): unit vector target->source, distance
+    int32_t* deg;        // [N+1] in-degree per target atom (symmetrised graph)
+    int32_t* nptr;       // [N+1] exclusive scan = CSR row pointer over targets
+    int32_t* cursor;     // [N]   fill cursors
+    int32_t* img_cnt;    // [B]   directed edges per image (empty-image check)
+    void* scan_tmp;      // hipcub scan workspace
+    size_t scan_tmp_bytes;
+    int32_t* e_src;      // [capE] source atom of every edge, grouped by target, sorted by distance
+    float4* e_geom;      // [capE] (ux,uy,uz,d): unit vector target->source, distance
     int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}
     float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
     float *hx, *hv, *hcat, *hy, *hv2;                  // head buffers
@@ -78,12 +76,23 @@ struct adf_painn {
     int64_t lastN, lastB;
     int32_t last_reps[3];
     int num_cus;
+    // ---- optional HIP-event profiling of the forward (bench.py roofline); see api.hip
+    bool prof_on;
+    std::vector<hipEvent_t>* prof_ev;     // pool of events, used pairwise
+    std::vector<int>* prof_cat;           // category of every recorded pair
+    size_t prof_used;                     // events handed out
+    unsigned long long* kcount;           // device counter: executed k-steps of the message kernel
 };
+
+enum { ADF_PROF_GRAPH = 0, ADF_PROF_MESSAGE = 1, ADF_PROF_NODE = 2, ADF_PROF_HEADS = 3, ADF_PROF_STEPPER = 4 };
+void adf_prof_begin(adf_painn* h, int cat, hipStream_t s);
+void adf_prof_end(adf_painn* h, hipStream_t s);
 
 // ---- kernels' host launchers (each enqueues on `s`, returns ADF_*)
 int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                         int M, int N, int K, int act_ssilu, hipStream_t s);
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
+size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, hipStream_t s);
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);

@@ -17,9 +17,11 @@
 //      lowest candidate index.  Everything else is bit-identical: d^2 is evaluated with the
 //      reference's fp32 operation order, no FMA contraction.)  Survivors are written in
 //      candidate order, which is the reference's edge order before symmetrisation.
-//   2. count / scan / fill: the symmetrised edge list is produced directly in the layout the
-//      message kernel consumes — edges grouped by ADF_GROUP_NODES consecutive *target* atoms
-//      (a CSR over node groups), each record = (source, target-in-group) + (unit vector, d).
+//   2. count / scan / fill / sort: the symmetrised edge list is produced directly in the layout the
+//      message kernel consumes — a CSR over *target* atoms (nptr[N+1]), each record = source index
+//      + (unit vector target->source, d), every target's edges ordered by distance.
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 struct GraphParams {
@@ -136,7 +138,7 @@ __device__ __forceinline__ bool edge_kept(int j, int i, int c, int r0, int r1, i
     return (sa < 0.f) || (sa == 0.f && sb < 0.f) || (sa == 0.f && sb == 0.f && sc < 0.f);
 }
 
-__global__ void adf_count_kernel(GraphParams p, int32_t* gcount) {
+__global__ void adf_count_kernel(GraphParams p, int32_t* deg) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = (int)(t / p.K);
     const int k = (int)(t - (long long)i * p.K);
@@ -144,45 +146,19 @@ __global__ void adf_count_kernel(GraphParams p, int32_t* gcount) {
     const int j = p.nbr_src[(size_t)i * p.K + k];
     const int c = p.nbr_shift[(size_t)i * p.K + k];
     if (!edge_kept(j, i, c, p.r0, p.r1, p.r2)) return;
-    atomicAdd(&gcount[i / ADF_GROUP_NODES], 1);
-    atomicAdd(&gcount[j / ADF_GROUP_NODES], 1);
+    atomicAdd(&deg[i], 1);
+    atomicAdd(&deg[j], 1);
 }
 
-// single-block exclusive scan over the group counts; also validates capacities / empty images
-__global__ __launch_bounds__(1024) void adf_scan_kernel(const int32_t* gcount, int32_t* gptr, int32_t* gcursor,
-                                                         int G, long long capE, const int32_t* img_cnt, int B,
-                                                         int32_t* flags) {
-    __shared__ int32_t s_part[1024];
-    __shared__ int32_t s_carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < G; base += 1024) {
-        const int idx = base + tid;
-        const int v = idx < G ? gcount[idx] : 0;
-        s_part[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int add = tid >= off ? s_part[tid - off] : 0;
-            __syncthreads();
-            s_part[tid] += add;
-            __syncthreads();
-        }
-        const int incl = s_part[tid] + s_carry;
-        if (idx < G) { gptr[idx] = incl - v; gcursor[idx] = incl - v; }
-        __syncthreads();
-        if (tid == 1023) s_carry = incl;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        gptr[G] = s_carry;
-        if ((long long)s_carry > capE) atomicExch(&flags[2], 1);
-    }
-    for (int b = tid; b < B; b += 1024)
-        if (img_cnt[b] == 0) atomicExch(&flags[1], 1);
+// validates capacities / empty images after the scan
+__global__ void adf_validate_kernel(const int32_t* nptr, int N, long long capE, const int32_t* img_cnt, int B,
+                                    int32_t* flags) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && (long long)nptr[N] > capE) atomicExch(&flags[2], 1);
+    if (t < B && img_cnt[t] == 0) atomicExch(&flags[1], 1);
 }
 
-__global__ void adf_fill_kernel(GraphParams p, int32_t* gcursor, adf_edge_meta* e_meta, float4* e_geom,
+__global__ void adf_fill_kernel(GraphParams p, const int32_t* nptr, int32_t* cursor, int32_t* e_src, float4* e_geom,
                                 long long capE) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = (int)(t / p.K);
@@ -202,47 +178,89 @@ __global__ void adf_fill_kernel(GraphParams p, int32_t* gcursor, adf_edge_meta* 
     const float vy = __fadd_rn(__fsub_rn(p.pos[3 * j + 1], p.pos[3 * i + 1]), oy);
     const float vz = __fadd_rn(__fsub_rn(p.pos[3 * j + 2], p.pos[3 * i + 2]), oz);
     float d = sqrtf(fmaf(vz, vz, fmaf(vy, vy, vx * vx)));
-    if (d == 0.f) return;  // utils.py:536-540 (unreachable after the d^2 > 1e-4 filter; counted edges stay padded)
+    // utils.py:536-540 drops d == 0 edges: unreachable after the d^2 > 1e-4 filter, so not handled
     if (fabsf(d) <= 1.0e-3f) d = 1.0e-3f;  // painn_denoising.py:366-367
     const float ux = vx / d, uy = vy / d, uz = vz / d;
-    // edge j -> i, stored in the group of its target i
-    int slot = atomicAdd(&gcursor[i / ADF_GROUP_NODES], 1);
-    if (slot < capE) {
-        e_meta[slot] = adf_edge_meta{j, i % ADF_GROUP_NODES};
-        e_geom[slot] = make_float4(ux, uy, uz, d);
-    }
+    // edge j -> i, stored in the segment of its target i
+    long long slot = (long long)nptr[i] + atomicAdd(&cursor[i], 1);
+    if (slot < capE) { e_src[slot] = j; e_geom[slot] = make_float4(ux, uy, uz, d); }
     // reversed copy i -> j, same distance, negated unit vector (painn_denoising.py:171-181,322-327)
-    slot = atomicAdd(&gcursor[j / ADF_GROUP_NODES], 1);
-    if (slot < capE) {
-        e_meta[slot] = adf_edge_meta{i, j % ADF_GROUP_NODES};
-        e_geom[slot] = make_float4(-ux, -uy, -uz, d);
+    slot = (long long)nptr[j] + atomicAdd(&cursor[j], 1);
+    if (slot < capE) { e_src[slot] = i; e_geom[slot] = make_float4(-ux, -uy, -uz, d); }
+}
+
+// Order every target's incoming edges by distance (ties: source index, then unit vector), one wave
+// per target.  Two reasons: (1) a 32-edge row block of the message kernel then spans a narrow band of
+// the Gaussian basis, which shrinks the k-window it has to contract over; (2) the order no longer
+// depends on the atomic cursor above, so the segmented sums are run-to-run reproducible.
+#define SORT_MAX 256
+__global__ __launch_bounds__(256) void adf_sort_edges_kernel(const int32_t* nptr, int32_t* e_src, float4* e_geom,
+                                                              int N) {
+    __shared__ float4 s_geo[4][SORT_MAX];
+    __shared__ int32_t s_src[4][SORT_MAX];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + w;
+    if (n >= N) return;
+    const int e0 = nptr[n];
+    const int deg = min(nptr[n + 1] - e0, SORT_MAX);  // deg <= 2K <= 256
+    for (int t = lane; t < deg; t += 64) { s_geo[w][t] = e_geom[e0 + t]; s_src[w][t] = e_src[e0 + t]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < deg; t += 64) {
+        const float4 g = s_geo[w][t];
+        const int sj = s_src[w][t];
+        int rank = 0;
+        for (int f = 0; f < deg; ++f) {
+            const float4 h = s_geo[w][f];
+            const int sf = s_src[w][f];
+            bool less = h.w < g.w;
+            if (h.w == g.w) {
+                if (sf != sj) less = sf < sj;
+                else if (h.x != g.x) less = h.x < g.x;
+                else if (h.y != g.y) less = h.y < g.y;
+                else less = h.z < g.z;
+            }
+            rank += less ? 1 : 0;
+        }
+        e_geom[e0 + rank] = g;
+        e_src[e0 + rank] = sj;
     }
 }
 
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
     const int N = b->num_atoms, B = b->num_systems, K = h->hp.max_neighbors;
-    const int G = (N + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
     GraphParams p;
     p.pos = b->pos; p.cell = b->cell; p.batch = b->batch; p.atom_offset = b->atom_offset;
     p.r0 = b->reps[0]; p.r1 = b->reps[1]; p.r2 = b->reps[2];
     p.rc2 = h->hp.cutoff * h->hp.cutoff;
     p.K = K; p.N = N;
     p.nbr_cnt = h->nbr_cnt; p.nbr_src = h->nbr_src; p.nbr_shift = h->nbr_shift;
-    p.img_cnt = h->gcursor + (G + 1);  // [B] scratch behind the cursors
+    p.img_cnt = h->img_cnt;
     p.flags = h->flags;
-    ADF_HIP_CHECK(hipMemsetAsync(h->gcount, 0, sizeof(int32_t) * (G + 1), s));
-    ADF_HIP_CHECK(hipMemsetAsync(p.img_cnt, 0, sizeof(int32_t) * B, s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->deg, 0, sizeof(int32_t) * (N + 1), s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->cursor, 0, sizeof(int32_t) * N, s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->img_cnt, 0, sizeof(int32_t) * B, s));
     ADF_HIP_CHECK(hipMemsetAsync(h->flags, 0, sizeof(int32_t) * 4, s));
     hipLaunchKernelGGL(adf_topk_kernel, dim3(N), dim3(256), 0, s, p);
     const long long slots = (long long)N * K;
     const unsigned nb = (unsigned)((slots + 255) / 256);
-    hipLaunchKernelGGL(adf_count_kernel, dim3(nb), dim3(256), 0, s, p, h->gcount);
-    hipLaunchKernelGGL(adf_scan_kernel, dim3(1), dim3(1024), 0, s, h->gcount, h->gptr, h->gcursor, G,
-                       (long long)h->capE, p.img_cnt, B, h->flags);
-    hipLaunchKernelGGL(adf_fill_kernel, dim3(nb), dim3(256), 0, s, p, h->gcursor, h->e_meta, h->e_geom,
+    hipLaunchKernelGGL(adf_count_kernel, dim3(nb), dim3(256), 0, s, p, h->deg);
+    size_t tmp = h->scan_tmp_bytes;
+    ADF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(h->scan_tmp, tmp, h->deg, h->nptr, N + 1, s));
+    const int vb = (max(B, 1) + 255) / 256;
+    hipLaunchKernelGGL(adf_validate_kernel, dim3(vb), dim3(256), 0, s, h->nptr, N, (long long)h->capE, h->img_cnt, B,
+                       h->flags);
+    hipLaunchKernelGGL(adf_fill_kernel, dim3(nb), dim3(256), 0, s, p, h->nptr, h->cursor, h->e_src, h->e_geom,
                        (long long)h->capE);
+    hipLaunchKernelGGL(adf_sort_edges_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->nptr, h->e_src, h->e_geom, N);
     ADF_HIP_CHECK(hipGetLastError());
     h->lastN = N; h->lastB = B;
     h->last_reps[0] = p.r0; h->last_reps[1] = p.r1; h->last_reps[2] = p.r2;
     return ADF_OK;
+}
+
+size_t adf_scan_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
+    return bytes;
 }

@@ -11,22 +11,25 @@
 //
 // MI355X mapping.  rbfh ([E,3H] fp32, 6 KB per edge) is never materialised: a persistent
 // 512-thread workgroup owns one 64-channel slice (3 x 64 = 192 columns of rbf_proj, k-major in
-// 96 KB of LDS) and walks groups of 32 consecutive target atoms.  A group's edges are cut into
-// 32-row blocks that the 8 waves pull from an LDS work counter.  Per block a wave
-//   1. builds the MFMA A operand in registers — lane (row, k) evaluates env(d_row)*exp(..) for its
-//      own k — and runs v_mfma_f32_32x32x2_f32 over 6 column blocks, but only over the k-window
-//      where some row's Gaussian is non-negligible: |k - 127 d/rc| <= 7 (dropped terms
-//      < exp(-24.5) = 2.3e-11 of the leading term, far below f32 rounding).  With the strict
-//      top-K graph binding near 5 A this cuts the 128-deep contraction to ~50;
-//   2. gathers xh[src], vec[src] for its 16 accumulator rows as float2 (the slice's column ->
-//      channel map puts channels 2q,2q+1 on lane q, so a half-wave reads 256 contiguous bytes of
-//      a source row — served by the XCD's L2: slice = blockIdx % 8 = XCD under round-robin
-//      dispatch, so one XCD only ever touches its own 64-channel columns of the node tables);
-//   3. forms the message and adds it into the group's [32 nodes][4][64] LDS accumulator with
-//      ds_add_f32 (wavefront-level segmented sum: 32 lanes of a half-wave hit 32 distinct banks).
-// After the group's blocks, x_out/vec_out rows are written once, residual fused, fully coalesced.
-// HBM traffic per layer = node tables once + 24 B per edge (vs 6 KB per edge if rbfh were
-// materialised); the roofline that binds is the f32 MFMA rate for step 1.
+// 96 KB of LDS).  Its 8 waves pull *target atoms* from an LDS work counter; one wave owns all
+// incoming edges of its target (CSR over targets, edges pre-sorted by distance), in 32-row blocks:
+//   1. the MFMA A operand is built in registers — lane (row, k) evaluates env(d_row)*exp(..) for its
+//      own k — and v_mfma_f32_32x32x2_f32 runs over 6 column blocks, but only over the k-window where
+//      some row's Gaussian is non-negligible: |k - (R-1) d/rc| <= 7 (dropped terms < exp(-24.5) =
+//      2.3e-11 of the leading term, far below f32 rounding).  Because a target's edges are sorted by
+//      distance, a 32-row block spans a narrow band and the 128-deep contraction shrinks to ~35;
+//   2. xh[src], vec[src] are gathered for the 16 accumulator rows of each lane as float2 (the
+//      slice's column -> channel map puts channels 2q,2q+1 on lane q, so a half-wave reads 256
+//      contiguous bytes of a source row, served by the XCD's L2: slice = blockIdx % 8 = XCD under
+//      round-robin dispatch, so one XCD only touches its own 64-channel columns of the node tables);
+//   3. the messages are summed in registers (wavefront segmented sum: the 16 rows of a lane, then
+//      one cross-half shuffle), and x_out / vec_out rows are written once with the residual fused.
+// No LDS atomics (ds_add_f32 measured 4x slower than the whole rest of the kernel), no barriers
+// after the weight image is staged, no zero-initialised outputs.  HBM traffic per layer = node
+// tables once + 20 B per edge (vs 6 KB per edge if rbfh were materialised); the roofline that
+// binds is the f32 MFMA rate of step 1.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -41,14 +44,16 @@ struct MsgParams {
     const float* x;
     float* x_out;
     float* vec_out;
-    const int32_t* gptr;
-    const adf_edge_meta* e_meta;
+    const int32_t* nptr;
+    const int32_t* e_src;
     const float4* e_geom;
     const float* wpack;
     const float* bpack;
     const float* mu;
     int N, H, R, G, nslices;
-    float inv_cutoff, coeff, env_a, env_b, env_c, env_p;
+    float inv_cutoff, coeff, env_a, env_b, env_c;
+    int env_pi;
+    unsigned long long* kcount;  // optional: sum over 32-row blocks of the k-window length (profiling)
 };
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -64,12 +69,11 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // carve: [R*192] weights | [192] bias | [R] mu | [32*4*64] accumulators | [8 waves][32][8] row meta | counter
+    // carve: [R*192] weights | [192] bias | [128] mu | [8 waves][32][8] row meta | work counter
     float* Wl = lds;
     float* Bl = Wl + p.R * MSG_COLS;
     float* Mu = Bl + MSG_COLS;
-    float* Acc = Mu + 128;
-    float* Meta = Acc + ADF_GROUP_NODES * 4 * 64;
+    float* Meta = Mu + 128;
     int* Ctr = reinterpret_cast<int*>(Meta + MSG_WAVES * 32 * 8);
 
     const int tid = threadIdx.x;
@@ -90,43 +94,53 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
         for (int i = tid; i < n4; i += MSG_THREADS) dst[i] = src[i];
         if (tid < MSG_COLS) Bl[tid] = p.bpack[slice * MSG_COLS + tid];
         if (tid < p.R) Mu[tid] = p.mu[tid];
+        if (tid == 0) *Ctr = 0;
     }
+    __syncthreads();
     float* meta_w = Meta + wave * 32 * 8;
     const float inv_sqrt3 = 0.57735026918962576f;
     const float inv_sqrt2 = 0.70710678118654752f;
     const float inv_sqrt_h = 1.0f / sqrtf((float)H);
     const float umax_scale = (float)(p.R - 1);
 
-    for (int g = worker; g < p.G; g += nworkers) {
-        const int e0 = p.gptr[g];
-        const int e1 = p.gptr[g + 1];
-        const int nblk = (e1 - e0 + 31) >> 5;
-        __syncthreads();  // previous group's output pass is done with Acc
-        for (int i = tid; i < ADF_GROUP_NODES * 4 * 64; i += MSG_THREADS) Acc[i] = 0.f;
-        if (tid == 0) *Ctr = 0;
-        __syncthreads();
+    unsigned int ksteps = 0;  // wave-uniform; one global atomic per wave at the very end (profiling)
+    // work item t of this workgroup -> target atom (group = worker + (t/32)*nworkers, node = t%32):
+    // consecutive items are consecutive atoms, so the 8 waves write neighbouring output rows
+    while (true) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(Ctr, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int g = worker + (t >> 5) * nworkers;
+        if (g >= p.G) break;
+        const int n = g * ADF_GROUP_NODES + (t & 31);
+        if (n >= p.N) continue;
+        const int e0 = p.nptr[n];
+        const int e1 = p.nptr[n + 1];
+        // running sums over this target's edges: sx = sum a ; s* = sum vec*b ; r* = sum c*r_hat
+        // (the 1/sqrt3 and 1/sqrtH factors of painn_denoising.py:550-553 are applied once at the end)
+        float sx0 = 0.f, sx1 = 0.f, sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f, sc0 = 0.f, sc1 = 0.f;
+        float ra0 = 0.f, ra1 = 0.f, rb0 = 0.f, rb1 = 0.f, rc0 = 0.f, rc1 = 0.f;
 
-        while (true) {
-            int blk = 0;
-            if (lane == 0) blk = atomicAdd(Ctr, 1);
-            blk = __builtin_amdgcn_readfirstlane(blk);
-            if (blk >= nblk) break;
-            const int e = e0 + blk * 32 + q;
+        for (int eb = e0; eb < e1; eb += 32) {
+            const int e = eb + q;
             const bool valid = e < e1;
             float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
-            adf_edge_meta em{0, 0};
-            if (valid) { geo = p.e_geom[e]; em = p.e_meta[e]; }
+            int src = 0;
+            if (valid) { geo = p.e_geom[e]; src = p.e_src[e]; }
             const float xs = geo.w * p.inv_cutoff;
             // polynomial envelope (radial_basis.py:36-43)
-            float env = 1.0f + p.env_a * powf(xs, p.env_p) + p.env_b * powf(xs, p.env_p + 1.0f) +
-                        p.env_c * powf(xs, p.env_p + 2.0f);
+            float xp = xs;
+            for (int i = 1; i < p.env_pi; ++i) xp *= xs;  // xs^p by repeated multiplication (p is a small int)
+            float env = 1.0f + p.env_a * xp + p.env_b * (xp * xs) + p.env_c * (xp * xs * xs);
             env = (xs < 1.0f && valid) ? env : 0.0f;
+            __builtin_amdgcn_wave_barrier();  // previous block's meta reads are done
             if (hi == 0) {
                 float* m = meta_w + q * 8;
-                m[0] = __int_as_float(em.src);
-                m[1] = __int_as_float(valid ? em.dstl : -1);
-                m[2] = geo.x; m[3] = geo.y; m[4] = geo.z;
+                m[0] = __int_as_float(valid ? src : p.N);  // row N of xh is all zeros
+                m[1] = geo.x; m[2] = geo.y; m[3] = geo.z;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             // k-window of this block
             const float u = xs * umax_scale;
             const float umin = wave_min(valid ? u : 1e30f);
@@ -135,6 +149,38 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
             int khi = min(p.R, ((int)ceilf(umax) + 8 + 1) & ~1);
             klo = __builtin_amdgcn_readfirstlane(klo);
             khi = __builtin_amdgcn_readfirstlane(khi);
+            ksteps += khi - klo;
+
+            // Gather addresses of the 16 accumulator rows of this lane.  Padded rows point at the
+            // all-zero row N of xh, so their messages vanish without a branch.
+#define ROW_OF(r) ((r & 3) + 8 * (r >> 2) + 4 * hi)
+#define GATHER(r)                                                                               \
+    const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
+    const int s##r = __float_as_int(m##r[0]);                                                   \
+    const float* xp##r = p.xh + (size_t)s##r * 3 * H + c0 + 2 * q;                              \
+    const float* vp##r = p.vec + (size_t)s##r * 3 * H + c0 + 2 * q;                             \
+    const float2 xa##r = *reinterpret_cast<const float2*>(xp##r);                               \
+    const float2 xb##r = *reinterpret_cast<const float2*>(xp##r + H);                           \
+    const float2 xc##r = *reinterpret_cast<const float2*>(xp##r + 2 * H);                       \
+    const float2 va##r = *reinterpret_cast<const float2*>(vp##r);                               \
+    const float2 vb##r = *reinterpret_cast<const float2*>(vp##r + H);                           \
+    const float2 vc##r = *reinterpret_cast<const float2*>(vp##r + 2 * H);
+#define CONSUME(r)                                                                              \
+    {                                                                                           \
+        const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
+        const float t2 = xb##r.x * acc[2][r];                                                   \
+        const float t3 = xc##r.x * acc[4][r];                                                   \
+        sx0 += xa##r.x * acc[0][r];                                                             \
+        sa0 += va##r.x * t2; sb0 += vb##r.x * t2; sc0 += vc##r.x * t2;                          \
+        ra0 += t3 * ux; rb0 += t3 * uy; rc0 += t3 * uz;                                         \
+        const float u2 = xb##r.y * acc[3][r];                                                   \
+        const float u3 = xc##r.y * acc[5][r];                                                   \
+        sx1 += xa##r.y * acc[1][r];                                                             \
+        sa1 += va##r.y * u2; sb1 += vb##r.y * u2; sc1 += vc##r.y * u2;                          \
+        ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
+    }
+            // rows 0-3: issued before the MFMA loop, they land while the matrix pipe is busy
+            GATHER(0) GATHER(1) GATHER(2) GATHER(3)
 
             f32x16 acc[6];
 #pragma unroll
@@ -146,69 +192,50 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
             for (int k2 = klo; k2 < khi; k2 += 2) {
                 const int k = k2 + hi;
                 const float dm = xs - Mu[k];
-                const float a = env * expf(p.coeff * (dm * dm));
+                // exp via v_exp_f32 (exp2): |arg| <= 24.5 inside the window, relative error <= ~2e-6 on
+                // the smallest kept terms and ~1e-7 on the leading ones
+                const float a = env * __builtin_amdgcn_exp2f((p.coeff * 1.44269504088896341f) * (dm * dm));
                 const float* wrow = Wl + k * MSG_COLS + q;
 #pragma unroll
                 for (int b = 0; b < 6; ++b)
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[b * 32], acc[b], 0, 0, 0);
             }
-
-            // epilogue: 16 accumulator rows per lane
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float* m = meta_w + row * 8;
-                const int dstl = __float_as_int(m[1]);
-                if (dstl < 0) continue;
-                const int src = __float_as_int(m[0]);
-                const float ux = m[2], uy = m[3], uz = m[4];
-                const float* xs_p = p.xh + (size_t)src * 3 * H + c0 + 2 * q;
-                const float* vs_p = p.vec + (size_t)src * 3 * H + c0 + 2 * q;
-                const float2 xa = *reinterpret_cast<const float2*>(xs_p);
-                const float2 xb = *reinterpret_cast<const float2*>(xs_p + H);
-                const float2 xc = *reinterpret_cast<const float2*>(xs_p + 2 * H);
-                const float2 v0 = *reinterpret_cast<const float2*>(vs_p);
-                const float2 v1 = *reinterpret_cast<const float2*>(vs_p + H);
-                const float2 v2 = *reinterpret_cast<const float2*>(vs_p + 2 * H);
-                float* ab = Acc + dstl * 256 + q;
-                {
-                    const float mx = xa.x * acc[0][r];
-                    const float t2 = (xb.x * acc[2][r]) * inv_sqrt3;
-                    const float t3 = xc.x * acc[4][r];
-                    atomicAdd(ab, mx);
-                    atomicAdd(ab + 64, (v0.x * t2 + t3 * ux) * inv_sqrt_h);
-                    atomicAdd(ab + 128, (v1.x * t2 + t3 * uy) * inv_sqrt_h);
-                    atomicAdd(ab + 192, (v2.x * t2 + t3 * uz) * inv_sqrt_h);
-                }
-                {
-                    const float mx = xa.y * acc[1][r];
-                    const float t2 = (xb.y * acc[3][r]) * inv_sqrt3;
-                    const float t3 = xc.y * acc[5][r];
-                    atomicAdd(ab + 32, mx);
-                    atomicAdd(ab + 96, (v0.y * t2 + t3 * ux) * inv_sqrt_h);
-                    atomicAdd(ab + 160, (v1.y * t2 + t3 * uy) * inv_sqrt_h);
-                    atomicAdd(ab + 224, (v2.y * t2 + t3 * uz) * inv_sqrt_h);
-                }
-            }
+            // epilogue, software pipelined: next rows' gathers are in flight while rows are consumed
+            GATHER(4) GATHER(5) GATHER(6) GATHER(7)
+            CONSUME(0) CONSUME(1) CONSUME(2) CONSUME(3)
+            GATHER(8) GATHER(9) GATHER(10) GATHER(11)
+            CONSUME(4) CONSUME(5) CONSUME(6) CONSUME(7)
+            GATHER(12) GATHER(13) GATHER(14) GATHER(15)
+            CONSUME(8) CONSUME(9) CONSUME(10) CONSUME(11)
+            CONSUME(12) CONSUME(13) CONSUME(14) CONSUME(15)
+#undef GATHER
+#undef CONSUME
+#undef ROW_OF
         }
-        __syncthreads();
-        // output pass: Acc[node][comp][j*32+q] -> channel c0 + 2q + j ; residuals fused
-        for (int i = tid; i < ADF_GROUP_NODES * 4 * 64; i += MSG_THREADS) {
-            const int node = i >> 8;
-            const int comp = (i >> 6) & 3;
-            const int ch = i & 63;
-            const int n = g * ADF_GROUP_NODES + node;
-            if (n >= p.N) continue;
-            const float s = Acc[node * 256 + comp * 64 + (ch & 1) * 32 + (ch >> 1)];
-            if (comp == 0) {
-                const size_t o = (size_t)n * H + c0 + ch;
-                p.x_out[o] = (p.x[o] + s) * inv_sqrt2;
-            } else {
-                const size_t o = ((size_t)n * 3 + (comp - 1)) * H + c0 + ch;
-                p.vec_out[o] = p.vec[o] + s;
-            }
+        sa0 = (sa0 * inv_sqrt3 + ra0) * inv_sqrt_h; sa1 = (sa1 * inv_sqrt3 + ra1) * inv_sqrt_h;
+        sb0 = (sb0 * inv_sqrt3 + rb0) * inv_sqrt_h; sb1 = (sb1 * inv_sqrt3 + rb1) * inv_sqrt_h;
+        sc0 = (sc0 * inv_sqrt3 + rc0) * inv_sqrt_h; sc1 = (sc1 * inv_sqrt3 + rc1) * inv_sqrt_h;
+        // the two half-waves hold disjoint rows of the same channels
+        sx0 += __shfl_xor(sx0, 32); sx1 += __shfl_xor(sx1, 32);
+        sa0 += __shfl_xor(sa0, 32); sa1 += __shfl_xor(sa1, 32);
+        sb0 += __shfl_xor(sb0, 32); sb1 += __shfl_xor(sb1, 32);
+        sc0 += __shfl_xor(sc0, 32); sc1 += __shfl_xor(sc1, 32);
+        // residuals fused (painn_denoising.py:443-445); half-wave 0 writes x and vec_x, half-wave 1 vec_y, vec_z
+        const size_t xo = (size_t)n * H + c0 + 2 * q;
+        const size_t vo = (size_t)n * 3 * H + c0 + 2 * q;
+        if (hi == 0) {
+            const float2 xin = *reinterpret_cast<const float2*>(p.x + xo);
+            *reinterpret_cast<float2*>(p.x_out + xo) = make_float2((xin.x + sx0) * inv_sqrt2, (xin.y + sx1) * inv_sqrt2);
+            const float2 vin = *reinterpret_cast<const float2*>(p.vec + vo);
+            *reinterpret_cast<float2*>(p.vec_out + vo) = make_float2(vin.x + sa0, vin.y + sa1);
+        } else {
+            const float2 vin1 = *reinterpret_cast<const float2*>(p.vec + vo + H);
+            *reinterpret_cast<float2*>(p.vec_out + vo + H) = make_float2(vin1.x + sb0, vin1.y + sb1);
+            const float2 vin2 = *reinterpret_cast<const float2*>(p.vec + vo + 2 * H);
+            *reinterpret_cast<float2*>(p.vec_out + vo + 2 * H) = make_float2(vin2.x + sc0, vin2.y + sc1);
         }
     }
+    if (p.kcount && lane == 0) atomicAdd(p.kcount, (unsigned long long)ksteps);
 }
 
 // rbf_proj -> [slice][k][part*64 + j*32 + q]  with channel = slice*64 + 2q + j
@@ -228,7 +255,7 @@ __global__ void adf_pack_rbf_kernel(const float* __restrict__ w, const float* __
 }
 
 static size_t msg_lds_bytes(int R) {
-    return sizeof(float) * ((size_t)R * MSG_COLS + MSG_COLS + 128 + ADF_GROUP_NODES * 4 * 64 + MSG_WAVES * 32 * 8) + 16;
+    return sizeof(float) * ((size_t)R * MSG_COLS + MSG_COLS + 128 + MSG_WAVES * 32 * 8) + 16;
 }
 
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
@@ -254,7 +281,7 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
     MsgParams p;
     p.xh = xh; p.vec = vec; p.x = x; p.x_out = x_out; p.vec_out = vec_out;
-    p.gptr = h->gptr; p.e_meta = h->e_meta; p.e_geom = h->e_geom;
+    p.nptr = h->nptr; p.e_src = h->e_src; p.e_geom = h->e_geom;
     p.nslices = H / ADF_SLICE_CH;
     p.wpack = h->rbf_pack + (size_t)layer * p.nslices * R * MSG_COLS;
     p.bpack = h->rbf_bias_pack + (size_t)layer * p.nslices * MSG_COLS;
@@ -265,10 +292,11 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     const double step = 1.0 / (R - 1);
     p.coeff = (float)(-0.5 / (step * step));
     const double pe = (double)h->hp.envelope_exponent;
-    p.env_p = (float)pe;
+    p.env_pi = h->hp.envelope_exponent;
     p.env_a = (float)(-(pe + 1) * (pe + 2) / 2);
     p.env_b = (float)(pe * (pe + 2));
     p.env_c = (float)(-pe * (pe + 1) / 2);
+    p.kcount = h->prof_on ? h->kcount : nullptr;
     int workers = h->num_cus / p.nslices;
     if (workers < 1) workers = 1;
     if (workers > p.G) workers = p.G;

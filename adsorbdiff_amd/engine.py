@@ -260,6 +260,22 @@ class PaiNNEngine:
             _lib.check(self.lib.adf_get_counters(self.handle, C.byref(c), self._stream()))
         return c
 
+    PROFILE_CATEGORIES = ("graph", "message", "node_dense", "heads", "stepper")
+
+    def profile_enable(self, on: bool = True) -> None:
+        _lib.check(self.lib.adf_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        """{category: (total_ms, groups)} since the last read (HIP events on the launch stream)."""
+        ms = (C.c_float * 5)()
+        cnt = (C.c_int64 * 5)()
+        ksteps = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.adf_profile_read(self.handle, ms, cnt, C.byref(ksteps), self._stream()))
+        out = {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROFILE_CATEGORIES)}
+        out["message_ksteps"] = int(ksteps.value)
+        return out
+
     def close(self) -> None:
         if getattr(self, "handle", None) is not None and self.handle:
             with torch.cuda.device(self.device):

@@ -17,7 +17,8 @@ ADF_OK, ADF_EINVAL, ADF_EOOM, ADF_ENONEIGHBOR, ADF_EHIP, ADF_EOVERFLOW = 0, 1, 2
 EXPORTS = (
     "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_check_flags",
     "adf_graph_export", "adf_painn_forward", "adf_painn_message_layer", "adf_painn_update_layer",
-    "adf_sde_init_placement", "adf_sde_step", "adf_get_counters", "adf_last_error", "adf_version",
+    "adf_sde_init_placement", "adf_sde_step", "adf_get_counters", "adf_profile_enable", "adf_profile_read",
+    "adf_last_error", "adf_version",
 )
 
 
@@ -85,6 +86,8 @@ def load():
         "adf_sde_init_placement": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp],
         "adf_sde_step": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, vp, C.POINTER(StepCoef), vp, vp, i32, vp, vp, vp, vp],
         "adf_get_counters": [vp, C.POINTER(Counters), vp],
+        "adf_profile_enable": [vp, i32],
+        "adf_profile_read": [vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64), vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)

@@ -182,6 +182,17 @@ typedef struct {
 } adf_counters;
 int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream);
 
+/* Optional HIP-event timing of the kernel groups of adf_painn_forward / adf_sde_step, recorded
+ * on the launch stream.  Categories: 0 graph build, 1 message kernel (one launch per layer),
+ * 2 node-side dense blocks (LayerNorm + GEMMs + update), 3 output heads, 4 stepper.
+ * adf_profile_read synchronises, returns summed milliseconds and number of timed groups per
+ * category (arrays of 5) and resets the log.  *message_ksteps (optional) = sum over all 32-edge
+ * row blocks of all message launches of the k-window length actually contracted; executed MFMA
+ * flops of the message kernel = message_ksteps * 32 * 192 * 2. */
+#define ADF_PROF_NCAT 5
+int32_t adf_profile_enable(adf_painn_t h, int32_t on);
+int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, int64_t* message_ksteps, void* stream);
+
 const char* adf_last_error(void);
 const char* adf_version(void);
 
