@@ -56,8 +56,9 @@ def schedule_coefs(params: dict) -> List[_lib.StepCoef]:
         else:
             c.coef_tr = float(tr_g**2 * dt)
             c.rot_pre = 1.0
-            c.noise_tr = float(tr_g * np.sqrt(dt))
-            c.noise_rot = float((rot_g * np.sqrt(dt)).to(torch.float32))
+            sqrt_dt = np.sqrt(np.float32(dt.item()))  # the reference's np.sqrt(dt) on a float32 0-dim tensor
+            c.noise_tr = float(tr_g * sqrt_dt)
+            c.noise_rot = float((rot_g * sqrt_dt).to(torch.float32))
         out.append(c)
     return out
 

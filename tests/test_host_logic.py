@@ -1,0 +1,134 @@
+"""CPU tests of the host-side mirror: containers, schedule scalars, repeat counts, weights table,
+C-ABI surface.  No GPU compute is called."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from adsorbdiff_amd import lib as L
+from adsorbdiff_amd.data import Batch, Data
+from adsorbdiff_amd.denoising_torch import schedule_coefs
+from adsorbdiff_amd.engine import batch_pbc, cell_repeats
+from adsorbdiff_amd.painn_denoising import PaiNN
+from adsorbdiff_amd.sampler import adsorbate_sites, balanced_partition
+from adsorbdiff_amd.scaling import PAINN_NB6_SCALE_FACTORS, ScaleFactor, ensure_fitted
+from adsorbdiff_amd.synthetic import make_batch
+from oracle import painn_oracle as O
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_c_abi_exports_match_header():
+    hdr = (ROOT / "include" / "adsorbdiff_hip.h").read_text()
+    declared = set(re.findall(r"\b(adf_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"adf_painn"}  # struct tag
+    lib = L.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert set(L.EXPORTS) == declared
+    assert b"gfx950" in lib.adf_version()
+
+
+def test_no_cpu_fallback():
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=1, so3_denoising=True)
+    b = make_batch(1, n_slab=16, n_ads=2, seed=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(b)
+
+
+def test_invalid_hparams_rejected():
+    lib = L.load()
+    hp = L.Hparams(hidden_channels=100, num_layers=1, num_rbf=128, num_elements=83, max_neighbors=50,
+                   envelope_exponent=5, num_heads=2, cutoff=6.0)
+    h = ctypes.c_void_p()
+    assert lib.adf_painn_create(ctypes.byref(hp), ctypes.byref(h)) == L.ADF_EINVAL
+    assert b"hidden_channels" in lib.adf_last_error()
+    with pytest.raises(ValueError):
+        L.check(L.ADF_ENONEIGHBOR)
+    with pytest.raises(RuntimeError):
+        L.check(L.ADF_EOOM)
+
+
+def test_state_dict_layout_matches_reference_keys():
+    m = PaiNN(None, 50, 1, so3_denoising=True, scale_file=PAINN_NB6_SCALE_FACTORS)
+    sd = m.state_dict()
+    assert sd["atom_emb.embeddings.weight"].shape == (83, 512)
+    assert sd["message_layers.5.x_proj.2.weight"].shape == (1536, 512)
+    assert sd["message_layers.0.rbf_proj.weight"].shape == (1536, 128)
+    assert sd["update_layers.3.vec_proj.weight"].shape == (1024, 512)
+    assert sd["update_layers.3.xvec_proj.0.weight"].shape == (512, 1024)
+    assert sd["out_forces2.output_network.1.update_net.2.weight"].shape == (2, 256)
+    assert sd["radial_basis.rbf.offset"].shape == (128,)
+    assert float(sd["upd_out_scalar_scale_0.scale_factor"]) == pytest.approx(1.0364354848861694)
+    assert m.num_params == 21451888  # SURVEY.md §6 [probe]
+    assert m.scale_factors()[5] == pytest.approx(0.8822302222251892)
+    ensure_fitted(m)
+    cond = PaiNN(None, 50, 1, hidden_channels=128, num_layers=1, so3_denoising=True, energy_encoding="scalar")
+    assert "energy_embedding.weight" in cond.state_dict() and "concat_lin.0.weight" in cond.state_dict()
+    with pytest.raises(ValueError):
+        ensure_fitted(cond)
+    sf = ScaleFactor()
+    x = torch.ones(3)
+    assert torch.equal(sf(x), x)  # unfitted -> identity (scale_factor.py:166-167)
+    sf.set_(2.0)
+    assert torch.equal(sf(x), 2 * x)
+
+
+def test_schedule_coefs_match_oracle_scalars():
+    for ode in (True, False):
+        params = dict(num_steps=50, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=ode)
+        cs = schedule_coefs(params)
+        assert len(cs) == 50
+        for t in (0, 1, 25, 49):
+            tr_g, rot_g, dt = O.schedule_scalars(t, 50, 0.1, 10, 0.01, 1.55)
+            s = torch.tensor([[0.3, -0.7, 0.11]])
+            if ode:
+                want_tr = 0.5 * tr_g**2 * dt * s
+                want_rot = 0.5 * s * dt * rot_g**2
+            else:
+                want_tr = tr_g**2 * dt * s
+                want_rot = s * dt * rot_g**2
+            got_tr = torch.tensor(cs[t].coef_tr, dtype=torch.float32) * s
+            got_rot = ((torch.tensor(cs[t].rot_pre) * s) * torch.tensor(cs[t].rot_dt)) * torch.tensor(cs[t].rot_g2)
+            assert torch.equal(got_tr, want_tr)
+            assert torch.allclose(got_rot, want_rot.float(), rtol=2e-7, atol=0)
+    assert cs[0].noise_tr > 0 and schedule_coefs(dict(params, ode=True))[0].noise_tr == 0
+
+
+def test_cell_repeats_and_pbc():
+    b = make_batch(3, n_slab=36, n_ads=4, seed=2)
+    assert cell_repeats(b.cell, 6.0) == O.cell_repeats(b.cell, 6.0) == [2, 2, 1]
+    big = make_batch(2, seed=3)
+    assert cell_repeats(big.cell, 10.0) == [1, 1, 1]
+    assert cell_repeats(big.cell, 10.0, (True, True, False)) == [1, 1, 0]
+    assert batch_pbc(b) == [True, True, True]
+    b.pbc = torch.tensor([[True, True, False]] * 3)
+    assert batch_pbc(b) == [True, True, False]
+    b.pbc = torch.tensor([[True, True, False], [True, True, True], [True, True, True]])
+    with pytest.raises(RuntimeError):
+        batch_pbc(b)
+
+
+def test_batch_collate_roundtrip_and_sites():
+    b = make_batch(3, n_slab=16, n_ads=3, seed=4)
+    parts = b.to_data_list()
+    assert [int(p.natoms) for p in parts] == [19, 19, 19]
+    b2 = Batch.from_data_list(parts)
+    assert torch.equal(b2.pos, b.pos) and torch.equal(b2.batch, b.batch) and b2.sid == b.sid
+    nested = Batch.from_data_list([Batch.from_data_list(parts[:1]), Batch.from_data_list(parts[1:])])
+    assert torch.equal(nested.cell, b.cell)
+    sites = adsorbate_sites(b)
+    assert sites.shape == (3, 3, 3)
+    assert torch.equal(sites[1], b.pos[(b.batch == 1) & (b.tags == 2)])
+    assert balanced_partition([5, 9, 3, 7, 1], 2) == [[1, 2, 4], [0, 3]]
+
+
+def test_synthetic_batch_shape():
+    b = make_batch(2, seed=1000)
+    assert b.pos.shape == (400, 3) and b.natoms.tolist() == [200, 200]
+    assert int((b.tags == 2).sum()) == 8 and int(b.atomic_numbers.max()) <= 83
+    assert torch.equal(b.fixed, (b.tags == 0).long())
+    assert torch.equal(make_batch(2, seed=1000).pos, b.pos)  # deterministic under the seed

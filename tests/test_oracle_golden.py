@@ -1,0 +1,96 @@
+"""CPU tests: the oracle restatement (oracle/painn_oracle.py) against the golden fixtures that
+oracle/make_golden.py generated from the REAL reference (imported from /root/reference in the
+build container).  These pin the oracle; the GPU tests then pin the HIP path to both."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import painn_oracle as O
+from tests.helpers import batch_from_fixture, load_npz, rel_err, state_dict_from_fixture
+
+torch.set_num_threads(4)
+
+
+@pytest.mark.parametrize("name", ["small", "mixed", "bench1", "small12", "tie"])
+def test_graph_oracle_vs_reference(name):
+    fx = load_npz(f"graph_{name}.npz")
+    b = batch_from_fixture(fx)
+    ei, sh, nb = O.radius_graph_pbc(b.pos, b.cell, b.natoms, float(fx["cutoff"]), int(fx["K"]))
+    assert np.array_equal(nb.numpy(), fx["neighbors0"])
+    assert np.array_equal(ei[1].numpy(), fx["edge_index0"][1])
+    if int(fx["exact"]):
+        assert np.array_equal(ei.numpy(), fx["edge_index0"])
+        assert np.array_equal(sh.numpy(), fx["shifts0"])
+        ei2, nb2, d, u = O.generate_graph_values(b.pos, b.cell, b.natoms, float(fx["cutoff"]), int(fx["K"]))
+        assert np.array_equal(ei2.numpy(), fx["edge_index"])
+        assert np.array_equal(nb2.numpy(), fx["neighbors"])
+        # float geometry: identical ops on this CPU -> equal up to BLAS/ISA differences between hosts
+        np.testing.assert_allclose(d.numpy(), fx["dist"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(u.numpy(), fx["unit_vec"], rtol=0, atol=2e-6)
+    else:
+        # exact d^2 ties at the K-th place (reference sort is unstable): same edge COUNT per centre
+        assert ei.shape == fx["edge_index0"].shape
+
+
+def test_symmetrise_reorder_rule_known_answers():
+    """The reference's only known-answer vectors are the repeat_blocks docstring examples
+    (painn_denoising.py:718-737); the symmetrisation uses repeats=2, repeat_inc=E_kept, i.e. per image
+    [kept..., kept + E_kept...].  Checked here on a hand-built 2-image case."""
+    ei = torch.tensor([[0, 1, 2, 1, 3, 4, 4], [1, 0, 1, 2, 4, 3, 4]])  # (src, dst)
+    sh = torch.zeros(7, 3)
+    sh[6] = torch.tensor([-1.0, 0.0, 0.0])  # self image, lexicographically negative -> kept
+    nb = torch.tensor([4, 3])
+    d = torch.arange(1, 8).float()
+    u = torch.eye(3)[[0, 1, 2, 0, 1, 2, 0]]
+    ei2, sh2, nb2, d2, u2 = O.symmetrize_edges(ei, sh, nb, d, u)
+    # kept: (0->1), (1->2) in image 0 ; (3->4), (4->4,-x) in image 1
+    assert ei2.tolist() == [[0, 1, 1, 2, 3, 4, 4, 4], [1, 2, 0, 1, 4, 4, 3, 4]]
+    assert nb2.tolist() == [4, 4]
+    assert d2.tolist() == [1.0, 4.0, 1.0, 4.0, 5.0, 7.0, 5.0, 7.0]
+    assert torch.equal(u2[2], -u2[0]) and torch.equal(sh2[7], -sh2[5])
+
+
+def test_axis_angle_vs_reference():
+    fx = load_npz("axis_angle.npz")
+    R = O.axis_angle_to_matrix(torch.from_numpy(fx["aa"]))
+    np.testing.assert_allclose(R.numpy(), fx["R"], rtol=0, atol=1e-6)
+
+
+def test_painn_small_oracle_vs_reference():
+    fx = load_npz("painn_small.npz")
+    sd = state_dict_from_fixture(fx)
+    b = batch_from_fixture(fx)
+    cap = {}
+    f1, f2 = O.painn_forward(sd, b.pos, b.atomic_numbers, b.cell, b.natoms, hidden_channels=128, num_layers=2,
+                             num_rbf=128, cutoff=6.0, max_neighbors=20, scale_factors=list(fx["scale_factors"]),
+                             capture=cap)
+    assert rel_err(f1, fx["f1"]) < 1e-5 and rel_err(f2, fx["f2"]) < 1e-5
+    np.testing.assert_allclose(cap["rbf"].numpy(), fx["rbf"], rtol=1e-5, atol=1e-7)
+    for li, L in enumerate(cap["layers"]):
+        for k, v in L.items():
+            assert rel_err(v, fx[f"layer{li}_{k}"]) < 1e-5, (li, k)
+
+
+def test_stepper_oracle_each_step_vs_reference():
+    """Teacher forcing on the reference's recorded positions (see tests/test_gpu_parity.py)."""
+    hp = dict(hidden_channels=128, num_layers=2, num_rbf=128, cutoff=6.0, max_neighbors=20)
+    fx = load_npz("stepper_ode8.npz")
+    sd = state_dict_from_fixture(fx)
+    b = batch_from_fixture(fx, pos_key="pos_in")
+    params = dict(num_steps=8, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True)
+    torch.manual_seed(int(fx["seed"]))
+    noise = torch.rand(4, 3)
+    p0 = O.initial_placement(b.pos.clone(), b.cell, b.tags, b.batch, noise)
+    log = torch.from_numpy(fx["pos_log"])
+    np.testing.assert_allclose(p0.numpy(), log[0].numpy(), rtol=0, atol=2e-6)
+    for t in (0, 7):  # first and last step (each forward costs ~0.3 s on CPU)
+        f1, f2 = O.painn_forward(sd, log[t], b.atomic_numbers, b.cell, b.natoms, scale_factors=[1.05, 0.9], **hp)
+        new_pos, dcom, drot, conv = O.reverse_step(log[t], b.cell, b.tags, b.batch, f1, f2, b.fixed, t, params)
+        want = log[t + 1] if t < 7 else torch.from_numpy(fx["pos_final"])
+        np.testing.assert_allclose(new_pos.numpy(), want.numpy(), rtol=0, atol=2e-5)
+
+
+def test_early_stop_rule():
+    """Cumulative (not consecutive) count, break before applying the 10th converged step."""
+    fx = load_npz("stepper_ode_early.npz")
+    assert fx["pos_log"].shape[0] == 10  # the reference made exactly 10 model calls out of 40
