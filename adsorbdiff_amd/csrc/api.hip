@@ -1,6 +1,7 @@
 // C ABI of libadsorbdiff_hip.so: handle life-cycle, grow-only workspaces, and the launch
 // sequence of one PaiNN denoiser forward (reference: painn_denoising.py:402-481).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -117,6 +118,18 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     int32_t st = dev_alloc(&h->rbf_pack, (size_t)L * (H / ADF_SLICE_CH) * R * 192);
     if (st == ADF_OK) st = dev_alloc(&h->rbf_bias_pack, (size_t)L * (H / ADF_SLICE_CH) * 192);
     if (st == ADF_OK) st = dev_alloc(&h->flags, 4);
+    {   // fp16 hi/lo arena: per layer 9 H^2 + 2 (H*2H) ... computed exactly below
+        const size_t HH = (size_t)H * H;
+        const size_t per_layer = HH + 3 * HH + 2 * HH + 2 * HH + 3 * HH;                 // xp0 xp2 vp xv0 xv2
+        const size_t per_head = HH + HH / 2 + 2 * HH + HH + HH / 4 + HH / 2;              // b0: vec1 vec2 un0 un2 ; b1: vec1 un0
+        const size_t elems = (size_t)L * per_layer + (size_t)hp->num_heads * per_head;
+        h->w16_bytes = elems * 2 * sizeof(uint16_t) + 4096;
+        if (st == ADF_OK) st = dev_alloc(&h->w16_arena, h->w16_bytes);
+        if (st == ADF_OK) st = dev_alloc(&h->w16_scales, 256);
+        if (st == ADF_OK) st = dev_alloc(&h->w16_scratch, 1);
+        const char* e = getenv("ADF_GEMM");
+        h->gemm_f32 = e && strcmp(e, "f32") == 0;
+    }
     if (st == ADF_OK) st = dev_alloc(&h->kcount, 1);
     if (st == ADF_OK && hipMemset(h->kcount, 0, sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;
     if (st != ADF_OK) { adf_painn_destroy(h); return st; }
@@ -143,6 +156,9 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->rbf_bias_pack) (void)hipFree(h->rbf_bias_pack);
     if (h->flags) (void)hipFree(h->flags);
     if (h->kcount) (void)hipFree(h->kcount);
+    if (h->w16_arena) (void)hipFree(h->w16_arena);
+    if (h->w16_scales) (void)hipFree(h->w16_scales);
+    if (h->w16_scratch) (void)hipFree(h->w16_scratch);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
     delete h->prof_cat;
     delete h;
@@ -178,6 +194,40 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
             bw.un2_b = f(k++);
         }
     ADF_TRY(adf_pack_rbf(h, (hipStream_t)stream));
+    {   // split every GEMM weight into fp16 hi/lo (gemm16.hip)
+        hipStream_t s = (hipStream_t)stream;
+        const long long H = h->hp.hidden_channels, HH = H * H;
+        unsigned char* cur = h->w16_arena;
+        int nscale = 0;
+        auto split = [&](const float* w, long long n, adf_w16* out) -> int32_t {
+            out->hi = cur; cur += n * 2;
+            out->lo = cur; cur += n * 2;
+            out->inv_scale = h->w16_scales + nscale++;
+            return adf_split_weight(w, n, out, h->w16_scratch, s);
+        };
+        for (int l = 0; l < L; ++l) {
+            adf_layer_weights& lw = h->layer[l];
+            ADF_TRY(split(lw.xp0_w, HH, &lw.xp0_16));
+            ADF_TRY(split(lw.xp2_w, 3 * HH, &lw.xp2_16));
+            ADF_TRY(split(lw.vp_w, 2 * HH, &lw.vp_16));
+            ADF_TRY(split(lw.xv0_w, 2 * HH, &lw.xv0_16));
+            ADF_TRY(split(lw.xv2_w, 3 * HH, &lw.xv2_16));
+        }
+        for (int hd = 0; hd < h->hp.num_heads; ++hd) {
+            adf_block_weights& b0 = h->head[hd][0];
+            adf_block_weights& b1 = h->head[hd][1];
+            ADF_TRY(split(b0.vec1_w, HH, &b0.vec1_16));
+            ADF_TRY(split(b0.vec2_w, HH / 2, &b0.vec2_16));
+            ADF_TRY(split(b0.un0_w, 2 * HH, &b0.un0_16));
+            ADF_TRY(split(b0.un2_w, HH, &b0.un2_16));
+            ADF_TRY(split(b1.vec1_w, HH / 4, &b1.vec1_16));
+            ADF_TRY(split(b1.un0_w, HH / 2, &b1.un0_16));
+        }
+        if ((size_t)(cur - h->w16_arena) > h->w16_bytes || nscale > 256) {
+            adf_set_error("internal: fp16 weight arena overflow");
+            return ADF_EINVAL;
+        }
+    }
     h->weights_set = true;
     return ADF_OK;
 }
@@ -329,8 +379,8 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
     // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
     adf_prof_begin(h, ADF_PROF_NODE, s);
     ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
-    ADF_TRY(adf_launch_gemm(h->y, H, w.xp0_w, H, w.xp0_b, h->cat, H, N, H, H, 1, s));
-    ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+    ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, N, H, H, 1, s));
+    ADF_TRY(adf_linear(h, h->cat, H, w.xp2_w, &w.xp2_16, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
     adf_prof_end(h, s);
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
     const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, s);
@@ -342,10 +392,10 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
     const int H = h->hp.hidden_channels;
     const adf_layer_weights& w = h->layer[l];
     adf_prof_begin(h, ADF_PROF_NODE, s);
-    ADF_TRY(adf_launch_gemm(vec, H, w.vp_w, H, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
+    ADF_TRY(adf_linear(h, vec, H, w.vp_w, &w.vp_16, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
     ADF_TRY(adf_nodewise_update_prep(h->vv, x, h->cat, h->dot, N, H, s));
-    ADF_TRY(adf_launch_gemm(h->cat, 2 * H, w.xv0_w, 2 * H, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
-    ADF_TRY(adf_launch_gemm(h->y, H, w.xv2_w, H, w.xv2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+    ADF_TRY(adf_linear(h, h->cat, 2 * H, w.xv0_w, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
+    ADF_TRY(adf_linear(h, h->y, H, w.xv2_w, &w.xv2_16, w.xv2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
     const int32_t st = adf_nodewise_update_apply(h->xh, h->dot, h->vv, x, vec, h->scale[l], N, H, s);
     adf_prof_end(h, s);
     return st;
@@ -400,6 +450,25 @@ extern "C" int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f
     if (h->hp.num_heads == 2) ADF_TRY(adf_head_forward(h, 1, N, h->x, vin, f2, s));
     adf_prof_end(h, s);
     return ADF_OK;
+}
+
+// Stand-alone nn.Linear (unit tests of the two GEMM kernels): C = act(A . W^T + b)
+extern "C" int32_t adf_linear_forward(const float* A, const float* W, const float* bias, float* C, int32_t M,
+                                      int32_t N, int32_t K, int32_t act_ssilu, int32_t mode, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) { adf_set_error("bad argument"); return ADF_EINVAL; }
+    if (mode == 0) return adf_launch_gemm(A, K, W, K, bias, C, N, M, N, K, act_ssilu, s);
+    unsigned char* buf = nullptr;
+    const size_t n = (size_t)N * K;
+    ADF_TRY(dev_alloc(&buf, n * 4 + 64));
+    adf_w16 w16;
+    w16.hi = buf; w16.lo = buf + n * 2; w16.inv_scale = reinterpret_cast<float*>(buf + n * 4);
+    unsigned int* scratch = reinterpret_cast<unsigned int*>(buf + n * 4 + 16);
+    int32_t st = adf_split_weight(W, (long long)n, &w16, scratch, s);
+    if (st == ADF_OK) st = adf_launch_gemm16(A, K, &w16, bias, C, N, M, N, K, act_ssilu, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(buf);
+    return st;
 }
 
 extern "C" int32_t adf_check_flags(adf_painn_t h, void* stream) {

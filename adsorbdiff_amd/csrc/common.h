@@ -32,12 +32,20 @@ void adf_set_error(const char* fmt, ...);
         if (_s != ADF_OK) return _s;      \
     } while (0)
 
+// fp16 hi/lo split of one nn.Linear weight (gemm16.hip), library-owned
+struct adf_w16 {
+    void* hi;
+    void* lo;
+    float* inv_scale;  // device scalar: 1 / (power-of-two scale applied before the split)
+};
 struct adf_layer_weights {
     const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
     const float *vp_w, *xv0_w, *xv0_b, *xv2_w, *xv2_b;
+    adf_w16 xp0_16, xp2_16, vp_16, xv0_16, xv2_16;
 };
 struct adf_block_weights {
     const float *vec1_w, *vec2_w, *un0_w, *un0_b, *un2_w, *un2_b;
+    adf_w16 vec1_16, vec2_16, un0_16, un2_16;
 };
 
 struct adf_painn {
@@ -52,8 +60,12 @@ struct adf_painn {
     // message-kernel image of rbf_proj: [layer][slice][R][192] and bias [layer][slice][192]
     float* rbf_pack;
     float* rbf_bias_pack;
-    // concatenated head projections (vec1|vec2 of block 0 for every head): [(H + H/2) * heads, H]
-    float* head_vproj_pack;
+    // fp16 hi/lo images of every GEMM weight (one arena) + their scales; gemm_f32 selects the exact path
+    unsigned char* w16_arena;
+    size_t w16_bytes;
+    float* w16_scales;
+    unsigned int* w16_scratch;
+    bool gemm_f32;
 
     // ---- grow-only workspaces
     int64_t capN, capB, capE;
@@ -91,6 +103,15 @@ void adf_prof_end(adf_painn* h, hipStream_t s);
 // ---- kernels' host launchers (each enqueues on `s`, returns ADF_*)
 int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                         int M, int N, int K, int act_ssilu, hipStream_t s);
+int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
+                          int N, int K, int act_ssilu, hipStream_t s);
+int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s);
+// C = act(A . W^T + b): f16x3 split MFMA by default, exact-f32 MFMA when h->gemm_f32 (ADF_GEMM=f32)
+static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, const float* W, const adf_w16* W16,
+                                 const float* bias, float* C, int ldc, int M, int N, int K, int act, hipStream_t s) {
+    if (h->gemm_f32) return adf_launch_gemm(A, lda, W, K, bias, C, ldc, M, N, K, act, s);
+    return adf_launch_gemm16(A, lda, W16, bias, C, ldc, M, N, K, act, s);
+}
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
 size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,

@@ -136,6 +136,13 @@ int32_t adf_painn_message_layer(adf_painn_t h, int32_t layer, int32_t num_atoms,
 int32_t adf_painn_update_layer(adf_painn_t h, int32_t layer, int32_t num_atoms, float* x, float* vec,
                                void* stream);
 
+/* Stand-alone torch.nn.functional.linear (+ optional ScaledSiLU) on device pointers, A[M,K]
+ * W[N,K] bias[N] C[M,N] contiguous; K % 32 == 0.  mode 0: exact-f32 MFMA (gemm.hip); mode 1:
+ * f16x3 split MFMA (gemm16.hip).  Unit-test entry for the dense blocks of painn_denoising.py:531,
+ * 603, 609, 689-693; synchronises in mode 1. */
+int32_t adf_linear_forward(const float* A, const float* W, const float* bias, float* C, int32_t M, int32_t N,
+                           int32_t K, int32_t act_ssilu, int32_t mode, void* stream);
+
 /* Per-step schedule scalars, computed by the host with the reference's own
  * 0-dim tensor arithmetic (denoising_torch.py:237-293) so that the products
  * round exactly as there:

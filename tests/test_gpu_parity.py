@@ -86,6 +86,36 @@ def test_graph_empty_image_raises():
         m(b.to(DEV))
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("shape", [(1000, 512, 512, 1), (777, 1536, 512, 0), (600, 1024, 512, 0), (300, 64, 128, 1),
+                                   (4099, 512, 1024, 1)])
+def test_linear_kernels_vs_fp64(mode, shape):
+    """Both GEMM kernels (exact-f32 MFMA and the f16x3 split) against an fp64 torch reference."""
+    import ctypes as C
+
+    from adsorbdiff_amd import lib as L
+
+    M, N, K, act = shape
+    g = torch.Generator().manual_seed(M + N)
+    A = (torch.randn(M, K, generator=g) * 1.5).to(DEV)
+    A[:: 7] *= 1e-3  # rows of small activations (fp16 subnormal lo parts)
+    W = ((torch.rand(N, K, generator=g) - 0.5) * 0.15).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(DEV)
+    out = torch.empty(M, N, device=DEV)
+    lib = L.load()
+    L.check(lib.adf_linear_forward(A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, act, mode,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t() + b.double()
+    if act:
+        ref = torch.nn.functional.silu(ref) / 0.6
+    # error relative to the magnitude of the dot products (sum |a||w|), the natural scale of a GEMM
+    scale = (A.double().abs() @ W.double().abs().t()).mean()
+    err = float((out.double() - ref).abs().max() / scale)
+    assert err < (3e-6 if mode == 0 else 6e-6), err
+    assert rel_err(out, ref) < (1e-6 if mode == 0 else 3e-6)
+
+
 def test_painn_small_layers_and_output():
     fx = load_npz("painn_small.npz")
     m = small_model(fx)
