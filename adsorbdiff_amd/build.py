@@ -37,6 +37,11 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        # No SLP vectorisation: with it hipcc (ROCm 7.2) packs adjacent f32 adds/mults of the message
+        # kernel's epilogue into v_pk_*_f32 next to the f16 MFMA loop and the kernel then returns
+        # run-to-run different sums in lanes 16-31 (scratch/ bisect: deterministic and correct without).
+        # Packed f32 VALU math is also slower beside MFMAs (MI355X_MICROARCH.md, filler prices).
+        "-fno-slp-vectorize",
         "-o", str(LIB),
     ] + [str(CSRC / s) for s in SOURCES]
     if verbose:

@@ -117,6 +117,13 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     const int H = hp->hidden_channels, R = hp->num_rbf, L = hp->num_layers;
     int32_t st = dev_alloc(&h->rbf_pack, (size_t)L * (H / ADF_SLICE_CH) * R * 192);
     if (st == ADF_OK) st = dev_alloc(&h->rbf_bias_pack, (size_t)L * (H / ADF_SLICE_CH) * 192);
+    {
+        uint16_t* p16 = nullptr;
+        if (st == ADF_OK) st = dev_alloc(&p16, (size_t)L * (H / ADF_SLICE_CH) * R * 192 * 2);
+        h->rbf_pack16 = p16;
+    }
+    if (st == ADF_OK) st = dev_alloc(&h->rbf_bias_pack16, (size_t)L * (H / ADF_SLICE_CH) * 192);
+    if (st == ADF_OK) st = dev_alloc(&h->rbf_scales, 16);
     if (st == ADF_OK) st = dev_alloc(&h->flags, 4);
     {   // fp16 hi/lo arena: per layer 9 H^2 + 2 (H*2H) ... computed exactly below
         const size_t HH = (size_t)H * H;
@@ -129,6 +136,8 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         if (st == ADF_OK) st = dev_alloc(&h->w16_scratch, 1);
         const char* e = getenv("ADF_GEMM");
         h->gemm_f32 = e && strcmp(e, "f32") == 0;
+        const char* e2 = getenv("ADF_MSG");
+        h->msg_f32 = e2 ? strcmp(e2, "f32") == 0 : h->gemm_f32;
     }
     if (st == ADF_OK) st = dev_alloc(&h->kcount, 1);
     if (st == ADF_OK && hipMemset(h->kcount, 0, sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;
@@ -154,6 +163,9 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     free_workspaces(h);
     if (h->rbf_pack) (void)hipFree(h->rbf_pack);
     if (h->rbf_bias_pack) (void)hipFree(h->rbf_bias_pack);
+    if (h->rbf_pack16) (void)hipFree(h->rbf_pack16);
+    if (h->rbf_bias_pack16) (void)hipFree(h->rbf_bias_pack16);
+    if (h->rbf_scales) (void)hipFree(h->rbf_scales);
     if (h->flags) (void)hipFree(h->flags);
     if (h->kcount) (void)hipFree(h->kcount);
     if (h->w16_arena) (void)hipFree(h->w16_arena);

@@ -60,12 +60,17 @@ struct adf_painn {
     // message-kernel image of rbf_proj: [layer][slice][R][192] and bias [layer][slice][192]
     float* rbf_pack;
     float* rbf_bias_pack;
+    // f16 hi/lo image of (rbf_proj * scale): [layer][slice][hi|lo][192][R] halves; bias * scale; 1/scale per layer
+    void* rbf_pack16;
+    float* rbf_bias_pack16;
+    float* rbf_scales;
     // fp16 hi/lo images of every GEMM weight (one arena) + their scales; gemm_f32 selects the exact path
     unsigned char* w16_arena;
     size_t w16_bytes;
     float* w16_scales;
     unsigned int* w16_scratch;
     bool gemm_f32;
+    bool msg_f32;
 
     // ---- grow-only workspaces
     int64_t capN, capB, capE;

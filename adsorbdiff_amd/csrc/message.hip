@@ -27,16 +27,24 @@
 // No LDS atomics (ds_add_f32 measured 4x slower than the whole rest of the kernel), no barriers
 // after the weight image is staged, no zero-initialised outputs.  HBM traffic per layer = node
 // tables once + 20 B per edge (vs 6 KB per edge if rbfh were materialised); the roofline that
-// binds is the f32 MFMA rate of step 1.
+// binds is the matrix-core rate of step 1.
+//
+// Two arithmetic modes for step 1, same structure otherwise:
+//   F16 = true  (default): f16x3 split (see gemm16.hip) — A = a_hi + a_lo generated in registers,
+//                W·s = w_hi + w_lo in LDS as [col][k] halves, v_mfma_f32_32x32x16_f16 x 3 products,
+//                fp32 accumulate; the k-window is aligned to 8 and contracted 16 k at a time.
+//   F16 = false (ADF_GEMM=f32): exact f32 v_mfma_f32_32x32x2_f32, window contracted 2 k at a time.
 #include <stdlib.h>
 
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 #define MSG_THREADS 512
 #define MSG_WAVES 8
 #define MSG_COLS 192
+#define MSG_LDK 136  // halves per column row of the f16 weight image (128 + 8 pad: conflict-free b128 reads)
 
 struct MsgParams {
     const float* xh;
@@ -47,13 +55,15 @@ struct MsgParams {
     const int32_t* nptr;
     const int32_t* e_src;
     const float4* e_geom;
-    const float* wpack;
-    const float* bpack;
+    const float* wpack;      // f32 image  [slice][R][192]
+    const _Float16* wpack16; // f16 image  [slice][hi|lo][192][R]
+    const float* bpack;      // [slice][192] bias (f32 mode) or bias * scale (f16 mode)
+    const float* inv_scale;  // device scalar (f16 mode)
     const float* mu;
     int N, H, R, G, nslices;
     float inv_cutoff, coeff, env_a, env_b, env_c;
     int env_pi;
-    unsigned long long* kcount;  // optional: sum over 32-row blocks of the k-window length (profiling)
+    unsigned long long* kcount;  // optional: sum over 32-row blocks of the contracted k length (profiling)
 };
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -67,11 +77,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p) {
+#ifndef MSG_WAVES_PER_SIMD
+#define MSG_WAVES_PER_SIMD 2
+#endif
+template <bool F16>
+__global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_kernel(MsgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // carve: [R*192] weights | [192] bias | [128] mu | [8 waves][32][8] row meta | work counter
+    // carve: weight image | [192] bias | [128] mu | [8 waves][32][8] row meta | work counter
+    const int wfloats = F16 ? (2 * MSG_COLS * MSG_LDK) / 2 : p.R * MSG_COLS;
     float* Wl = lds;
-    float* Bl = Wl + p.R * MSG_COLS;
+    _Float16* Wh = reinterpret_cast<_Float16*>(lds);       // [192][MSG_LDK] hi
+    _Float16* Wlo = Wh + MSG_COLS * MSG_LDK;               // [192][MSG_LDK] lo
+    float* Bl = lds + wfloats;
     float* Mu = Bl + MSG_COLS;
     float* Meta = Mu + 128;
     int* Ctr = reinterpret_cast<int*>(Meta + MSG_WAVES * 32 * 8);
@@ -88,20 +105,35 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
     const int c0 = slice * ADF_SLICE_CH;
 
     {   // stage this slice's rbf_proj image once
-        const float4* src = reinterpret_cast<const float4*>(p.wpack + (size_t)slice * p.R * MSG_COLS);
-        float4* dst = reinterpret_cast<float4*>(Wl);
-        const int n4 = p.R * MSG_COLS / 4;
-        for (int i = tid; i < n4; i += MSG_THREADS) dst[i] = src[i];
+        if (F16) {
+            const int R8 = p.R / 8;  // 16-B pieces per column row
+            const half8* src = reinterpret_cast<const half8*>(p.wpack16 + (size_t)slice * 2 * MSG_COLS * p.R);
+            for (int i = tid; i < 2 * MSG_COLS * R8; i += MSG_THREADS) {
+                const int row = i / R8, piece = i - row * R8;  // row in [0, 384): hi rows then lo rows
+                *reinterpret_cast<half8*>(Wh + (size_t)row * MSG_LDK + piece * 8) = src[i];
+            }
+        } else {
+            const float4* src = reinterpret_cast<const float4*>(p.wpack + (size_t)slice * p.R * MSG_COLS);
+            float4* dst = reinterpret_cast<float4*>(Wl);
+            const int n4 = p.R * MSG_COLS / 4;
+            for (int i = tid; i < n4; i += MSG_THREADS) dst[i] = src[i];
+        }
         if (tid < MSG_COLS) Bl[tid] = p.bpack[slice * MSG_COLS + tid];
-        if (tid < p.R) Mu[tid] = p.mu[tid];
+        if (tid < 128) Mu[tid] = tid < p.R ? p.mu[tid] : 2.0f;
         if (tid == 0) *Ctr = 0;
     }
     __syncthreads();
     float* meta_w = Meta + wave * 32 * 8;
     const float inv_sqrt3 = 0.57735026918962576f;
     const float inv_sqrt2 = 0.70710678118654752f;
-    const float inv_sqrt_h = 1.0f / sqrtf((float)H);
+    const float out_scale = F16 ? *p.inv_scale * (1.0f / 256.0f) : 1.0f;  // accumulators hold 256*scale*rbfh (f16)
+    const float inv_sqrt_h = out_scale / sqrtf((float)H);
     const float umax_scale = (float)(p.R - 1);
+    const float coeff2 = p.coeff * 1.44269504088896341f;  // exp(c z) = exp2(c log2e z)
+    const unsigned int row_bytes = 3u * H * sizeof(float);
+    const char* xh_b = reinterpret_cast<const char*>(p.xh) + (size_t)(c0 + 2 * q) * sizeof(float);
+    const char* vec_b = reinterpret_cast<const char*>(p.vec) + (size_t)(c0 + 2 * q) * sizeof(float);
+    const unsigned int hb = (unsigned int)H * sizeof(float);
 
     unsigned int ksteps = 0;  // wave-uniform; one global atomic per wave at the very end (profiling)
     // work item t of this workgroup -> target atom (group = worker + (t/32)*nworkers, node = t%32):
@@ -136,7 +168,8 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
             __builtin_amdgcn_wave_barrier();  // previous block's meta reads are done
             if (hi == 0) {
                 float* m = meta_w + q * 8;
-                m[0] = __int_as_float(valid ? src : p.N);  // row N of xh is all zeros
+                // byte offset of the source row; padded rows gather the all-zero row N of xh
+                m[0] = __uint_as_float((unsigned int)(valid ? src : p.N) * row_bytes);
                 m[1] = geo.x; m[2] = geo.y; m[3] = geo.z;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -145,26 +178,31 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
             const float u = xs * umax_scale;
             const float umin = wave_min(valid ? u : 1e30f);
             const float umax = wave_max(valid ? u : -1e30f);
-            int klo = max(0, (int)floorf(umin) - 7) & ~1;
-            int khi = min(p.R, ((int)ceilf(umax) + 8 + 1) & ~1);
+            int klo, khi;
+            if (F16) {
+                klo = max(0, (int)floorf(umin) - 7) & ~7;
+                khi = min(p.R, (int)ceilf(umax) + 8);
+                khi = klo + ((khi - klo + 15) & ~15);       // whole 16-deep MFMA steps
+                if (khi > 128) { klo -= khi - 128; khi = 128; }  // keep the LDS reads inside the image
+            } else {
+                klo = max(0, (int)floorf(umin) - 7) & ~1;
+                khi = min(p.R, ((int)ceilf(umax) + 8 + 1) & ~1);
+            }
             klo = __builtin_amdgcn_readfirstlane(klo);
             khi = __builtin_amdgcn_readfirstlane(khi);
             ksteps += khi - klo;
 
-            // Gather addresses of the 16 accumulator rows of this lane.  Padded rows point at the
-            // all-zero row N of xh, so their messages vanish without a branch.
+            // Gather addresses of the 16 accumulator rows of this lane (32-bit byte offsets).
 #define ROW_OF(r) ((r & 3) + 8 * (r >> 2) + 4 * hi)
 #define GATHER(r)                                                                               \
     const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
-    const int s##r = __float_as_int(m##r[0]);                                                   \
-    const float* xp##r = p.xh + (size_t)s##r * 3 * H + c0 + 2 * q;                              \
-    const float* vp##r = p.vec + (size_t)s##r * 3 * H + c0 + 2 * q;                             \
-    const float2 xa##r = *reinterpret_cast<const float2*>(xp##r);                               \
-    const float2 xb##r = *reinterpret_cast<const float2*>(xp##r + H);                           \
-    const float2 xc##r = *reinterpret_cast<const float2*>(xp##r + 2 * H);                       \
-    const float2 va##r = *reinterpret_cast<const float2*>(vp##r);                               \
-    const float2 vb##r = *reinterpret_cast<const float2*>(vp##r + H);                           \
-    const float2 vc##r = *reinterpret_cast<const float2*>(vp##r + 2 * H);
+    const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
+    const float2 xa##r = *reinterpret_cast<const float2*>(xh_b + o##r);                         \
+    const float2 xb##r = *reinterpret_cast<const float2*>(xh_b + o##r + hb);                    \
+    const float2 xc##r = *reinterpret_cast<const float2*>(xh_b + o##r + 2 * hb);                \
+    const float2 va##r = *reinterpret_cast<const float2*>(vec_b + o##r);                        \
+    const float2 vb##r = *reinterpret_cast<const float2*>(vec_b + o##r + hb);                   \
+    const float2 vc##r = *reinterpret_cast<const float2*>(vec_b + o##r + 2 * hb);
 #define CONSUME(r)                                                                              \
     {                                                                                           \
         const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
@@ -179,9 +217,12 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
         sa1 += va##r.y * u2; sb1 += vb##r.y * u2; sc1 += vc##r.y * u2;                          \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
+#ifndef MSG_NO_PREFETCH
             // rows 0-3: issued before the MFMA loop, they land while the matrix pipe is busy
             GATHER(0) GATHER(1) GATHER(2) GATHER(3)
+#endif
 
+            const float env256 = env * 256.0f;
             f32x16 acc[6];
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
@@ -189,17 +230,57 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[b][r] = bv;
             }
-            for (int k2 = klo; k2 < khi; k2 += 2) {
-                const int k = k2 + hi;
-                const float dm = xs - Mu[k];
-                // exp via v_exp_f32 (exp2): |arg| <= 24.5 inside the window, relative error <= ~2e-6 on
-                // the smallest kept terms and ~1e-7 on the leading ones
-                const float a = env * __builtin_amdgcn_exp2f((p.coeff * 1.44269504088896341f) * (dm * dm));
-                const float* wrow = Wl + k * MSG_COLS + q;
+            if (F16) {
+                for (int k0 = klo; k0 < khi; k0 += 16) {
+                    // A fragment: lane (row q, half hi) holds k = k0 + 8*hi + j, j = 0..7
+                    const float4 mu0 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi);
+                    const float4 mu1 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi + 4);
+                    const float mus[8] = {mu0.x, mu0.y, mu0.z, mu0.w, mu1.x, mu1.y, mu1.z, mu1.w};
+                    half8 ah, al;
 #pragma unroll
-                for (int b = 0; b < 6; ++b)
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[b * 32], acc[b], 0, 0, 0);
+                    for (int j = 0; j < 8; ++j) {
+                        const float dm = xs - mus[j];
+                        // a in [0,1] is lifted by 2^8 before the split so that a_lo is a normal fp16 number
+                        // for every term that matters (the matrix core flushes fp16 subnormals)
+                        const float a = env256 * __builtin_amdgcn_exp2f(coeff2 * (dm * dm));
+                        const _Float16 h = (_Float16)a;
+                        ah[j] = h;
+                        al[j] = (_Float16)(a - (float)h);
+                    }
+                    const _Float16* wh = Wh + (size_t)q * MSG_LDK + k0 + 8 * hi;
+                    const _Float16* wl = Wlo + (size_t)q * MSG_LDK + k0 + 8 * hi;
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        const half8 bh = *reinterpret_cast<const half8*>(wh + b * 32 * MSG_LDK);
+                        const half8 bl = *reinterpret_cast<const half8*>(wl + b * 32 * MSG_LDK);
+#ifndef MSG_ONE_PRODUCT
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+#endif
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                    }
+                }
+#ifdef MSG_EXTRA_NOPS
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            } else {
+                for (int k2 = klo; k2 < khi; k2 += 2) {
+                    const int k = k2 + hi;
+                    const float dm = xs - Mu[k];
+                    // exp via v_exp_f32 (exp2): |arg| <= 24.5 inside the window, relative error <= ~2e-6
+                    // on the smallest kept terms and ~1e-7 on the leading ones
+                    const float a = env * __builtin_amdgcn_exp2f(coeff2 * (dm * dm));
+                    const float* wrow = Wl + k * MSG_COLS + q;
+#pragma unroll
+                    for (int b = 0; b < 6; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[b * 32], acc[b], 0, 0, 0);
+                }
             }
+#ifdef MSG_NO_PREFETCH
+            GATHER(0) GATHER(1) GATHER(2) GATHER(3)
+#endif
             // epilogue, software pipelined: next rows' gathers are in flight while rows are consumed
             GATHER(4) GATHER(5) GATHER(6) GATHER(7)
             CONSUME(0) CONSUME(1) CONSUME(2) CONSUME(3)
@@ -212,6 +293,7 @@ __global__ __launch_bounds__(MSG_THREADS, 2) void adf_message_kernel(MsgParams p
 #undef CONSUME
 #undef ROW_OF
         }
+        sx0 *= out_scale; sx1 *= out_scale;
         sa0 = (sa0 * inv_sqrt3 + ra0) * inv_sqrt_h; sa1 = (sa1 * inv_sqrt3 + ra1) * inv_sqrt_h;
         sb0 = (sb0 * inv_sqrt3 + rb0) * inv_sqrt_h; sb1 = (sb1 * inv_sqrt3 + rb1) * inv_sqrt_h;
         sc0 = (sc0 * inv_sqrt3 + rc0) * inv_sqrt_h; sc1 = (sc1 * inv_sqrt3 + rc1) * inv_sqrt_h;
@@ -254,8 +336,38 @@ __global__ void adf_pack_rbf_kernel(const float* __restrict__ w, const float* __
     }
 }
 
-static size_t msg_lds_bytes(int R) {
-    return sizeof(float) * ((size_t)R * MSG_COLS + MSG_COLS + 128 + MSG_WAVES * 32 * 8) + 16;
+// f16 image: [slice][hi|lo][col][k] halves of (w * scale), bias16 = bias * scale.
+// scale = power of two with |w*scale| in [2^9, 2^10)  (absmax from adf_absmax_kernel, gemm16.hip)
+__global__ void adf_pack_rbf16_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                      const unsigned int* absmax_bits, _Float16* wpack16, float* bpack16,
+                                      float* inv_scale, int H, int R) {
+    const float amax = __uint_as_float(*absmax_bits);
+    int e = 0;
+    if (amax > 0.f) (void)frexpf(amax, &e);
+    const float scale = ldexpf(1.0f, 10 - e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = 1.0f / scale;
+    const int nslices = H / ADF_SLICE_CH;
+    const int total = nslices * MSG_COLS * R;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int k = i % R;
+        const int col = (i / R) % MSG_COLS;
+        const int slice = i / (R * MSG_COLS);
+        const int part = col / 64, j = (col >> 5) & 1, qq = col & 31;
+        const int ch = slice * ADF_SLICE_CH + 2 * qq + j;
+        const float v = w[(size_t)(part * H + ch) * R + k] * scale;
+        const _Float16 h = (_Float16)v;
+        const size_t base = (size_t)slice * 2 * MSG_COLS * R;
+        wpack16[base + (size_t)col * R + k] = h;
+        wpack16[base + (size_t)(MSG_COLS + col) * R + k] = (_Float16)(v - (float)h);
+        if (k == 0) bpack16[slice * MSG_COLS + col] = b[part * H + ch] * scale * 256.0f;  // matches the 2^8 lift of A
+    }
+}
+
+__global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsigned int* out_bits);
+
+static size_t msg_lds_bytes(int R, bool f16) {
+    const size_t w = f16 ? (size_t)2 * MSG_COLS * MSG_LDK * 2 : sizeof(float) * (size_t)R * MSG_COLS;
+    return w + sizeof(float) * (MSG_COLS + 128 + MSG_WAVES * 32 * 8) + 16;
 }
 
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
@@ -265,12 +377,20 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
     for (int l = 0; l < h->hp.num_layers; ++l) {
         hipLaunchKernelGGL(adf_pack_rbf_kernel, dim3(256), dim3(256), 0, s, h->layer[l].rbf_w, h->layer[l].rbf_b,
                            h->rbf_pack + l * per_layer, h->rbf_bias_pack + l * per_layer_b, H, R);
+        ADF_HIP_CHECK(hipMemsetAsync(h->w16_scratch, 0, sizeof(unsigned int), s));
+        hipLaunchKernelGGL(adf_absmax_kernel, dim3(64), dim3(256), 0, s, h->layer[l].rbf_w, (long long)3 * H * R,
+                           h->w16_scratch);
+        hipLaunchKernelGGL(adf_pack_rbf16_kernel, dim3(256), dim3(256), 0, s, h->layer[l].rbf_w, h->layer[l].rbf_b,
+                           h->w16_scratch, reinterpret_cast<_Float16*>(h->rbf_pack16) + l * 2 * per_layer,
+                           h->rbf_bias_pack16 + l * per_layer_b, h->rbf_scales + l, H, R);
     }
     ADF_HIP_CHECK(hipGetLastError());
     static bool attr_set = false;
     if (!attr_set) {
-        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128)));
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128, false)));
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128, true)));
         attr_set = true;
     }
     return ADF_OK;
@@ -279,12 +399,19 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, hipStream_t s) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
+    if ((unsigned long long)(N + 1) * 3ull * H * sizeof(float) >= (1ull << 32)) {
+        adf_set_error("message kernel uses 32-bit byte offsets into the node tables: N=%d is too large, split the batch", N);
+        return ADF_EOOM;  // surfaces as RuntimeError -> ml_diffuse splits the batch
+    }
     MsgParams p;
     p.xh = xh; p.vec = vec; p.x = x; p.x_out = x_out; p.vec_out = vec_out;
     p.nptr = h->nptr; p.e_src = h->e_src; p.e_geom = h->e_geom;
     p.nslices = H / ADF_SLICE_CH;
+    const bool f16 = !h->msg_f32;
     p.wpack = h->rbf_pack + (size_t)layer * p.nslices * R * MSG_COLS;
-    p.bpack = h->rbf_bias_pack + (size_t)layer * p.nslices * MSG_COLS;
+    p.wpack16 = reinterpret_cast<const _Float16*>(h->rbf_pack16) + (size_t)layer * 2 * p.nslices * R * MSG_COLS;
+    p.bpack = (f16 ? h->rbf_bias_pack16 : h->rbf_bias_pack) + (size_t)layer * p.nslices * MSG_COLS;
+    p.inv_scale = h->rbf_scales + layer;
     p.mu = h->rbf_offset;
     p.N = N; p.H = H; p.R = R;
     p.G = (N + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
@@ -301,7 +428,10 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     if (workers < 1) workers = 1;
     if (workers > p.G) workers = p.G;
     dim3 grid((unsigned)(workers * p.nslices));
-    hipLaunchKernelGGL(adf_message_kernel, grid, dim3(MSG_THREADS), msg_lds_bytes(R), s, p);
+    if (f16)
+        hipLaunchKernelGGL(adf_message_kernel<true>, grid, dim3(MSG_THREADS), msg_lds_bytes(R, true), s, p);
+    else
+        hipLaunchKernelGGL(adf_message_kernel<false>, grid, dim3(MSG_THREADS), msg_lds_bytes(R, false), s, p);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

@@ -55,6 +55,11 @@ _LIB = None
 
 
 def lib_path() -> Path:
+    import os
+
+    override = os.environ.get("ADF_LIB_PATH")  # development only: A/B a differently built library
+    if override:
+        return Path(override)
     return Path(__file__).resolve().parent / "libadsorbdiff_hip.so"
 
 
