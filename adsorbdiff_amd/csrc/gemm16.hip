@@ -13,11 +13,13 @@
 // while they are staged into LDS.  The exact-f32 kernel (gemm.hip) stays selectable
 // (ADF_GEMM=f32) and is what this kernel is tested against.
 //
-// Tiling: 256(M) x 128(N) x 32(K) per 512-thread workgroup, 8 waves as 4(M) x 2(N), each wave 64x64 =
-// 2x2 MFMA 32x32 accumulators.  LDS holds A_hi, A_lo [256][32+8] and W_hi, W_lo [128][32+8] halves
+// Tiling: 256(M) x 256(N) x 32(K) per 256-thread workgroup, 4 waves as 2(M) x 2(N), each wave 128x128 =
+// 4x4 MFMA 32x32 accumulators.  LDS holds A_hi, A_lo [256][32+8] and W_hi, W_lo [256][32+8] halves
 // (row stride 80 B: the 16 lanes of a ds_read_b128 lane group land on 16 distinct 16-B bank quads).
 // Global loads are 16 B per lane, prefetched one K-tile ahead in registers; XCD-aware tile map as in
 // gemm.hip (all N-tiles of an M-panel on one XCD's L2).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,7 +27,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 #define HM 256
-#define HN 128
+#define HN 256
 #define HK 32
 #define HLD 40  // halves per LDS row (32 + 8 pad)
 
@@ -34,60 +36,74 @@ __device__ __forceinline__ float ssilu16(float x) {
     return s * 1.6666666666666667f;
 }
 
-template <int ACT>
-__global__ __launch_bounds__(512, 2) void adf_gemm_f16x3_kernel(const float* __restrict__ A, int lda,
+// 256 x 256 x 32 tile, 4 waves as 2(M) x 2(N), each wave 128 x 128 = 4 x 4 MFMA 32x32 accumulators
+// (256 acc VGPRs, one wave per SIMD): every A/B fragment read from LDS feeds 4 MFMAs x 3 products,
+// which keeps the LDS pipe at ~40 % of the matrix pipe's time.
+template <int ACT, int MI>
+__global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(const float* __restrict__ A, int lda,
                                                                  const _Float16* __restrict__ Whi,
                                                                  const _Float16* __restrict__ Wlo,
                                                                  const float* __restrict__ inv_scale,
                                                                  const float* __restrict__ bias, float* __restrict__ C,
                                                                  int ldc, int M, int N, int K, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * HM + 2 * HN) * HLD];
+    constexpr int TM = 64 * MI;   // rows per workgroup: 2 waves x MI blocks of 32
+    constexpr int NA = TM / 32;   // float4 A loads per thread
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * HN) * HLD];
     _Float16* Ahi = lds;
-    _Float16* Alo = Ahi + HM * HLD;
-    _Float16* Bhi = Alo + HM * HLD;
+    _Float16* Alo = Ahi + TM * HLD;
+    _Float16* Bhi = Alo + TM * HLD;
     _Float16* Blo = Bhi + HN * HLD;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave >> 1) * 64;
-    const int wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (32 * MI);
+    const int wn = (wave & 1) * 128;
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
     const int qd = id >> 3;
     const int tile_m = (qd / tiles_n) * 8 + xcd;
     const int tile_n = qd % tiles_n;
-    const int m0 = tile_m * HM;
+    const int m0 = tile_m * TM;
     const int n0 = tile_n * HN;
     if (m0 >= M) return;
 
-    // A staging: 4 float4 per thread (8 lanes per 128-B row segment)
-    const float* a_ptr[4];
-    int a_off[4];
+    // A staging: 8 float4 per thread (8 lanes per 128-B row segment, 32 rows per pass)
+    const float* a_ptr[NA];
+    int a_off[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + 512 * i;
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
         const int row = f >> 3, kq = f & 7;
         a_ptr[i] = A + (size_t)min(m0 + row, M - 1) * lda + kq * 4;
         a_off[i] = row * HLD + kq * 4;
     }
-    // W staging: one 16-B piece (8 halves) of hi and of lo per thread
-    const int wrow = tid >> 2, wpart = tid & 3;
-    const size_t w_src = (size_t)min(n0 + wrow, N - 1) * K + wpart * 8;
-    const int w_off = wrow * HLD + wpart * 8;
+    // W staging: 4 pieces of 16 B (8 halves) of hi and of lo per thread (4 lanes per 64-B row)
+    size_t w_src[4];
+    int w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        const int row = f >> 2, part = f & 3;
+        w_src[i] = (size_t)min(n0 + row, N - 1) * K + part * 8;
+        w_off[i] = row * HLD + part * 8;
+    }
 
-    float4 ra[4];
-    half8 rwh, rwl;
+    float4 ra[NA];
+    half8 rwh[4], rwl[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
-    rwh = *reinterpret_cast<const half8*>(Whi + w_src);
-    rwl = *reinterpret_cast<const half8*>(Wlo + w_src);
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i]);
+        rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i]);
+    }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void adf_gemm_f16x3_kernel(const float* __r
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             half4 h, l;
             h[0] = (_Float16)ra[i].x; h[1] = (_Float16)ra[i].y; h[2] = (_Float16)ra[i].z; h[3] = (_Float16)ra[i].w;
             l[0] = (_Float16)(ra[i].x - (float)h[0]); l[1] = (_Float16)(ra[i].y - (float)h[1]);
@@ -105,45 +121,52 @@ __global__ __launch_bounds__(512, 2) void adf_gemm_f16x3_kernel(const float* __r
             *reinterpret_cast<half4*>(Ahi + a_off[i]) = h;
             *reinterpret_cast<half4*>(Alo + a_off[i]) = l;
         }
-        *reinterpret_cast<half8*>(Bhi + w_off) = rwh;
-        *reinterpret_cast<half8*>(Blo + w_off) = rwl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<half8*>(Bhi + w_off[i]) = rwh[i];
+            *reinterpret_cast<half8*>(Blo + w_off[i]) = rwl[i];
+        }
         __syncthreads();
         if (kt + 1 < nk) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)(kt + 1) * HK);
-            rwh = *reinterpret_cast<const half8*>(Whi + w_src + (size_t)(kt + 1) * HK);
-            rwl = *reinterpret_cast<const half8*>(Wlo + w_src + (size_t)(kt + 1) * HK);
+            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)(kt + 1) * HK);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + (size_t)(kt + 1) * HK);
+                rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + (size_t)(kt + 1) * HK);
+            }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8 ah[2], al[2], bh[2], bl[2];
+            half8 bh[4], bl[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const half8*>(Ahi + fa + i * 32 * HLD + ks * 16);
-                al[i] = *reinterpret_cast<const half8*>(Alo + fa + i * 32 * HLD + ks * 16);
-                bh[i] = *reinterpret_cast<const half8*>(Bhi + fb + i * 32 * HLD + ks * 16);
-                bl[i] = *reinterpret_cast<const half8*>(Blo + fb + i * 32 * HLD + ks * 16);
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *reinterpret_cast<const half8*>(Bhi + fb + j * 32 * HLD + ks * 16);
+                bl[j] = *reinterpret_cast<const half8*>(Blo + fb + j * 32 * HLD + ks * 16);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i) {
+                const half8 ah = *reinterpret_cast<const half8*>(Ahi + fa + i * 32 * HLD + ks * 16);
+                const half8 al = *reinterpret_cast<const half8*>(Alo + fa + i * 32 * HLD + ks * 16);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < 4; ++j) {
                     // small terms first, then the leading product
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
                 }
+            }
         }
     }
 
     const float isc = *inv_scale;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn + 32 * j + (lane & 31);
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -199,16 +222,19 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
         adf_set_error("gemm16: K=%d must be a multiple of %d and lda a multiple of 4", K, HK);
         return ADF_EINVAL;
     }
+    static int mi = 0;
+    if (!mi) { const char* e = getenv("ADF_GEMM16_MI"); mi = e ? atoi(e) : 2; if (mi != 4) mi = 2; }
+    const int TM = 64 * mi;
     const int tiles_n = (N + HN - 1) / HN;
-    const int tiles_m = (M + HM - 1) / HM;
+    const int tiles_m = (M + TM - 1) / TM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
-    if (act_ssilu)
-        hipLaunchKernelGGL(adf_gemm_f16x3_kernel<1>, grid, dim3(512), 0, s, A, lda, (const _Float16*)W->hi,
-                           (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, tiles_n);
-    else
-        hipLaunchKernelGGL(adf_gemm_f16x3_kernel<0>, grid, dim3(512), 0, s, A, lda, (const _Float16*)W->hi,
-                           (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, tiles_n);
+#define LAUNCH16(ACT_, MI_)                                                                                       \
+    hipLaunchKernelGGL((adf_gemm_f16x3_kernel<ACT_, MI_>), grid, dim3(256), 0, s, A, lda, (const _Float16*)W->hi, \
+                       (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, tiles_n)
+    if (mi == 4) { if (act_ssilu) LAUNCH16(1, 4); else LAUNCH16(0, 4); }
+    else { if (act_ssilu) LAUNCH16(1, 2); else LAUNCH16(0, 2); }
+#undef LAUNCH16
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
