@@ -385,7 +385,7 @@ static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
 }
 
 static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const float* vec, float* x_out,
-                             float* vec_out, hipStream_t s) {
+                             float* vec_out, bool vec_is_zero, hipStream_t s) {
     const int H = h->hp.hidden_channels;
     const adf_layer_weights& w = h->layer[l];
     // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
@@ -395,7 +395,7 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
     ADF_TRY(adf_linear(h, h->cat, H, w.xp2_w, &w.xp2_16, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
     adf_prof_end(h, s);
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
-    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, s);
+    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s);
     adf_prof_end(h, s);
     return st;
 }
@@ -424,7 +424,7 @@ extern "C" int32_t adf_painn_message_layer(adf_painn_t h, int32_t layer, int32_t
     const size_t bytes = sizeof(float) * (size_t)N * 3 * h->hp.hidden_channels;
     ADF_TRY(zero_pad_rows(h, N, s));
     ADF_HIP_CHECK(hipMemcpyAsync(h->vecA, vec, bytes, hipMemcpyDeviceToDevice, s));
-    ADF_TRY(message_layer(h, layer, N, x, h->vecA, x_out, h->vecB, s));
+    ADF_TRY(message_layer(h, layer, N, x, h->vecA, x_out, h->vecB, false, s));
     ADF_HIP_CHECK(hipMemcpyAsync(vec_out, h->vecB, bytes, hipMemcpyDeviceToDevice, s));
     return ADF_OK;
 }
@@ -449,11 +449,11 @@ extern "C" int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f
     ADF_TRY(adf_graph_build_impl(h, b, s));
     adf_prof_end(h, s);
     ADF_TRY(zero_pad_rows(h, N, s));
-    ADF_TRY(adf_nodewise_embed(h, b->atomic_numbers, N, h->x, h->vecA, s));
+    ADF_TRY(adf_nodewise_embed(h, b->atomic_numbers, N, h->x, s));  // vec = 0 is implicit in layer 0
     float* vin = h->vecA;
     float* vout = h->vecB;
     for (int l = 0; l < h->hp.num_layers; ++l) {
-        ADF_TRY(message_layer(h, l, N, h->x, vin, h->x, vout, s));
+        ADF_TRY(message_layer(h, l, N, h->x, vin, h->x, vout, l == 0, s));
         ADF_TRY(update_layer(h, l, N, h->x, vout, s));
         float* t = vin; vin = vout; vout = t;
     }

@@ -11,7 +11,7 @@
 
 #define ADF_GROUP_NODES 32      // target nodes per message-kernel work item
 #define ADF_SLICE_CH 64         // channels per message-kernel slice (x3 parts = 192 MFMA columns)
-#define ADF_MAX_CAND 4096       // in-cutoff candidates per centre held in LDS by the top-K kernel
+#define ADF_MAX_CAND 1024       // in-cutoff candidates per centre held in LDS by the top-K kernel
 #define ADF_MAX_K 128
 
 void adf_set_error(const char* fmt, ...);
@@ -120,9 +120,9 @@ static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, co
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
 size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
-                         float* x_out, float* vec_out, hipStream_t s);
+                         float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s);
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
-int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, float* vec, hipStream_t s);
+int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s);
 int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s);
 int32_t adf_nodewise_update_prep(const float* vv, const float* x, float* cat, float* dot, int N, int H, hipStream_t s);
 int32_t adf_nodewise_update_apply(const float* h3, const float* dot, const float* vv, float* x, float* vec,

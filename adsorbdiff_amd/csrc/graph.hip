@@ -9,9 +9,9 @@
 //                                                   negative shift), append reversed copies
 //
 // MI355X design: the graph is integer/HBM-latency work, not GEMM work.
-//   1. adf_topk_kernel: one 256-thread workgroup per centre atom.  All n x n_shift candidates
+//   1. adf_topk_kernel: one wave per centre atom.  All n x n_shift candidates
 //      of the centre's own system are evaluated from L2-resident positions; in-cutoff ones are
-//      compacted into LDS, then the K smallest are selected by rank counting on the key
+//      compacted into LDS (ballot + prefix popcount), then the K smallest are selected by rank counting on the key
 //      (d^2, candidate index) — i.e. a *stable* sort order.  (The reference's torch.sort is not
 //      stable, so for exact d^2 ties at the K-th place its pick is arbitrary; ours is the
 //      lowest candidate index.  Everything else is bit-identical: d^2 is evaluated with the
@@ -51,80 +51,125 @@ __device__ __forceinline__ void decode_shift(int c, int r0, int r1, int r2, floa
     sc = (float)(ic - r2);
 }
 
+// One wave per centre atom, 4 centres per workgroup.  Lane = neighbour atom j (64 per pass), inner
+// loop over the lattice shifts; in-cutoff candidates are compacted into the wave's LDS list with
+// ballot + prefix popcount (no atomics).  Selection of the K smallest keys (d^2, candidate index):
+// every lane keeps its candidates in registers and counts, for each of them, how many list entries
+// are smaller (entries are broadcast from LDS).  Survivors are emitted in candidate order.
+#define TOPK_CAP 1024  // in-cutoff candidates per centre (a 12 A sphere in a dense bulk holds ~630)
 __global__ __launch_bounds__(256) void adf_topk_kernel(GraphParams p) {
-    __shared__ float s_d2[ADF_MAX_CAND];
-    __shared__ int32_t s_id[ADF_MAX_CAND];
-    __shared__ int32_t s_kept[ADF_MAX_K];
-    __shared__ int32_t s_count, s_nkept;
-    const int i = blockIdx.x;
-    const int tid = threadIdx.x;
+    __shared__ float s_d2[4][TOPK_CAP];
+    __shared__ int32_t s_id[4][TOPK_CAP];
+    __shared__ float s_off[4][3 * 128];  // Cartesian offsets of the shift table (<= 125 shifts cached)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + w;
+    if (i >= p.N) return;
     const int b = p.batch[i];
     const int a0 = p.atom_offset[b];
     const int n = p.atom_offset[b + 1] - a0;
     const int C = (2 * p.r0 + 1) * (2 * p.r1 + 1) * (2 * p.r2 + 1);
-    const int ncand = n * C;
-    if (tid == 0) { s_count = 0; s_nkept = 0; }
     const float* cl = p.cell + 9 * b;
     const float c00 = cl[0], c01 = cl[1], c02 = cl[2];
     const float c10 = cl[3], c11 = cl[4], c12 = cl[5];
     const float c20 = cl[6], c21 = cl[7], c22 = cl[8];
+    const bool cached = C <= 128;
+    if (cached) {
+        for (int c = lane; c < C; c += 64) {
+            float sa, sb, sc;
+            decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
+            // offset = cell^T . shift, summed in k order without FMA (utils.py:680-681)
+            s_off[w][3 * c] = __fadd_rn(__fadd_rn(__fmul_rn(c00, sa), __fmul_rn(c10, sb)), __fmul_rn(c20, sc));
+            s_off[w][3 * c + 1] = __fadd_rn(__fadd_rn(__fmul_rn(c01, sa), __fmul_rn(c11, sb)), __fmul_rn(c21, sc));
+            s_off[w][3 * c + 2] = __fadd_rn(__fadd_rn(__fmul_rn(c02, sa), __fmul_rn(c12, sb)), __fmul_rn(c22, sc));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     const float pix = p.pos[3 * i], piy = p.pos[3 * i + 1], piz = p.pos[3 * i + 2];
-    __syncthreads();
-    for (int cid = tid; cid < ncand; cid += 256) {
-        const int j = cid / C;
-        const int c = cid - j * C;
-        float sa, sb, sc;
-        decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
-        // offset = cell^T . shift, summed in k order without FMA (utils.py:680-681)
-        const float ox = __fadd_rn(__fadd_rn(__fmul_rn(c00, sa), __fmul_rn(c10, sb)), __fmul_rn(c20, sc));
-        const float oy = __fadd_rn(__fadd_rn(__fmul_rn(c01, sa), __fmul_rn(c11, sb)), __fmul_rn(c21, sc));
-        const float oz = __fadd_rn(__fadd_rn(__fmul_rn(c02, sa), __fmul_rn(c12, sb)), __fmul_rn(c22, sc));
-        const float* pj = p.pos + 3 * (size_t)(a0 + j);
-        const float dx = __fsub_rn(pix, __fadd_rn(pj[0], ox));
-        const float dy = __fsub_rn(piy, __fadd_rn(pj[1], oy));
-        const float dz = __fsub_rn(piz, __fadd_rn(pj[2], oz));
-        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        if (d2 <= p.rc2 && d2 > 0.0001f) {
-            const int slot = atomicAdd(&s_count, 1);
-            if (slot < ADF_MAX_CAND) { s_d2[slot] = d2; s_id[slot] = cid; }
-        }
-    }
-    __syncthreads();
-    int M = s_count;
-    if (M > ADF_MAX_CAND) {
-        if (tid == 0) atomicExch(&p.flags[0], 1);
-        M = ADF_MAX_CAND;
-    }
-    const int K = p.K;
-    // rank selection on (d2, cid)
-    for (int e = tid; e < M; e += 256) {
-        bool keep = true;
-        if (M > K) {
-            const float d = s_d2[e];
-            const int id = s_id[e];
-            int rank = 0;
-            for (int f = 0; f < M; ++f) {
-                const float df = s_d2[f];
-                rank += (df < d) || (df == d && s_id[f] < id);
+    int M = 0;  // wave-uniform count of in-cutoff candidates
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        const bool jv = j < n;
+        const float* pj = p.pos + 3 * (size_t)(a0 + (jv ? j : 0));
+        const float pjx = pj[0], pjy = pj[1], pjz = pj[2];
+        for (int c = 0; c < C; ++c) {
+            float ox, oy, oz;
+            if (cached) {
+                ox = s_off[w][3 * c]; oy = s_off[w][3 * c + 1]; oz = s_off[w][3 * c + 2];
+            } else {
+                float sa, sb, sc;
+                decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
+                ox = __fadd_rn(__fadd_rn(__fmul_rn(c00, sa), __fmul_rn(c10, sb)), __fmul_rn(c20, sc));
+                oy = __fadd_rn(__fadd_rn(__fmul_rn(c01, sa), __fmul_rn(c11, sb)), __fmul_rn(c21, sc));
+                oz = __fadd_rn(__fadd_rn(__fmul_rn(c02, sa), __fmul_rn(c12, sb)), __fmul_rn(c22, sc));
             }
-            keep = rank < K;
-        }
-        if (keep) {
-            const int slot = atomicAdd(&s_nkept, 1);
-            s_kept[slot] = s_id[e];
+            const float dx = __fsub_rn(pix, __fadd_rn(pjx, ox));
+            const float dy = __fsub_rn(piy, __fadd_rn(pjy, oy));
+            const float dz = __fsub_rn(piz, __fadd_rn(pjz, oz));
+            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            const bool in = jv && d2 <= p.rc2 && d2 > 0.0001f;
+            const unsigned long long mask = __ballot(in);
+            if (in) {
+                const int slot = M + __popcll(mask & ((1ull << lane) - 1ull));
+                if (slot < TOPK_CAP) { s_d2[w][slot] = d2; s_id[w][slot] = j * C + c; }
+            }
+            M += __popcll(mask);
         }
     }
-    __syncthreads();
-    const int nk = s_nkept;
-    if (tid < nk) {
-        const int id = s_kept[tid];
+    if (M > TOPK_CAP) {
+        if (lane == 0) atomicExch(&p.flags[0], 1);
+        M = TOPK_CAP;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int K = p.K;
+    // keep[e] for the lane's entries e = lane + 64*t
+    unsigned int keepbits = 0;  // bit t
+    const int T = (M + 63) >> 6;  // <= 16
+    if (M <= K) {
+        keepbits = 0xFFFFu;
+    } else {
+        for (int t0 = 0; t0 < T; t0 += 4) {  // 4 entries of this lane at a time
+            float d[4]; int id[4]; int rank[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = lane + 64 * (t0 + u);
+                d[u] = e < M ? s_d2[w][e] : 3.0e38f;
+                id[u] = e < M ? s_id[w][e] : 0x7fffffff;
+                rank[u] = 0;
+            }
+            for (int f = 0; f < M; ++f) {
+                const float df = s_d2[w][f];
+                const int idf = s_id[w][f];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rank[u] += ((df < d[u]) || (df == d[u] && idf < id[u])) ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (rank[u] < K) keepbits |= 1u << (t0 + u);
+        }
+    }
+    // survivors in candidate order: position = number of survivors with a smaller candidate index
+    __shared__ int32_t s_kept[4][ADF_MAX_K];
+    int nk = 0;
+    for (int t = 0; t < T; ++t) {
+        const int e = lane + 64 * t;
+        const bool kp = e < M && ((keepbits >> t) & 1u);
+        const unsigned long long mask = __ballot(kp);
+        if (kp) s_kept[w][nk + __popcll(mask & ((1ull << lane) - 1ull))] = s_id[w][e];
+        nk += __popcll(mask);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < nk; t += 64) {
+        const int id = s_kept[w][t];
         int posn = 0;
-        for (int f = 0; f < nk; ++f) posn += s_kept[f] < id;
+        for (int f = 0; f < nk; ++f) posn += s_kept[w][f] < id;
         const int j = id / C;
         p.nbr_src[(size_t)i * K + posn] = a0 + j;
         p.nbr_shift[(size_t)i * K + posn] = id - j * C;
     }
-    if (tid == 0) {
+    if (lane == 0) {
         p.nbr_cnt[i] = nk;
         if (nk) atomicAdd(&p.img_cnt[b], nk);
     }
@@ -241,7 +286,7 @@ int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
     ADF_HIP_CHECK(hipMemsetAsync(h->cursor, 0, sizeof(int32_t) * N, s));
     ADF_HIP_CHECK(hipMemsetAsync(h->img_cnt, 0, sizeof(int32_t) * B, s));
     ADF_HIP_CHECK(hipMemsetAsync(h->flags, 0, sizeof(int32_t) * 4, s));
-    hipLaunchKernelGGL(adf_topk_kernel, dim3(N), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(adf_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, s, p);
     const long long slots = (long long)N * K;
     const unsigned nb = (unsigned)((slots + 255) / 256);
     hipLaunchKernelGGL(adf_count_kernel, dim3(nb), dim3(256), 0, s, p, h->deg);

@@ -80,7 +80,9 @@ __device__ __forceinline__ float wave_max(float v) {
 #ifndef MSG_WAVES_PER_SIMD
 #define MSG_WAVES_PER_SIMD 2
 #endif
-template <bool F16>
+// VZ = true: vec is identically zero on entry (first layer, painn_denoising.py:426) — its gathers,
+// the vec*b sums and the residual read are skipped.
+template <bool F16, bool VZ>
 __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_kernel(MsgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // carve: weight image | [192] bias | [128] mu | [8 waves][32][8] row meta | work counter
@@ -200,21 +202,24 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const float2 xa##r = *reinterpret_cast<const float2*>(xh_b + o##r);                         \
     const float2 xb##r = *reinterpret_cast<const float2*>(xh_b + o##r + hb);                    \
     const float2 xc##r = *reinterpret_cast<const float2*>(xh_b + o##r + 2 * hb);                \
-    const float2 va##r = *reinterpret_cast<const float2*>(vec_b + o##r);                        \
-    const float2 vb##r = *reinterpret_cast<const float2*>(vec_b + o##r + hb);                   \
-    const float2 vc##r = *reinterpret_cast<const float2*>(vec_b + o##r + 2 * hb);
+    float2 va##r = make_float2(0.f, 0.f), vb##r = va##r, vc##r = va##r;                         \
+    if (!VZ) {                                                                                  \
+        va##r = *reinterpret_cast<const float2*>(vec_b + o##r);                                 \
+        vb##r = *reinterpret_cast<const float2*>(vec_b + o##r + hb);                            \
+        vc##r = *reinterpret_cast<const float2*>(vec_b + o##r + 2 * hb);                        \
+    }
 #define CONSUME(r)                                                                              \
     {                                                                                           \
         const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
         const float t2 = xb##r.x * acc[2][r];                                                   \
         const float t3 = xc##r.x * acc[4][r];                                                   \
         sx0 += xa##r.x * acc[0][r];                                                             \
-        sa0 += va##r.x * t2; sb0 += vb##r.x * t2; sc0 += vc##r.x * t2;                          \
+        if (!VZ) { sa0 += va##r.x * t2; sb0 += vb##r.x * t2; sc0 += vc##r.x * t2; }             \
         ra0 += t3 * ux; rb0 += t3 * uy; rc0 += t3 * uz;                                         \
         const float u2 = xb##r.y * acc[3][r];                                                   \
         const float u3 = xc##r.y * acc[5][r];                                                   \
         sx1 += xa##r.y * acc[1][r];                                                             \
-        sa1 += va##r.y * u2; sb1 += vb##r.y * u2; sc1 += vc##r.y * u2;                          \
+        if (!VZ) { sa1 += va##r.y * u2; sb1 += vb##r.y * u2; sc1 += vc##r.y * u2; }             \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
 #ifndef MSG_NO_PREFETCH
@@ -308,12 +313,16 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
         if (hi == 0) {
             const float2 xin = *reinterpret_cast<const float2*>(p.x + xo);
             *reinterpret_cast<float2*>(p.x_out + xo) = make_float2((xin.x + sx0) * inv_sqrt2, (xin.y + sx1) * inv_sqrt2);
-            const float2 vin = *reinterpret_cast<const float2*>(p.vec + vo);
+            float2 vin = make_float2(0.f, 0.f);
+            if (!VZ) vin = *reinterpret_cast<const float2*>(p.vec + vo);
             *reinterpret_cast<float2*>(p.vec_out + vo) = make_float2(vin.x + sa0, vin.y + sa1);
         } else {
-            const float2 vin1 = *reinterpret_cast<const float2*>(p.vec + vo + H);
+            float2 vin1 = make_float2(0.f, 0.f), vin2 = vin1;
+            if (!VZ) {
+                vin1 = *reinterpret_cast<const float2*>(p.vec + vo + H);
+                vin2 = *reinterpret_cast<const float2*>(p.vec + vo + 2 * H);
+            }
             *reinterpret_cast<float2*>(p.vec_out + vo + H) = make_float2(vin1.x + sb0, vin1.y + sb1);
-            const float2 vin2 = *reinterpret_cast<const float2*>(p.vec + vo + 2 * H);
             *reinterpret_cast<float2*>(p.vec_out + vo + 2 * H) = make_float2(vin2.x + sc0, vin2.y + sc1);
         }
     }
@@ -387,17 +396,18 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
     ADF_HIP_CHECK(hipGetLastError());
     static bool attr_set = false;
     if (!attr_set) {
-        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128, false)));
-        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128, true)));
+#define SET_LDS(F16_, VZ_)                                                                                    \
+    ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<F16_, VZ_>),           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128, F16_)))
+        SET_LDS(false, false); SET_LDS(false, true); SET_LDS(true, false); SET_LDS(true, true);
+#undef SET_LDS
         attr_set = true;
     }
     return ADF_OK;
 }
 
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
-                         float* x_out, float* vec_out, hipStream_t s) {
+                         float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
     if ((unsigned long long)(N + 1) * 3ull * H * sizeof(float) >= (1ull << 32)) {
         adf_set_error("message kernel uses 32-bit byte offsets into the node tables: N=%d is too large, split the batch", N);
@@ -428,10 +438,11 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     if (workers < 1) workers = 1;
     if (workers > p.G) workers = p.G;
     dim3 grid((unsigned)(workers * p.nslices));
-    if (f16)
-        hipLaunchKernelGGL(adf_message_kernel<true>, grid, dim3(MSG_THREADS), msg_lds_bytes(R, true), s, p);
-    else
-        hipLaunchKernelGGL(adf_message_kernel<false>, grid, dim3(MSG_THREADS), msg_lds_bytes(R, false), s, p);
+#define LAUNCH_MSG(F16_, VZ_)                                                                              \
+    hipLaunchKernelGGL((adf_message_kernel<F16_, VZ_>), grid, dim3(MSG_THREADS), msg_lds_bytes(R, F16_), s, p)
+    if (f16) { if (vec_is_zero) LAUNCH_MSG(true, true); else LAUNCH_MSG(true, false); }
+    else { if (vec_is_zero) LAUNCH_MSG(false, true); else LAUNCH_MSG(false, false); }
+#undef LAUNCH_MSG
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

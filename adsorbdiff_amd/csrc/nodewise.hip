@@ -12,9 +12,10 @@ __device__ __forceinline__ float ssilu_d(float x) {
     return s * 1.6666666666666667f;
 }
 
-// x[n,:] = emb[Z[n]-1,:]   (gemnet_oc/layers/embedding_block.py:42) ; vec = 0
+// x[n,:] = emb[Z[n]-1,:]   (gemnet_oc/layers/embedding_block.py:42).  vec = 0 (painn_denoising.py:426) is
+// not materialised: the first message layer runs in its vec-is-zero mode.
 __global__ void adf_embed_kernel(const float* __restrict__ emb, const int32_t* __restrict__ Z, float* __restrict__ x,
-                                 float* __restrict__ vec, int N, int H) {
+                                 int N, int H) {
     const int h4 = H / 4;
     const long long total = (long long)N * h4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -22,9 +23,6 @@ __global__ void adf_embed_kernel(const float* __restrict__ emb, const int32_t* _
         const int n = (int)(i / h4), c = (int)(i - (long long)n * h4);
         const float4 v = reinterpret_cast<const float4*>(emb + (size_t)(Z[n] - 1) * H)[c];
         reinterpret_cast<float4*>(x + (size_t)n * H)[c] = v;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4* vp = reinterpret_cast<float4*>(vec + (size_t)n * 3 * H);
-        vp[c] = z; vp[h4 + c] = z; vp[2 * h4 + c] = z;
     }
 }
 
@@ -197,9 +195,9 @@ static inline unsigned ew_grid(long long total) {
     return (unsigned)b;
 }
 
-int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, float* vec, hipStream_t s) {
+int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s) {
     const int H = h->hp.hidden_channels;
-    hipLaunchKernelGGL(adf_embed_kernel, dim3(ew_grid((long long)N * H / 4)), dim3(256), 0, s, h->emb, Z, x, vec, N, H);
+    hipLaunchKernelGGL(adf_embed_kernel, dim3(ew_grid((long long)N * H / 4)), dim3(256), 0, s, h->emb, Z, x, N, H);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

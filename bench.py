@@ -37,7 +37,8 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 METRIC = "sampled adsorbate sites/sec (50 denoise steps, ~200-atom slabs)"
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix), dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: Peak BF16/FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
 
 
@@ -164,12 +165,18 @@ def main():
         assert bool(torch.isfinite(sites).all())
         H, R = 512, 128
         E = counters.num_edges
+        N_atoms = counters.num_atoms
         msg_ms, msg_launches = prof["message"]
-        alg_flops_per_launch = 2.0 * R * 3 * H * E
-        exec_flops_per_launch = prof["message_ksteps"] * 32 * 192 * 2.0 / max(msg_launches, 1)
+        f16 = os.environ.get("ADF_MSG", os.environ.get("ADF_GEMM", "f16")) != "f32"
+        products = 3 if f16 else 1  # f16x3 split issues three MFMA products per contraction step
+        peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+        dense_flops_per_launch = 2.0 * R * 3 * H * E
+        issued_flops_per_launch = prof["message_ksteps"] * 32 * 192 * 2.0 * products / max(msg_launches, 1)
         avg_s = msg_ms * 1e-3 / max(msg_launches, 1)
-        achieved = alg_flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
-        executed = exec_flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
+        issued = issued_flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
+        dense_equiv = dense_flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
+        gathered_bytes = E * 6 * H * 4.0  # xh[src] (3H) + vec[src] (3H) per edge, served by L2
+        hbm_alg_bytes = counters.message_bytes_per_layer - E * 3 * H * 4.0 + N_atoms * 4 * H * 4.0  # fused: no rbfh
         traffic = None
         pmc = ROOT / "profiles" / "message_kernel_pmc.json"
         if pmc.exists():
@@ -189,7 +196,7 @@ def main():
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if not f16 else "f32 (f16x3-split MFMA, fp32 accumulate; ADF_GEMM=f32 selects exact f32)",
             "data": "synthetic",
             "config": {
                 "workload": "PaiNN denoiser (H=512, 6 layers, R=128, K=50), %d-step ODE sampling on %d synthetic "
@@ -205,23 +212,26 @@ def main():
             "system_steps_per_s": total_systems * args.steps * args.num_steps / elapsed,
             "gpu_ms_per_pass": gpu_ms,
             "roofline": {
-                "kernel": "adf_message_kernel (fused rbf-projection MFMA + gather + segmented sum)",
+                "kernel": "adf_message_kernel (fused rbf-projection MFMA + gather + segmented sum), %s mode"
+                          % ("f16x3-split" if f16 else "exact-f32"),
                 "bound": "mfma",
-                "achieved": executed,
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "achieved": issued,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": executed / PEAK_F32_MFMA_TFLOPS,
+                "frac": issued / peak,
                 "traffic": traffic,
                 "avg_launch_ms": avg_s * 1e3,
                 "launches": msg_launches,
-                "flops_per_launch": exec_flops_per_launch,
-                "dense_equivalent_flops_per_launch": alg_flops_per_launch,
-                "dense_equivalent_tflops": achieved,
-                "note": "achieved = f32 MFMA flops the kernel issues (sum over its 32-edge row blocks of "
-                        "k-window x 32 x 192 x 2, padded rows included) / launch time from HIP events. The "
-                        "kernel contracts only the k-window |k-127d/rc|<=7 of rbf_proj per block (dropped terms "
-                        "< 2.3e-11 relative); dense_equivalent = SURVEY 8d's 2*R*3H*E. rbfh is never "
-                        "materialised, so the HBM roofline of SURVEY 8d (65.7 MB/system-layer) does not bind.",
+                "flops_per_launch": issued_flops_per_launch,
+                "dense_equivalent_tflops": dense_equiv,
+                "l2_gather_tbps": gathered_bytes / avg_s / 1e12 if avg_s > 0 else 0.0,
+                "hbm_algorithmic_gbps": hbm_alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0,
+                "hbm_algorithmic_frac": (hbm_alg_bytes / avg_s / 1e9) / PEAK_HBM_GBS if avg_s > 0 else 0.0,
+                "note": "achieved = matrix-core flops the kernel issues (k-window x 32 x 192 x 2 per 32-edge row "
+                        "block, padded rows and the 3 split products included) / launch time from HIP events on the "
+                        "launch stream. rbfh is never materialised, so neither SURVEY 8d roofline binds: the kernel "
+                        "is bounded by the L2-served gathers of xh[src]/vec[src] (12 KB per edge; l2_gather_tbps) - "
+                        "see DESIGN.md 4.",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -142,6 +142,31 @@ def test_painn_small_layers_and_output():
         assert rel_err(vec.cpu(), fx[f"layer{li}_vec"]) < REL_TOL
 
 
+def test_forward_is_run_to_run_deterministic():
+    """No atomics on floats anywhere on the path (edges are pre-sorted, sums run in registers): two runs of the
+    same forward must agree bit for bit.  (Guards against the packed-f32 miscompute seen with SLP
+    vectorisation next to the f16 MFMA loop, see adsorbdiff_amd/build.py.)"""
+    fx = load_npz("painn_small.npz")
+    m = small_model(fx)
+    b = batch_from_fixture(fx, device=DEV)
+    f1, f2 = m(b)
+    for _ in range(5):
+        g1, g2 = m(b)
+        assert torch.equal(f1, g1) and torch.equal(f2, g2)
+
+
+def test_exact_f32_mode_matches_default(monkeypatch):
+    """ADF_GEMM=f32 selects the exact-f32 MFMA kernels everywhere; the default f16x3-split path must agree
+    with it far inside the 1e-4 budget."""
+    fx = load_npz("painn_small.npz")
+    b = batch_from_fixture(fx, device=DEV)
+    f1, f2 = small_model(fx)(b)
+    monkeypatch.setenv("ADF_GEMM", "f32")
+    e1, e2 = small_model(fx)(b)
+    assert rel_err(f1, e1) < 2e-5 and rel_err(f2, e2) < 2e-5
+    assert rel_err(e1.cpu(), fx["f1"]) < 1e-5 and rel_err(e2.cpu(), fx["f2"]) < 1e-5
+
+
 def test_painn_full_h512_vs_reference_fixture():
     fx = load_npz("painn_full.npz")
     torch.manual_seed(int(fx["seed"]))
