@@ -148,13 +148,13 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
 
 static void free_workspaces(adf_painn* h) {
     void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
-                    h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys};
+                    h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->nbr_cnt = h->nbr_src = h->nbr_shift = h->deg = h->nptr = h->cursor = h->img_cnt = h->e_src = nullptr;
     h->scan_tmp = nullptr; h->scan_tmp_bytes = 0;
     h->e_geom = nullptr;
-    h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = nullptr;
+    h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = h->rec = nullptr;
     h->capN = h->capB = h->capE = 0;
 }
 
@@ -274,21 +274,16 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
         h->scan_tmp = tmp;
     }
     ALLOC(x, capN * H);
-    ALLOC(vecA, (capN + 1) * 3 * H);
-    ALLOC(vecB, (capN + 1) * 3 * H);
+    ALLOC(vecA, capN * 3 * H);
+    ALLOC(vecB, capN * 3 * H);
+    ALLOC(rec, (capN + 1) * 5 * H);  // + one all-zero record row: gather target of padded edge rows
     ALLOC(y, capN * H);
-    ALLOC(xh, (capN + 1) * 3 * H);   // + one all-zero row: gather target of padded edge rows
+    ALLOC(xh, capN * 3 * H);
     ALLOC(vv, capN * 6 * H);
     ALLOC(cat, capN * 2 * H);
     ALLOC(dot, capN * H);
     ALLOC(sys, capB * 16);
 #undef ALLOC
-    if (st == ADF_OK) {
-        hipError_t e1 = hipMemset(h->vecA, 0, sizeof(float) * (size_t)(capN + 1) * 3 * H);
-        hipError_t e2 = hipMemset(h->vecB, 0, sizeof(float) * (size_t)(capN + 1) * 3 * H);
-        hipError_t e3 = hipMemset(h->xh, 0, sizeof(float) * (size_t)(capN + 1) * 3 * H);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) st = ADF_EHIP;
-    }
     if (st != ADF_OK) { free_workspaces(h); return st; }
     h->capN = capN; h->capB = capB; h->capE = capE;
     return ADF_OK;
@@ -374,13 +369,11 @@ extern "C" int32_t adf_graph_export(adf_painn_t h, int32_t* nbr_count, int32_t* 
     return ADF_OK;
 }
 
-// Row N of xh / vecA / vecB is the all-zero gather target of padded edge rows (message.hip); rows
-// beyond the current N may hold data of an earlier, larger batch, so it is re-zeroed per forward.
+// Record row N is the all-zero gather target of padded edge rows (message.hip); rows beyond the
+// current N may hold data of an earlier, larger batch, so it is re-zeroed per forward.
 static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
-    const size_t row = (size_t)3 * h->hp.hidden_channels;
-    ADF_HIP_CHECK(hipMemsetAsync(h->xh + (size_t)N * row, 0, sizeof(float) * row, s));
-    ADF_HIP_CHECK(hipMemsetAsync(h->vecA + (size_t)N * row, 0, sizeof(float) * row, s));
-    ADF_HIP_CHECK(hipMemsetAsync(h->vecB + (size_t)N * row, 0, sizeof(float) * row, s));
+    const size_t row = (size_t)5 * h->hp.hidden_channels;
+    ADF_HIP_CHECK(hipMemsetAsync(h->rec + (size_t)N * row, 0, sizeof(float) * row, s));
     return ADF_OK;
 }
 
@@ -393,6 +386,7 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
     ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
     ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, N, H, H, 1, s));
     ADF_TRY(adf_linear(h, h->cat, H, w.xp2_w, &w.xp2_16, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+    ADF_TRY(adf_pack_records(h, N, h->xh, vec, vec_is_zero, s));
     adf_prof_end(h, s);
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
     const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s);
@@ -419,13 +413,9 @@ extern "C" int32_t adf_painn_message_layer(adf_painn_t h, int32_t layer, int32_t
         adf_set_error("message_layer: bad handle/layer, or N differs from the built graph");
         return ADF_EINVAL;
     }
-    // the kernel gathers row N of `vec` for padded edge rows: run on the internal (N+1)-row buffers
     hipStream_t s = (hipStream_t)stream;
-    const size_t bytes = sizeof(float) * (size_t)N * 3 * h->hp.hidden_channels;
     ADF_TRY(zero_pad_rows(h, N, s));
-    ADF_HIP_CHECK(hipMemcpyAsync(h->vecA, vec, bytes, hipMemcpyDeviceToDevice, s));
-    ADF_TRY(message_layer(h, layer, N, x, h->vecA, x_out, h->vecB, false, s));
-    ADF_HIP_CHECK(hipMemcpyAsync(vec_out, h->vecB, bytes, hipMemcpyDeviceToDevice, s));
+    ADF_TRY(message_layer(h, layer, N, x, vec, x_out, vec_out, false, s));
     return ADF_OK;
 }
 

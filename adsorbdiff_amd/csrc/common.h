@@ -87,6 +87,7 @@ struct adf_painn {
     float4* e_geom;      // [capE] (ux,uy,uz,d): unit vector target->source, distance
     int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}
     float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
+    float* rec;          // [(N+1)][H/64][320] gather records of the message kernel (message.hip)
     float *hx, *hv, *hcat, *hy, *hv2;                  // head buffers
     float* sys;          // [B*16] per-system scratch of the stepper
     // last graph
@@ -122,6 +123,7 @@ size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s);
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
+int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s);
 int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s);
 int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s);
 int32_t adf_nodewise_update_prep(const float* vv, const float* x, float* cat, float* dot, int N, int H, hipStream_t s);

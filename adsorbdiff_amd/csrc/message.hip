@@ -47,7 +47,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define MSG_LDK 136  // halves per column row of the f16 weight image (128 + 8 pad: conflict-free b128 reads)
 
 struct MsgParams {
-    const float* xh;
+    const float* rec;   // gather records [(N+1)][nslices][320] (adf_pack_records_kernel); row N is all zeros
     const float* vec;
     const float* x;
     float* x_out;
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const float inv_sqrt_h = out_scale / sqrtf((float)H);
     const float umax_scale = (float)(p.R - 1);
     const float coeff2 = p.coeff * 1.44269504088896341f;  // exp(c z) = exp2(c log2e z)
-    const unsigned int row_bytes = 3u * H * sizeof(float);
-    const char* xh_b = reinterpret_cast<const char*>(p.xh) + (size_t)(c0 + 2 * q) * sizeof(float);
-    const char* vec_b = reinterpret_cast<const char*>(p.vec) + (size_t)(c0 + 2 * q) * sizeof(float);
-    const unsigned int hb = (unsigned int)H * sizeof(float);
+    // one record row = nslices x 1280 B; this lane's pieces: chunk0 (16 B), chunk1 (16 B), chunk2 (8 B)
+    const unsigned int row_bytes = (unsigned int)p.nslices * 1280u;
+    const char* rec16 = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 16;
+    const char* rec8 = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + 1024 + (size_t)q * 8;
 
     unsigned int ksteps = 0;  // wave-uniform; one global atomic per wave at the very end (profiling)
     // work item t of this workgroup -> target atom (group = worker + (t/32)*nworkers, node = t%32):
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             __builtin_amdgcn_wave_barrier();  // previous block's meta reads are done
             if (hi == 0) {
                 float* m = meta_w + q * 8;
-                // byte offset of the source row; padded rows gather the all-zero row N of xh
-                m[0] = __uint_as_float((unsigned int)(valid ? src : p.N) * row_bytes);
+                // byte offset of the source's record row; padded rows gather the all-zero row N
+                m[0] = __uint_as_float((unsigned int)(valid ? src : p.N) * row_bytes);  // row N: zero record
                 m[1] = geo.x; m[2] = geo.y; m[3] = geo.z;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -199,27 +199,23 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 #define GATHER(r)                                                                               \
     const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
     const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
-    const float2 xa##r = *reinterpret_cast<const float2*>(xh_b + o##r);                         \
-    const float2 xb##r = *reinterpret_cast<const float2*>(xh_b + o##r + hb);                    \
-    const float2 xc##r = *reinterpret_cast<const float2*>(xh_b + o##r + 2 * hb);                \
-    float2 va##r = make_float2(0.f, 0.f), vb##r = va##r, vc##r = va##r;                         \
+    const float4 g0##r = *reinterpret_cast<const float4*>(rec16 + o##r);   /* xa0 xa1 xc0 xc1 */  \
+    float4 g1##r = make_float4(0.f, 0.f, 0.f, 0.f);                        /* P00 P01 P10 P11 */  \
+    float2 g2##r = make_float2(0.f, 0.f);                                  /* P20 P21 */          \
     if (!VZ) {                                                                                  \
-        va##r = *reinterpret_cast<const float2*>(vec_b + o##r);                                 \
-        vb##r = *reinterpret_cast<const float2*>(vec_b + o##r + hb);                            \
-        vc##r = *reinterpret_cast<const float2*>(vec_b + o##r + 2 * hb);                        \
+        g1##r = *reinterpret_cast<const float4*>(rec16 + o##r + 512);                           \
+        g2##r = *reinterpret_cast<const float2*>(rec8 + o##r);                                  \
     }
 #define CONSUME(r)                                                                              \
     {                                                                                           \
         const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
-        const float t2 = xb##r.x * acc[2][r];                                                   \
-        const float t3 = xc##r.x * acc[4][r];                                                   \
-        sx0 += xa##r.x * acc[0][r];                                                             \
-        if (!VZ) { sa0 += va##r.x * t2; sb0 += vb##r.x * t2; sc0 += vc##r.x * t2; }             \
+        const float t3 = g0##r.z * acc[4][r];                                                   \
+        sx0 += g0##r.x * acc[0][r];                                                             \
+        if (!VZ) { sa0 += g1##r.x * acc[2][r]; sb0 += g1##r.z * acc[2][r]; sc0 += g2##r.x * acc[2][r]; } \
         ra0 += t3 * ux; rb0 += t3 * uy; rc0 += t3 * uz;                                         \
-        const float u2 = xb##r.y * acc[3][r];                                                   \
-        const float u3 = xc##r.y * acc[5][r];                                                   \
-        sx1 += xa##r.y * acc[1][r];                                                             \
-        if (!VZ) { sa1 += va##r.y * u2; sb1 += vb##r.y * u2; sc1 += vc##r.y * u2; }             \
+        const float u3 = g0##r.w * acc[5][r];                                                   \
+        sx1 += g0##r.y * acc[1][r];                                                             \
+        if (!VZ) { sa1 += g1##r.y * acc[3][r]; sb1 += g1##r.w * acc[3][r]; sc1 += g2##r.y * acc[3][r]; } \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
 #ifndef MSG_NO_PREFETCH
@@ -307,29 +303,26 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
         sa0 += __shfl_xor(sa0, 32); sa1 += __shfl_xor(sa1, 32);
         sb0 += __shfl_xor(sb0, 32); sb1 += __shfl_xor(sb1, 32);
         sc0 += __shfl_xor(sc0, 32); sc1 += __shfl_xor(sc1, 32);
-        // residuals fused (painn_denoising.py:443-445); half-wave 0 writes x and vec_x, half-wave 1 vec_y, vec_z
-        const size_t xo = (size_t)n * H + c0 + 2 * q;
-        const size_t vo = (size_t)n * 3 * H + c0 + 2 * q;
+        // residuals fused (painn_denoising.py:443-445); lane q owns channels c0+q and c0+32+q;
+        // half-wave 0 writes x and vec_x, half-wave 1 vec_y and vec_z
+        const size_t xo = (size_t)n * H + c0 + q;
+        const size_t vo = (size_t)n * 3 * H + c0 + q;
         if (hi == 0) {
-            const float2 xin = *reinterpret_cast<const float2*>(p.x + xo);
-            *reinterpret_cast<float2*>(p.x_out + xo) = make_float2((xin.x + sx0) * inv_sqrt2, (xin.y + sx1) * inv_sqrt2);
-            float2 vin = make_float2(0.f, 0.f);
-            if (!VZ) vin = *reinterpret_cast<const float2*>(p.vec + vo);
-            *reinterpret_cast<float2*>(p.vec_out + vo) = make_float2(vin.x + sa0, vin.y + sa1);
+            p.x_out[xo] = (p.x[xo] + sx0) * inv_sqrt2;
+            p.x_out[xo + 32] = (p.x[xo + 32] + sx1) * inv_sqrt2;
+            p.vec_out[vo] = (VZ ? 0.f : p.vec[vo]) + sa0;
+            p.vec_out[vo + 32] = (VZ ? 0.f : p.vec[vo + 32]) + sa1;
         } else {
-            float2 vin1 = make_float2(0.f, 0.f), vin2 = vin1;
-            if (!VZ) {
-                vin1 = *reinterpret_cast<const float2*>(p.vec + vo + H);
-                vin2 = *reinterpret_cast<const float2*>(p.vec + vo + 2 * H);
-            }
-            *reinterpret_cast<float2*>(p.vec_out + vo + H) = make_float2(vin1.x + sb0, vin1.y + sb1);
-            *reinterpret_cast<float2*>(p.vec_out + vo + 2 * H) = make_float2(vin2.x + sc0, vin2.y + sc1);
+            p.vec_out[vo + H] = (VZ ? 0.f : p.vec[vo + H]) + sb0;
+            p.vec_out[vo + H + 32] = (VZ ? 0.f : p.vec[vo + H + 32]) + sb1;
+            p.vec_out[vo + 2 * H] = (VZ ? 0.f : p.vec[vo + 2 * H]) + sc0;
+            p.vec_out[vo + 2 * H + 32] = (VZ ? 0.f : p.vec[vo + 2 * H + 32]) + sc1;
         }
     }
     if (p.kcount && lane == 0) atomicAdd(p.kcount, (unsigned long long)ksteps);
 }
 
-// rbf_proj -> [slice][k][part*64 + j*32 + q]  with channel = slice*64 + 2q + j
+// rbf_proj -> [slice][k][part*64 + j*32 + q]  with channel = slice*64 + 32j + q
 __global__ void adf_pack_rbf_kernel(const float* __restrict__ w, const float* __restrict__ b, float* wpack,
                                     float* bpack, int H, int R) {
     const int nslices = H / ADF_SLICE_CH;
@@ -339,7 +332,7 @@ __global__ void adf_pack_rbf_kernel(const float* __restrict__ w, const float* __
         const int k = (i / MSG_COLS) % R;
         const int slice = i / (MSG_COLS * R);
         const int part = col / 64, j = (col >> 5) & 1, qq = col & 31;
-        const int ch = slice * ADF_SLICE_CH + 2 * qq + j;
+        const int ch = slice * ADF_SLICE_CH + 32 * j + qq;
         wpack[i] = w[(size_t)(part * H + ch) * R + k];
         if (k == 0) bpack[slice * MSG_COLS + col] = b[part * H + ch];
     }
@@ -362,7 +355,7 @@ __global__ void adf_pack_rbf16_kernel(const float* __restrict__ w, const float* 
         const int col = (i / R) % MSG_COLS;
         const int slice = i / (R * MSG_COLS);
         const int part = col / 64, j = (col >> 5) & 1, qq = col & 31;
-        const int ch = slice * ADF_SLICE_CH + 2 * qq + j;
+        const int ch = slice * ADF_SLICE_CH + 32 * j + qq;
         const float v = w[(size_t)(part * H + ch) * R + k] * scale;
         const _Float16 h = (_Float16)v;
         const size_t base = (size_t)slice * 2 * MSG_COLS * R;
@@ -373,6 +366,48 @@ __global__ void adf_pack_rbf16_kernel(const float* __restrict__ w, const float* 
 }
 
 __global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsigned int* out_bits);
+
+// Gather records of the message kernel.  Per source atom n and 64-channel slice s, 1280 B:
+//   chunk0 [32 lanes][xa(c), xa(c+32), xc(c), xc(c+32)]     xa/xb/xc = the three H-wide parts of xh
+//   chunk1 [32 lanes][P0(c), P0(c+32), P1(c), P1(c+32)]     P_i = vec_i * xb  (per channel)
+//   chunk2 [32 lanes][P2(c), P2(c+32)]                      c = 64 s + lane
+// vec*xb is the only place vec[src] and xb[src] enter the message (painn_denoising.py:549-552), so the
+// per-edge gather shrinks from 12 to 10 floats per channel pair and every piece a half-wave reads is one
+// contiguous, 16-B aligned run of the source row.
+__global__ void adf_pack_records_kernel(const float* __restrict__ xh, const float* __restrict__ vec,
+                                        float* __restrict__ rec, int N, int H, int vec_is_zero) {
+    const int nsl = H / ADF_SLICE_CH;
+    const long long total = (long long)N * nsl * 32;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (long long)gridDim.x * blockDim.x) {
+        const int qq = (int)(t & 31);
+        const int sl = (int)((t >> 5) % nsl);
+        const long long n = t / (32LL * nsl);
+        const int c = sl * ADF_SLICE_CH + qq;
+        const float* xr = xh + (size_t)n * 3 * H;
+        const float xa0 = xr[c], xa1 = xr[c + 32];
+        const float xb0 = xr[H + c], xb1 = xr[H + c + 32];
+        const float xc0 = xr[2 * H + c], xc1 = xr[2 * H + c + 32];
+        float* out = rec + ((size_t)n * nsl + sl) * 320;
+        reinterpret_cast<float4*>(out)[qq] = make_float4(xa0, xa1, xc0, xc1);
+        if (!vec_is_zero) {
+            const float* vr = vec + (size_t)n * 3 * H;
+            reinterpret_cast<float4*>(out + 128)[qq] =
+                make_float4(vr[c] * xb0, vr[c + 32] * xb1, vr[H + c] * xb0, vr[H + c + 32] * xb1);
+            reinterpret_cast<float2*>(out + 256)[qq] = make_float2(vr[2 * H + c] * xb0, vr[2 * H + c + 32] * xb1);
+        }
+    }
+}
+
+int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s) {
+    const int H = h->hp.hidden_channels;
+    long long blocks = ((long long)N * (H / ADF_SLICE_CH) * 32 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(adf_pack_records_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xh, vec, h->rec, N, H,
+                       vec_is_zero ? 1 : 0);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
 
 static size_t msg_lds_bytes(int R, bool f16) {
     const size_t w = f16 ? (size_t)2 * MSG_COLS * MSG_LDK * 2 : sizeof(float) * (size_t)R * MSG_COLS;
@@ -409,12 +444,12 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
-    if ((unsigned long long)(N + 1) * 3ull * H * sizeof(float) >= (1ull << 32)) {
+    if ((unsigned long long)(N + 1) * 5ull * H * sizeof(float) >= (1ull << 32)) {
         adf_set_error("message kernel uses 32-bit byte offsets into the node tables: N=%d is too large, split the batch", N);
         return ADF_EOOM;  // surfaces as RuntimeError -> ml_diffuse splits the batch
     }
     MsgParams p;
-    p.xh = xh; p.vec = vec; p.x = x; p.x_out = x_out; p.vec_out = vec_out;
+    p.rec = h->rec; p.vec = vec; p.x = x; p.x_out = x_out; p.vec_out = vec_out;
     p.nptr = h->nptr; p.e_src = h->e_src; p.e_geom = h->e_geom;
     p.nslices = H / ADF_SLICE_CH;
     const bool f16 = !h->msg_f32;
