@@ -133,6 +133,7 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         h->w16_bytes = elems * 2 * sizeof(uint16_t) + 4096;
         if (st == ADF_OK) st = dev_alloc(&h->w16_arena, h->w16_bytes);
         if (st == ADF_OK) st = dev_alloc(&h->w16_scales, 256);
+        if (st == ADF_OK) st = dev_alloc(&h->w16_bias_perm, (size_t)L * 2 * 3 * H);
         if (st == ADF_OK) st = dev_alloc(&h->w16_scratch, 1);
         const char* e = getenv("ADF_GEMM");
         h->gemm_f32 = e && strcmp(e, "f32") == 0;
@@ -170,6 +171,7 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->kcount) (void)hipFree(h->kcount);
     if (h->w16_arena) (void)hipFree(h->w16_arena);
     if (h->w16_scales) (void)hipFree(h->w16_scales);
+    if (h->w16_bias_perm) (void)hipFree(h->w16_bias_perm);
     if (h->w16_scratch) (void)hipFree(h->w16_scratch);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
     delete h->prof_cat;
@@ -211,19 +213,25 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
         const long long H = h->hp.hidden_channels, HH = H * H;
         unsigned char* cur = h->w16_arena;
         int nscale = 0;
-        auto split = [&](const float* w, long long n, adf_w16* out) -> int32_t {
+        float* bperm = h->w16_bias_perm;
+        auto split = [&](const float* w, long long n, adf_w16* out, const float* fused_bias = nullptr) -> int32_t {
             out->hi = cur; cur += n * 2;
             out->lo = cur; cur += n * 2;
             out->inv_scale = h->w16_scales + nscale++;
+            out->bias_perm = nullptr;
+            if (fused_bias) {  // 3H-wide layer feeding a fused epilogue: rows permuted (gemm16.hip)
+                out->bias_perm = bperm; bperm += 3 * H;
+                return adf_split_weight(w, n, out, h->w16_scratch, s, (int)H, (int)H, fused_bias);
+            }
             return adf_split_weight(w, n, out, h->w16_scratch, s);
         };
         for (int l = 0; l < L; ++l) {
             adf_layer_weights& lw = h->layer[l];
             ADF_TRY(split(lw.xp0_w, HH, &lw.xp0_16));
-            ADF_TRY(split(lw.xp2_w, 3 * HH, &lw.xp2_16));
+            ADF_TRY(split(lw.xp2_w, 3 * HH, &lw.xp2_16, lw.xp2_b));
             ADF_TRY(split(lw.vp_w, 2 * HH, &lw.vp_16));
             ADF_TRY(split(lw.xv0_w, 2 * HH, &lw.xv0_16));
-            ADF_TRY(split(lw.xv2_w, 3 * HH, &lw.xv2_16));
+            ADF_TRY(split(lw.xv2_w, 3 * HH, &lw.xv2_16, lw.xv2_b));
         }
         for (int hd = 0; hd < h->hp.num_heads; ++hd) {
             adf_block_weights& b0 = h->head[hd][0];
@@ -385,8 +393,14 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
     adf_prof_begin(h, ADF_PROF_NODE, s);
     ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
     ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, N, H, H, 1, s));
-    ADF_TRY(adf_linear(h, h->cat, H, w.xp2_w, &w.xp2_16, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
-    ADF_TRY(adf_pack_records(h, N, h->xh, vec, vec_is_zero, s));
+    if (h->gemm_f32) {
+        ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+        ADF_TRY(adf_pack_records(h, N, h->xh, vec, vec_is_zero, s));
+    } else {  // x_proj.2 with the gather records written from the accumulators (xh never materialised)
+        adf_epi ep = {};
+        ep.vec_in = vec; ep.rec = h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
+        ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, N, H, H, 1, &ep, s));
+    }
     adf_prof_end(h, s);
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
     const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s);
@@ -401,8 +415,15 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
     ADF_TRY(adf_linear(h, vec, H, w.vp_w, &w.vp_16, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
     ADF_TRY(adf_nodewise_update_prep(h->vv, x, h->cat, h->dot, N, H, s));
     ADF_TRY(adf_linear(h, h->cat, 2 * H, w.xv0_w, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
-    ADF_TRY(adf_linear(h, h->y, H, w.xv2_w, &w.xv2_16, w.xv2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
-    const int32_t st = adf_nodewise_update_apply(h->xh, h->dot, h->vv, x, vec, h->scale[l], N, H, s);
+    int32_t st;
+    if (h->gemm_f32) {
+        ADF_TRY(adf_launch_gemm(h->y, H, w.xv2_w, H, w.xv2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+        st = adf_nodewise_update_apply(h->xh, h->dot, h->vv, x, vec, h->scale[l], N, H, s);
+    } else {  // xvec_proj.2 with gating + residuals + ScaleFactor applied on the accumulators
+        adf_epi ep = {};
+        ep.x = x; ep.vec = vec; ep.dot = h->dot; ep.vv = h->vv; ep.scale = h->scale[l]; ep.H = H;
+        st = adf_launch_gemm16_fused(h->y, H, &w.xv2_16, N, H, H, 2, &ep, s);
+    }
     adf_prof_end(h, s);
     return st;
 }

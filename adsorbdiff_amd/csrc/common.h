@@ -37,6 +37,19 @@ struct adf_w16 {
     void* hi;
     void* lo;
     float* inv_scale;  // device scalar: 1 / (power-of-two scale applied before the split)
+    float* bias_perm;  // row-permuted bias of the fused 3H-wide layers (else null)
+};
+// operands of the fused GEMM epilogues (gemm16.hip)
+struct adf_epi {
+    const float* vec_in;  // EPI 1: vec [N,3,H] (P_i = vec_i * xb)
+    float* rec;           // EPI 1: gather records
+    float* x;             // EPI 2
+    float* vec;           // EPI 2
+    const float* dot;     // EPI 2
+    const float* vv;      // EPI 2: vec_proj output [N,3,2H], v1 = first H columns
+    float scale;          // EPI 2: ScaleFactor
+    int H;
+    int vec_is_zero;      // EPI 1
 };
 struct adf_layer_weights {
     const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
@@ -68,6 +81,7 @@ struct adf_painn {
     unsigned char* w16_arena;
     size_t w16_bytes;
     float* w16_scales;
+    float* w16_bias_perm;  // [L][2][3H] row-permuted biases of x_proj.2 / xvec_proj.2
     unsigned int* w16_scratch;
     bool gemm_f32;
     bool msg_f32;
@@ -111,7 +125,10 @@ int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const 
                         int M, int N, int K, int act_ssilu, hipStream_t s);
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s);
-int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s);
+int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
+                         int perm_H = 0, int K = 0, const float* bias = nullptr);
+int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
+                                const adf_epi* ep, hipStream_t s);
 // C = act(A . W^T + b): f16x3 split MFMA by default, exact-f32 MFMA when h->gemm_f32 (ADF_GEMM=f32)
 static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, const float* W, const adf_w16* W16,
                                  const float* bias, float* C, int ldc, int M, int N, int K, int act, hipStream_t s) {

@@ -26,8 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-#define HM 256
-#define HN 256
 #define HK 32
 #define HLD 40  // halves per LDS row (32 + 8 pad)
 
@@ -36,28 +34,32 @@ __device__ __forceinline__ float ssilu16(float x) {
     return s * 1.6666666666666667f;
 }
 
-// 256 x 256 x 32 tile, 4 waves as 2(M) x 2(N), each wave 128 x 128 = 4 x 4 MFMA 32x32 accumulators
-// (256 acc VGPRs, one wave per SIMD): every A/B fragment read from LDS feeds 4 MFMAs x 3 products,
-// which keeps the LDS pipe at ~40 % of the matrix pipe's time.
-template <int ACT, int MI>
-__global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(const float* __restrict__ A, int lda,
-                                                                 const _Float16* __restrict__ Whi,
-                                                                 const _Float16* __restrict__ Wlo,
-                                                                 const float* __restrict__ inv_scale,
-                                                                 const float* __restrict__ bias, float* __restrict__ C,
-                                                                 int ldc, int M, int N, int K, int tiles_n) {
-    constexpr int TM = 64 * MI;   // rows per workgroup: 2 waves x MI blocks of 32
+// Workgroup = 4 waves as 2(M) x 2(N); wave tile = (32*MI) rows x (32*NJ) columns of MFMA 32x32 blocks.
+//   MI=2,NJ=4 (default): 128 x 256 tile, 2 workgroups per CU.
+//   NJ=3 with EPI != 0: the three column blocks of a wave are the three H-wide parts of a 3H-wide
+//   linear layer for the SAME 32 channels (weights row-permuted at set_weights:
+//   column g*96 + part*32 + q  <->  original row part*H + 32g + q), so the consumer's elementwise
+//   work runs on the accumulators and the 3H-wide intermediate never goes to HBM:
+//     EPI 1  x_proj.2 -> gather records of the message kernel (xa, xc, P_i = vec_i * xb; message.hip)
+//     EPI 2  xvec_proj.2 -> PaiNNUpdate gating + residuals + ScaleFactor (painn_denoising.py:614-623,449-451)
+template <int ACT, int MI, int NJ, int EPI>
+__global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
+    const float* __restrict__ A, int lda, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
+    const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
+    int K, int tiles_n, adf_epi ep) {
+    constexpr int TM = 64 * MI;   // rows per workgroup
+    constexpr int TN = 64 * NJ;   // columns per workgroup
     constexpr int NA = TM / 32;   // float4 A loads per thread
-    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * HN) * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * HLD];
     _Float16* Ahi = lds;
     _Float16* Alo = Ahi + TM * HLD;
     _Float16* Bhi = Alo + TM * HLD;
-    _Float16* Blo = Bhi + HN * HLD;
+    _Float16* Blo = Bhi + TN * HLD;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = (wave >> 1) * (32 * MI);
-    const int wn = (wave & 1) * 128;
+    const int wn = (wave & 1) * (32 * NJ);
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
@@ -65,10 +67,10 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const int tile_m = (qd / tiles_n) * 8 + xcd;
     const int tile_n = qd % tiles_n;
     const int m0 = tile_m * TM;
-    const int n0 = tile_n * HN;
+    const int n0 = tile_n * TN;
     if (m0 >= M) return;
 
-    // A staging: 8 float4 per thread (8 lanes per 128-B row segment, 32 rows per pass)
+    // A staging: NA float4 per thread (8 lanes per 128-B row segment, 32 rows per pass)
     const float* a_ptr[NA];
     int a_off[NA];
 #pragma unroll
@@ -78,11 +80,11 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         a_ptr[i] = A + (size_t)min(m0 + row, M - 1) * lda + kq * 4;
         a_off[i] = row * HLD + kq * 4;
     }
-    // W staging: 4 pieces of 16 B (8 halves) of hi and of lo per thread (4 lanes per 64-B row)
-    size_t w_src[4];
-    int w_off[4];
+    // W staging: NJ pieces of 16 B (8 halves) of hi and of lo per thread (4 lanes per 64-B row)
+    size_t w_src[NJ];
+    int w_off[NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NJ; ++i) {
         const int f = tid + 256 * i;
         const int row = f >> 2, part = f & 3;
         w_src[i] = (size_t)min(n0 + row, N - 1) * K + part * 8;
@@ -90,20 +92,20 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     }
 
     float4 ra[NA];
-    half8 rwh[4], rwl[4];
+    half8 rwh[NJ], rwl[NJ];
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NJ; ++i) {
         rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i]);
         rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i]);
     }
 
-    f32x16 acc[MI][4];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             *reinterpret_cast<half4*>(Alo + a_off[i]) = l;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NJ; ++i) {
             *reinterpret_cast<half8*>(Bhi + w_off[i]) = rwh[i];
             *reinterpret_cast<half8*>(Blo + w_off[i]) = rwl[i];
         }
@@ -131,16 +133,16 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)(kt + 1) * HK);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NJ; ++i) {
                 rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + (size_t)(kt + 1) * HK);
                 rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + (size_t)(kt + 1) * HK);
             }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            half8 bh[4], bl[4];
+            half8 bh[NJ], bl[NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 bh[j] = *reinterpret_cast<const half8*>(Bhi + fb + j * 32 * HLD + ks * 16);
                 bl[j] = *reinterpret_cast<const half8*>(Blo + fb + j * 32 * HLD + ks * 16);
             }
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 const half8 ah = *reinterpret_cast<const half8*>(Ahi + fa + i * 32 * HLD + ks * 16);
                 const half8 al = *reinterpret_cast<const half8*>(Alo + fa + i * 32 * HLD + ks * 16);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     // small terms first, then the leading product
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
@@ -160,22 +162,97 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     }
 
     const float isc = *inv_scale;
+    if constexpr (EPI == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn + 32 * j + (lane & 31);
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
+        for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < M) {
+                        float v = acc[i][j][r] * isc + bv;
+                        if (ACT) v = ssilu16(v);
+                        C[(size_t)row * ldc + col] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        // Columns of this wave: parts 0,1,2 of the 32 channels of group g.  The accumulators (lane =
+        // channel, 16 rows) are transposed through the wave's share of the now idle staging LDS so
+        // that every lane then owns 4 consecutive channels of one row: 16-B global accesses, 8 rows x
+        // 128 B per wave instruction instead of 2 rows x 128 B.
+        static_assert(NJ == 3 && MI == 2, "fused epilogues are written for the 64 x 96 wave tile");
+        const int q = lane & 31;
+        const int g = (n0 + wn) / 96;
+        const int H = ep.H;
+        const float b0 = bias[n0 + wn + q], b1 = bias[n0 + wn + 32 + q], b2 = bias[n0 + wn + 64 + q];
+        __syncthreads();  // all waves are done reading the operand tiles
+        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 rows][100] floats (96 + 4 pad)
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M) {
-                    float v = acc[i][j][r] * isc + bv;
-                    if (ACT) v = ssilu16(v);
-                    C[(size_t)row * ldc + col] = v;
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                T[lr * 100 + q] = acc[i][0][r] * isc + b0;
+                T[lr * 100 + 32 + q] = acc[i][1][r] * isc + b1;
+                T[lr * 100 + 64 + q] = acc[i][2][r] * isc + b2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int item = lane + 64 * it;
+                const int lr = item >> 3, c4 = item & 7;
+                const int n = m0 + wm + 32 * i + lr;
+                if (n < M) {
+                    const float4 p0 = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
+                    const float4 p1 = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
+                    const float4 p2 = *reinterpret_cast<const float4*>(T + lr * 100 + 64 + 4 * c4);
+                    const int c = 32 * g + 4 * c4;
+                    if constexpr (EPI == 1) {
+                        // half-record of (atom n, group g): [32 x (xa, xc)] then [32 x (P0, P1, P2)]
+                        float* rec = ep.rec + ((size_t)n * (H / 32) + g) * 160;
+                        float4* ra_ = reinterpret_cast<float4*>(rec + 8 * c4);
+                        ra_[0] = make_float4(p0.x, p2.x, p0.y, p2.y);
+                        ra_[1] = make_float4(p0.z, p2.z, p0.w, p2.w);
+                        if (!ep.vec_is_zero) {
+                            const float* vr = ep.vec_in + (size_t)n * 3 * H + c;
+                            const float4 v0 = *reinterpret_cast<const float4*>(vr);
+                            const float4 v1 = *reinterpret_cast<const float4*>(vr + H);
+                            const float4 v2 = *reinterpret_cast<const float4*>(vr + 2 * H);
+                            float4* pr = reinterpret_cast<float4*>(rec + 64 + 12 * c4);
+                            pr[0] = make_float4(v0.x * p1.x, v1.x * p1.x, v2.x * p1.x, v0.y * p1.y);
+                            pr[1] = make_float4(v1.y * p1.y, v2.y * p1.y, v0.z * p1.z, v1.z * p1.z);
+                            pr[2] = make_float4(v2.z * p1.z, v0.w * p1.w, v1.w * p1.w, v2.w * p1.w);
+                        }
+                    } else {
+                        const size_t xo = (size_t)n * H + c;
+                        const float4 d = *reinterpret_cast<const float4*>(ep.dot + xo);
+                        float4 xv = *reinterpret_cast<const float4*>(ep.x + xo);
+                        const float k2 = 0.70710678118654752f, sc = ep.scale;
+                        xv.x = (xv.x + (p0.x + p1.x * d.x) * k2) * sc;
+                        xv.y = (xv.y + (p0.y + p1.y * d.y) * k2) * sc;
+                        xv.z = (xv.z + (p0.z + p1.z * d.z) * k2) * sc;
+                        xv.w = (xv.w + (p0.w + p1.w * d.w) * k2) * sc;
+                        *reinterpret_cast<float4*>(ep.x + xo) = xv;
+                        float* vr = ep.vec + (size_t)n * 3 * H + c;
+                        const float* v1p = ep.vv + (size_t)n * 6 * H + c;
+#pragma unroll
+                        for (int ax = 0; ax < 3; ++ax) {
+                            const float4 v1 = *reinterpret_cast<const float4*>(v1p + ax * 2 * H);
+                            float4 t = *reinterpret_cast<const float4*>(vr + ax * H);
+                            t.x += p2.x * v1.x; t.y += p2.y * v1.y; t.z += p2.z * v1.z; t.w += p2.w * v1.w;
+                            *reinterpret_cast<float4*>(vr + ax * H) = t;
+                        }
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();  // T is rewritten for the next 32-row block
         }
     }
 }
@@ -190,8 +267,10 @@ __global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsi
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order like uints
 }
 
+// perm_H > 0: the matrix is [3*perm_H, K]; output row g*96 + part*32 + q takes input row part*perm_H + 32g + q
 __global__ void adf_split_kernel(const float* __restrict__ w, long long n, const unsigned int* absmax_bits,
-                                 _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* inv_scale) {
+                                 _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* inv_scale, int perm_H,
+                                 int K, const float* __restrict__ bias, float* __restrict__ bias_perm) {
     const float amax = __uint_as_float(*absmax_bits);
     // scale = 2^(9 - floor(log2(amax)))  ->  |w*scale| in [2^9, 2^10)
     int e = 0;
@@ -199,18 +278,28 @@ __global__ void adf_split_kernel(const float* __restrict__ w, long long n, const
     const float scale = ldexpf(1.0f, 10 - e);
     if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = 1.0f / scale;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float v = w[i] * scale;
+        long long src = i;
+        if (perm_H > 0) {
+            const long long prow = i / K;
+            const int k = (int)(i - prow * K);
+            const int g = (int)(prow / 96), part = (int)((prow % 96) / 32), qq = (int)(prow % 32);
+            const long long orow = (long long)part * perm_H + 32 * g + qq;
+            src = orow * K + k;
+            if (k == 0 && bias_perm) bias_perm[prow] = bias ? bias[orow] : 0.f;
+        }
+        const float v = w[src] * scale;
         const _Float16 h = (_Float16)v;
         hi[i] = h;
         lo[i] = (_Float16)(v - (float)h);
     }
 }
 
-int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s) {
+int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
+                         int perm_H, int K, const float* bias) {
     ADF_HIP_CHECK(hipMemsetAsync(scratch_bits, 0, sizeof(unsigned int), s));
     hipLaunchKernelGGL(adf_absmax_kernel, dim3(64), dim3(256), 0, s, w, n, scratch_bits);
     hipLaunchKernelGGL(adf_split_kernel, dim3(64), dim3(256), 0, s, w, n, scratch_bits, (_Float16*)out->hi,
-                       (_Float16*)out->lo, out->inv_scale);
+                       (_Float16*)out->lo, out->inv_scale, perm_H, K, bias, out->bias_perm);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
@@ -224,17 +313,42 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     }
     static int mi = 0;
     if (!mi) { const char* e = getenv("ADF_GEMM16_MI"); mi = e ? atoi(e) : 2; if (mi != 4) mi = 2; }
-    const int TM = 64 * mi;
-    const int tiles_n = (N + HN - 1) / HN;
+    const int TM = 64 * mi, TN = 256;
+    const int tiles_n = (N + TN - 1) / TN;
     const int tiles_m = (M + TM - 1) / TM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
-#define LAUNCH16(ACT_, MI_)                                                                                       \
-    hipLaunchKernelGGL((adf_gemm_f16x3_kernel<ACT_, MI_>), grid, dim3(256), 0, s, A, lda, (const _Float16*)W->hi, \
-                       (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, tiles_n)
+    adf_epi ep = {};
+#define LAUNCH16(ACT_, MI_)                                                                                  \
+    hipLaunchKernelGGL((adf_gemm_f16x3_kernel<ACT_, MI_, 4, 0>), grid, dim3(256), 0, s, A, lda,              \
+                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, \
+                       tiles_n, ep)
     if (mi == 4) { if (act_ssilu) LAUNCH16(1, 4); else LAUNCH16(0, 4); }
     else { if (act_ssilu) LAUNCH16(1, 2); else LAUNCH16(0, 2); }
 #undef LAUNCH16
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// 3H-wide layer with row-permuted weights and a fused consumer epilogue (EPI 1 or 2, see kernel comment)
+int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
+                                const adf_epi* ep, hipStream_t s) {
+    if (M <= 0) return ADF_OK;
+    if (K % HK != 0 || (lda & 3) || H % 64 != 0 || !W->bias_perm) {
+        adf_set_error("gemm16_fused: bad shape");
+        return ADF_EINVAL;
+    }
+    const int N = 3 * H, TM = 128, TN = 192;
+    const int tiles_n = N / TN;  // H % 64 == 0
+    const int tiles_m = (M + TM - 1) / TM;
+    const int tiles_m8 = (tiles_m + 7) / 8 * 8;
+    dim3 grid((unsigned)(tiles_m8 * tiles_n));
+    if (epi == 1)
+        hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 2, 3, 1>), grid, dim3(256), 0, s, A, lda, (const _Float16*)W->hi,
+                           (const _Float16*)W->lo, W->inv_scale, W->bias_perm, (float*)nullptr, 0, M, N, K, tiles_n, *ep);
+    else
+        hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 2, 3, 2>), grid, dim3(256), 0, s, A, lda, (const _Float16*)W->hi,
+                           (const _Float16*)W->lo, W->inv_scale, W->bias_perm, (float*)nullptr, 0, M, N, K, tiles_n, *ep);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

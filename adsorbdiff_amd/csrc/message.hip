@@ -47,7 +47,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define MSG_LDK 136  // halves per column row of the f16 weight image (128 + 8 pad: conflict-free b128 reads)
 
 struct MsgParams {
-    const float* rec;   // gather records [(N+1)][nslices][320] (adf_pack_records_kernel); row N is all zeros
+    const float* rec;   // gather records [(N+1)][H/32][160] (gemm16.hip EPI 1 / adf_pack_records_kernel); row N zero
     const float* vec;
     const float* x;
     float* x_out;
@@ -132,10 +132,11 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const float inv_sqrt_h = out_scale / sqrtf((float)H);
     const float umax_scale = (float)(p.R - 1);
     const float coeff2 = p.coeff * 1.44269504088896341f;  // exp(c z) = exp2(c log2e z)
-    // one record row = nslices x 1280 B; this lane's pieces: chunk0 (16 B), chunk1 (16 B), chunk2 (8 B)
+    // one record row = H/32 half-records of 640 B: [32 x (xa, xc)] + [32 x (P0, P1, P2)] for 32 channels.
+    // Lane q owns channels c0+q (half-record 2*slice) and c0+32+q (half-record 2*slice+1).
     const unsigned int row_bytes = (unsigned int)p.nslices * 1280u;
-    const char* rec16 = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 16;
-    const char* rec8 = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + 1024 + (size_t)q * 8;
+    const char* recA = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 8;
+    const char* recP = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + 256 + (size_t)q * 12;
 
     unsigned int ksteps = 0;  // wave-uniform; one global atomic per wave at the very end (profiling)
     // work item t of this workgroup -> target atom (group = worker + (t/32)*nworkers, node = t%32):
@@ -199,23 +200,23 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 #define GATHER(r)                                                                               \
     const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
     const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
-    const float4 g0##r = *reinterpret_cast<const float4*>(rec16 + o##r);   /* xa0 xa1 xc0 xc1 */  \
-    float4 g1##r = make_float4(0.f, 0.f, 0.f, 0.f);                        /* P00 P01 P10 P11 */  \
-    float2 g2##r = make_float2(0.f, 0.f);                                  /* P20 P21 */          \
+    const float2 ga0##r = *reinterpret_cast<const float2*>(recA + o##r);          /* xa xc (j=0) */ \
+    const float2 ga1##r = *reinterpret_cast<const float2*>(recA + o##r + 640);    /* xa xc (j=1) */ \
+    float3 gp0##r = make_float3(0.f, 0.f, 0.f), gp1##r = gp0##r;                  /* P0 P1 P2 */    \
     if (!VZ) {                                                                                  \
-        g1##r = *reinterpret_cast<const float4*>(rec16 + o##r + 512);                           \
-        g2##r = *reinterpret_cast<const float2*>(rec8 + o##r);                                  \
+        gp0##r = *reinterpret_cast<const float3*>(recP + o##r);                                 \
+        gp1##r = *reinterpret_cast<const float3*>(recP + o##r + 640);                           \
     }
 #define CONSUME(r)                                                                              \
     {                                                                                           \
         const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
-        const float t3 = g0##r.z * acc[4][r];                                                   \
-        sx0 += g0##r.x * acc[0][r];                                                             \
-        if (!VZ) { sa0 += g1##r.x * acc[2][r]; sb0 += g1##r.z * acc[2][r]; sc0 += g2##r.x * acc[2][r]; } \
+        const float t3 = ga0##r.y * acc[4][r];                                                  \
+        sx0 += ga0##r.x * acc[0][r];                                                            \
+        if (!VZ) { sa0 += gp0##r.x * acc[2][r]; sb0 += gp0##r.y * acc[2][r]; sc0 += gp0##r.z * acc[2][r]; } \
         ra0 += t3 * ux; rb0 += t3 * uy; rc0 += t3 * uz;                                         \
-        const float u3 = g0##r.w * acc[5][r];                                                   \
-        sx1 += g0##r.y * acc[1][r];                                                             \
-        if (!VZ) { sa1 += g1##r.y * acc[3][r]; sb1 += g1##r.w * acc[3][r]; sc1 += g2##r.y * acc[3][r]; } \
+        const float u3 = ga1##r.y * acc[5][r];                                                  \
+        sx1 += ga1##r.x * acc[1][r];                                                            \
+        if (!VZ) { sa1 += gp1##r.x * acc[3][r]; sb1 += gp1##r.y * acc[3][r]; sc1 += gp1##r.z * acc[3][r]; } \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
 #ifndef MSG_NO_PREFETCH
@@ -367,41 +368,37 @@ __global__ void adf_pack_rbf16_kernel(const float* __restrict__ w, const float* 
 
 __global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsigned int* out_bits);
 
-// Gather records of the message kernel.  Per source atom n and 64-channel slice s, 1280 B:
-//   chunk0 [32 lanes][xa(c), xa(c+32), xc(c), xc(c+32)]     xa/xb/xc = the three H-wide parts of xh
-//   chunk1 [32 lanes][P0(c), P0(c+32), P1(c), P1(c+32)]     P_i = vec_i * xb  (per channel)
-//   chunk2 [32 lanes][P2(c), P2(c+32)]                      c = 64 s + lane
-// vec*xb is the only place vec[src] and xb[src] enter the message (painn_denoising.py:549-552), so the
-// per-edge gather shrinks from 12 to 10 floats per channel pair and every piece a half-wave reads is one
-// contiguous, 16-B aligned run of the source row.
+// Gather records of the message kernel (stand-alone producer, used by the exact-f32 mode; the f16x3
+// mode writes the same layout from the x_proj.2 GEMM epilogue, gemm16.hip EPI 1).  Per source atom n and
+// group g of 32 channels, 640 B:  [32 lanes][xa(c), xc(c)]  then  [32 lanes][P0(c), P1(c), P2(c)],
+// c = 32 g + lane, xa/xb/xc = the three H-wide parts of xh, P_i = vec_i * xb.  vec*xb is the only place
+// vec[src] and xb[src] enter the message (painn_denoising.py:549-552), so the per-edge gather shrinks
+// from 6 to 5 floats per channel and every piece a half-wave reads is one contiguous run of the source row.
 __global__ void adf_pack_records_kernel(const float* __restrict__ xh, const float* __restrict__ vec,
                                         float* __restrict__ rec, int N, int H, int vec_is_zero) {
-    const int nsl = H / ADF_SLICE_CH;
-    const long long total = (long long)N * nsl * 32;
+    const int ng = H / 32;
+    const long long total = (long long)N * ng * 32;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (long long)gridDim.x * blockDim.x) {
         const int qq = (int)(t & 31);
-        const int sl = (int)((t >> 5) % nsl);
-        const long long n = t / (32LL * nsl);
-        const int c = sl * ADF_SLICE_CH + qq;
+        const int g = (int)((t >> 5) % ng);
+        const long long n = t / (32LL * ng);
+        const int c = 32 * g + qq;
         const float* xr = xh + (size_t)n * 3 * H;
-        const float xa0 = xr[c], xa1 = xr[c + 32];
-        const float xb0 = xr[H + c], xb1 = xr[H + c + 32];
-        const float xc0 = xr[2 * H + c], xc1 = xr[2 * H + c + 32];
-        float* out = rec + ((size_t)n * nsl + sl) * 320;
-        reinterpret_cast<float4*>(out)[qq] = make_float4(xa0, xa1, xc0, xc1);
+        const float xa = xr[c], xb = xr[H + c], xc = xr[2 * H + c];
+        float* out = rec + ((size_t)n * ng + g) * 160;
+        reinterpret_cast<float2*>(out)[qq] = make_float2(xa, xc);
         if (!vec_is_zero) {
             const float* vr = vec + (size_t)n * 3 * H;
-            reinterpret_cast<float4*>(out + 128)[qq] =
-                make_float4(vr[c] * xb0, vr[c + 32] * xb1, vr[H + c] * xb0, vr[H + c + 32] * xb1);
-            reinterpret_cast<float2*>(out + 256)[qq] = make_float2(vr[2 * H + c] * xb0, vr[2 * H + c + 32] * xb1);
+            float* pr = out + 64 + 3 * qq;
+            pr[0] = vr[c] * xb; pr[1] = vr[H + c] * xb; pr[2] = vr[2 * H + c] * xb;
         }
     }
 }
 
 int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s) {
     const int H = h->hp.hidden_channels;
-    long long blocks = ((long long)N * (H / ADF_SLICE_CH) * 32 + 255) / 256;
+    long long blocks = ((long long)N * H + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(adf_pack_records_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xh, vec, h->rec, N, H,
                        vec_is_zero ? 1 : 0);
