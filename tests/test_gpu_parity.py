@@ -332,3 +332,76 @@ def test_full_size_properties():
     h1, _ = m(sh.to(DEV))
     u1 = O.ads_mean(h1.cpu(), b.tags, b.batch, 16)
     assert rel_err(u1, s1) < 5e-4  # positions are re-rounded, neighbours at the K-th place may tie-flip
+
+
+def _oracle_vs_hip(b, hp, seed=0, so3=True, pbc=None, scale=None):
+    from oracle import painn_oracle as O
+
+    torch.manual_seed(seed)
+    m = PaiNN(None, 50, 1, so3_denoising=so3, scale_file=scale, **hp).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    kw = dict(hidden_channels=hp["hidden_channels"], num_layers=hp["num_layers"], cutoff=hp["cutoff"],
+              max_neighbors=hp["max_neighbors"], scale_factors=m.scale_factors(), so3_denoising=so3)
+    if pbc is not None:
+        graph = O.radius_graph_pbc(b.pos, b.cell, b.natoms, hp["cutoff"], hp["max_neighbors"], pbc=pbc)
+        ei, d, v, _ = O.pbc_distances(b.pos, graph[0], b.cell, graph[1], graph[2])
+        ei, sh, nb, d, u = O.symmetrize_edges(ei, graph[1], graph[2], d, v / d[:, None])
+        kw["graph"] = (ei, nb, d, u)
+    ref = O.painn_forward(sd, b.pos, b.atomic_numbers, b.cell, b.natoms, **kw)
+    bd = b.clone().to(DEV)
+    if pbc is not None:
+        bd.pbc = torch.tensor([list(pbc)] * len(b.natoms))
+    out = m.to(DEV)(bd)
+    return out, ref
+
+
+def test_ragged_batch_vs_oracle():
+    """Systems of different sizes in one batch (16+3, 100+4 and 36+4 atoms; N = 163 is not a multiple of the
+    32-atom work groups)."""
+    from adsorbdiff_amd.data import Batch
+
+    parts = (make_batch(1, n_slab=16, n_ads=3, seed=61).to_data_list() + make_batch(1, n_slab=100, n_ads=4, seed=62).to_data_list()
+             + make_batch(1, n_slab=36, n_ads=4, seed=63).to_data_list())
+    b = Batch.from_data_list(parts)
+    hp = dict(hidden_channels=128, num_layers=3, cutoff=6.0, max_neighbors=20)
+    (f1, f2), (r1, r2) = _oracle_vs_hip(b, hp, scale={"upd_out_scalar_scale_1": 0.8})
+    assert rel_err(f1.cpu(), r1) < REL_TOL and rel_err(f2.cpu(), r2) < REL_TOL
+
+
+def test_single_head_and_k_not_binding():
+    """so3_denoising=False returns one tensor; a tiny cutoff keeps every centre below K neighbours."""
+    b = make_batch(2, n_slab=36, n_ads=2, seed=64)
+    hp = dict(hidden_channels=128, num_layers=2, cutoff=3.0, max_neighbors=50)
+    out, ref = _oracle_vs_hip(b, hp, so3=False)
+    assert torch.is_tensor(out) and out.shape == (76, 3)
+    assert rel_err(out.cpu(), ref) < REL_TOL
+
+
+def test_non_periodic_z_vs_oracle():
+    """data.pbc = [T, T, F]: no images along the third lattice vector (reference utils/utils.py:566-576,650-655)."""
+    b = make_batch(2, n_slab=36, n_ads=4, seed=65)
+    b.cell[:, 2, 2] = 9.0  # short c axis: periodic images along z would be inside the cutoff
+    b.pos[:, 2] -= 6.0
+    hp = dict(hidden_channels=128, num_layers=2, cutoff=6.0, max_neighbors=20)
+    (f1, f2), (r1, r2) = _oracle_vs_hip(b, hp, pbc=(True, True, False))
+    assert rel_err(f1.cpu(), r1) < REL_TOL and rel_err(f2.cpu(), r2) < REL_TOL
+    (g1, _), (s1, _) = _oracle_vs_hip(b, hp)  # fully periodic gives a different answer
+    assert rel_err(g1.cpu(), s1) < REL_TOL and rel_err(g1.cpu(), r1) > 1e-3
+
+
+def test_weight_update_is_picked_up():
+    """EMA-style in-place parameter changes re-bind / re-pack the device weights."""
+    fx = load_npz("painn_small.npz")
+    m = small_model(fx)
+    b = batch_from_fixture(fx, device=DEV)
+    f1, _ = m(b)
+    with torch.no_grad():
+        m.message_layers[0].rbf_proj.weight.mul_(1.5)
+        m.update_layers[1].xvec_proj[2].bias.add_(0.3)
+    g1, _ = m(b)
+    assert rel_err(g1, f1) > 1e-3
+    with torch.no_grad():
+        m.message_layers[0].rbf_proj.weight.div_(1.5)
+        m.update_layers[1].xvec_proj[2].bias.sub_(0.3)
+    h1, _ = m(b)
+    assert rel_err(h1, f1) < 1e-6
