@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--num-steps", type=int, default=50, help="reverse-diffusion steps per sample")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                                                      "testing the N>1 path with several ranks on one GPU)")
     ap.add_argument("--cpu-systems", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -94,13 +96,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"LOCAL_RANK={local_rank} but only {ndev} GPU(s) visible")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.painn_denoising import PaiNN
@@ -153,7 +161,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = eng.profile_read()
