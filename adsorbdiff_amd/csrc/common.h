@@ -102,7 +102,6 @@ struct adf_painn {
     int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}
     float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
     float* rec;          // [(N+1)][H/64][320] gather records of the message kernel (message.hip)
-    float *hx, *hv, *hcat, *hy, *hv2;                  // head buffers
     float* sys;          // [B*16] per-system scratch of the stepper
     // last graph
     int64_t lastN, lastB;

@@ -18,24 +18,22 @@
 //      some row's Gaussian is non-negligible: |k - (R-1) d/rc| <= 7 (dropped terms < exp(-24.5) =
 //      2.3e-11 of the leading term, far below f32 rounding).  Because a target's edges are sorted by
 //      distance, a 32-row block spans a narrow band and the 128-deep contraction shrinks to ~35;
-//   2. xh[src], vec[src] are gathered for the 16 accumulator rows of each lane as float2 (the
-//      slice's column -> channel map puts channels 2q,2q+1 on lane q, so a half-wave reads 256
-//      contiguous bytes of a source row, served by the XCD's L2: slice = blockIdx % 8 = XCD under
-//      round-robin dispatch, so one XCD only touches its own 64-channel columns of the node tables);
+//   2. the 16 accumulator rows of each lane gather their source's packed record (xa, xc and
+//      P_i = vec_i * xb for the lane's channels c0+q and c0+32+q; 40 B per lane and row, contiguous
+//      per half-wave), served by the XCD's L2: slice = blockIdx % 8 = XCD under round-robin
+//      dispatch, so one XCD only touches its own 64-channel columns of the record table;
 //   3. the messages are summed in registers (wavefront segmented sum: the 16 rows of a lane, then
 //      one cross-half shuffle), and x_out / vec_out rows are written once with the residual fused.
 // No LDS atomics (ds_add_f32 measured 4x slower than the whole rest of the kernel), no barriers
-// after the weight image is staged, no zero-initialised outputs.  HBM traffic per layer = node
-// tables once + 20 B per edge (vs 6 KB per edge if rbfh were materialised); the roofline that
-// binds is the matrix-core rate of step 1.
+// after the weight image is staged, no zero-initialised outputs.  HBM traffic per layer = record
+// table + residual rows once + 20 B per edge (vs 6 KB per edge if rbfh were materialised).  Measured
+// (PMC): VALU ~50 % busy, matrix pipe ~25 %, gathers ~10 TB/s out of L2 at a 93 % hit rate.
 //
 // Two arithmetic modes for step 1, same structure otherwise:
 //   F16 = true  (default): f16x3 split (see gemm16.hip) — A = a_hi + a_lo generated in registers,
 //                W·s = w_hi + w_lo in LDS as [col][k] halves, v_mfma_f32_32x32x16_f16 x 3 products,
 //                fp32 accumulate; the k-window is aligned to 8 and contracted 16 k at a time.
 //   F16 = false (ADF_GEMM=f32): exact f32 v_mfma_f32_32x32x2_f32, window contracted 2 k at a time.
-#include <stdlib.h>
-
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -77,9 +75,7 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-#ifndef MSG_WAVES_PER_SIMD
 #define MSG_WAVES_PER_SIMD 2
-#endif
 // VZ = true: vec is identically zero on entry (first layer, painn_denoising.py:426) — its gathers,
 // the vec*b sums and the residual read are skipped.
 template <bool F16, bool VZ>
@@ -219,10 +215,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
         if (!VZ) { sa1 += gp1##r.x * acc[3][r]; sb1 += gp1##r.y * acc[3][r]; sc1 += gp1##r.z * acc[3][r]; } \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
-#ifndef MSG_NO_PREFETCH
             // rows 0-3: issued before the MFMA loop, they land while the matrix pipe is busy
             GATHER(0) GATHER(1) GATHER(2) GATHER(3)
-#endif
 
             const float env256 = env * 256.0f;
             f32x16 acc[6];
@@ -255,18 +249,11 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                     for (int b = 0; b < 6; ++b) {
                         const half8 bh = *reinterpret_cast<const half8*>(wh + b * 32 * MSG_LDK);
                         const half8 bl = *reinterpret_cast<const half8*>(wl + b * 32 * MSG_LDK);
-#ifndef MSG_ONE_PRODUCT
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-#endif
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
                     }
                 }
-#ifdef MSG_EXTRA_NOPS
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#endif
             } else {
                 for (int k2 = klo; k2 < khi; k2 += 2) {
                     const int k = k2 + hi;
@@ -280,9 +267,6 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[b * 32], acc[b], 0, 0, 0);
                 }
             }
-#ifdef MSG_NO_PREFETCH
-            GATHER(0) GATHER(1) GATHER(2) GATHER(3)
-#endif
             // epilogue, software pipelined: next rows' gathers are in flight while rows are consumed
             GATHER(4) GATHER(5) GATHER(6) GATHER(7)
             CONSUME(0) CONSUME(1) CONSUME(2) CONSUME(3)

@@ -104,6 +104,7 @@ class PaiNNEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.adf_painn_create(C.byref(hp), C.byref(self.handle)))
         self._weights_keepalive: List[torch.Tensor] = []
+        self._last_graph_N = 0
         self.bind_weights()
 
     # ------------------------------------------------------------------ weights
@@ -205,6 +206,8 @@ class PaiNNEngine:
     def export_graph(self):
         """(nbr_count[N], nbr_src[N,K], nbr_shift[N,K,3], edge_src[E], edge_dst[E], dist[E], vec[E,3])."""
         N, K = self._last_graph_N, self.model.max_neighbors
+        if N <= 0:
+            raise RuntimeError("export_graph: call build_graph first")
         dev = self.device
         cnt = torch.empty(N, dtype=torch.int32, device=dev)
         src = torch.empty(N, K, dtype=torch.int32, device=dev)
