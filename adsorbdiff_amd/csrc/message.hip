@@ -135,29 +135,66 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const char* recP = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + 256 + (size_t)q * 12;
 
     unsigned int ksteps = 0;  // wave-uniform; one global atomic per wave at the very end (profiling)
-    // work item t of this workgroup -> target atom (group = worker + (t/32)*nworkers, node = t%32):
-    // consecutive items are consecutive atoms, so the 8 waves write neighbouring output rows
-    while (true) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(Ctr, 1);
-        t = __builtin_amdgcn_readfirstlane(t);
-        const int g = worker + (t >> 5) * nworkers;
-        if (g >= p.G) break;
-        const int n = g * ADF_GROUP_NODES + (t & 31);
-        if (n >= p.N) continue;
-        const int e0 = p.nptr[n];
-        const int e1 = p.nptr[n + 1];
-        // running sums over this target's edges: sx = sum a ; s* = sum vec*b ; r* = sum c*r_hat
-        // (the 1/sqrt3 and 1/sqrtH factors of painn_denoising.py:550-553 are applied once at the end)
-        float sx0 = 0.f, sx1 = 0.f, sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f, sc0 = 0.f, sc1 = 0.f;
-        float ra0 = 0.f, ra1 = 0.f, rb0 = 0.f, rb1 = 0.f, rc0 = 0.f, rc1 = 0.f;
 
-        for (int eb = e0; eb < e1; eb += 32) {
-            const int e = eb + q;
-            const bool valid = e < e1;
-            float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
-            int src = 0;
-            if (valid) { geo = p.e_geom[e]; src = p.e_src[e]; }
+    // Work items of this workgroup are target atoms (item t -> group worker + (t/32)*nworkers, atom
+    // t%32: consecutive items are consecutive atoms, so the 8 waves write neighbouring output rows);
+    // a wave walks its targets' 32-edge blocks as one flat, software-pipelined sequence: the NEXT
+    // block's edge records (and, one target ahead, the next target's CSR bounds and residual rows)
+    // are requested before the current block is processed, so a block exposes no dependent
+    // HBM/L2 round trip of its own.
+    auto fetch_target = [&](int& n_out) -> bool {
+        while (true) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(Ctr, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            const int g = worker + (t >> 5) * nworkers;
+            if (g >= p.G) return false;
+            const int n = g * ADF_GROUP_NODES + (t & 31);
+            if (n < p.N) { n_out = n; return true; }
+        }
+    };
+    auto load_block = [&](int eb, int e1, float4& geo, int& src, bool& valid) {
+        const int e = eb + q;
+        valid = e < e1;
+        geo = make_float4(0.f, 0.f, 0.f, 0.f);
+        src = 0;
+        if (valid) { geo = p.e_geom[e]; src = p.e_src[e]; }
+    };
+
+    int n = 0, eb = 0, e1 = 0;           // current block
+    bool have = fetch_target(n);
+    if (have) { eb = p.nptr[n]; e1 = p.nptr[n + 1]; }
+    int nN = 0, e0N = 0, e1N = 0;        // next target (bounds requested one target ahead)
+    bool haveN = have && fetch_target(nN);
+    if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
+    float4 geo; int src; bool valid;
+    if (have) load_block(eb, e1, geo, src, valid);
+    bool first = true;                   // current block is the first of its target
+    // running sums over the current target's edges: sx = sum a ; s* = sum P*b ; r* = sum c*r_hat
+    // (the 1/sqrt3 and 1/sqrtH factors of painn_denoising.py:550-553 are applied once at the end)
+    float sx0 = 0.f, sx1 = 0.f, sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f, sc0 = 0.f, sc1 = 0.f;
+    float ra0 = 0.f, ra1 = 0.f, rb0 = 0.f, rb1 = 0.f, rc0 = 0.f, rc1 = 0.f;
+    float res0 = 0.f, res1 = 0.f, res2 = 0.f, res3 = 0.f;  // residual inputs of this lane's output rows
+
+    while (have) {
+        {
+            // ---- request what the NEXT block needs
+            const bool last = eb + 32 >= e1;
+            float4 geoN = make_float4(0.f, 0.f, 0.f, 0.f); int srcN = 0; bool validN = false;
+            if (!last) load_block(eb + 32, e1, geoN, srcN, validN);
+            else if (haveN) load_block(e0N, e1N, geoN, srcN, validN);
+            if (first) {  // residual rows of this target (painn_denoising.py:443-445), used at its last block
+                const size_t xo = (size_t)n * H + c0 + q;
+                const size_t vo = (size_t)n * 3 * H + c0 + q;
+                if (hi == 0) {
+                    res0 = p.x[xo]; res1 = p.x[xo + 32];
+                    if (!VZ) { res2 = p.vec[vo]; res3 = p.vec[vo + 32]; }
+                } else if (!VZ) {
+                    res0 = p.vec[vo + H]; res1 = p.vec[vo + H + 32];
+                    res2 = p.vec[vo + 2 * H]; res3 = p.vec[vo + 2 * H + 32];
+                }
+            }
+
             const float xs = geo.w * p.inv_cutoff;
             // polynomial envelope (radial_basis.py:36-43)
             float xp = xs;
@@ -178,7 +215,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             const float umin = wave_min(valid ? u : 1e30f);
             const float umax = wave_max(valid ? u : -1e30f);
             int klo, khi;
-            if (F16) {
+            if (!(umax >= 0.f)) {  // target without incoming edges: one dummy step on all-zero A (env = 0)
+                klo = 0; khi = 16;
+            } else if (F16) {
                 klo = max(0, (int)floorf(umin) - 7) & ~7;
                 khi = min(p.R, (int)ceilf(umax) + 8);
                 khi = klo + ((khi - klo + 15) & ~15);       // whole 16-deep MFMA steps
@@ -227,7 +266,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                 for (int r = 0; r < 16; ++r) acc[b][r] = bv;
             }
             if (F16) {
-                for (int k0 = klo; k0 < khi; k0 += 16) {
+                int k0 = klo;
+                do {  // at least one step: lets the accumulators live in place across the loop
                     // A fragment: lane (row q, half hi) holds k = k0 + 8*hi + j, j = 0..7
                     const float4 mu0 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi);
                     const float4 mu1 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi + 4);
@@ -253,9 +293,11 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
                     }
-                }
+                    k0 += 16;
+                } while (k0 < khi);
             } else {
-                for (int k2 = klo; k2 < khi; k2 += 2) {
+                int k2 = klo;
+                do {
                     const int k = k2 + hi;
                     const float dm = xs - Mu[k];
                     // exp via v_exp_f32 (exp2): |arg| <= 24.5 inside the window, relative error <= ~2e-6
@@ -265,7 +307,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 #pragma unroll
                     for (int b = 0; b < 6; ++b)
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wrow[b * 32], acc[b], 0, 0, 0);
-                }
+                    k2 += 2;
+                } while (k2 < khi);
             }
             // epilogue, software pipelined: next rows' gathers are in flight while rows are consumed
             GATHER(4) GATHER(5) GATHER(6) GATHER(7)
@@ -278,30 +321,47 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 #undef GATHER
 #undef CONSUME
 #undef ROW_OF
-        }
-        sx0 *= out_scale; sx1 *= out_scale;
-        sa0 = (sa0 * inv_sqrt3 + ra0) * inv_sqrt_h; sa1 = (sa1 * inv_sqrt3 + ra1) * inv_sqrt_h;
-        sb0 = (sb0 * inv_sqrt3 + rb0) * inv_sqrt_h; sb1 = (sb1 * inv_sqrt3 + rb1) * inv_sqrt_h;
-        sc0 = (sc0 * inv_sqrt3 + rc0) * inv_sqrt_h; sc1 = (sc1 * inv_sqrt3 + rc1) * inv_sqrt_h;
-        // the two half-waves hold disjoint rows of the same channels
-        sx0 += __shfl_xor(sx0, 32); sx1 += __shfl_xor(sx1, 32);
-        sa0 += __shfl_xor(sa0, 32); sa1 += __shfl_xor(sa1, 32);
-        sb0 += __shfl_xor(sb0, 32); sb1 += __shfl_xor(sb1, 32);
-        sc0 += __shfl_xor(sc0, 32); sc1 += __shfl_xor(sc1, 32);
-        // residuals fused (painn_denoising.py:443-445); lane q owns channels c0+q and c0+32+q;
-        // half-wave 0 writes x and vec_x, half-wave 1 vec_y and vec_z
-        const size_t xo = (size_t)n * H + c0 + q;
-        const size_t vo = (size_t)n * 3 * H + c0 + q;
-        if (hi == 0) {
-            p.x_out[xo] = (p.x[xo] + sx0) * inv_sqrt2;
-            p.x_out[xo + 32] = (p.x[xo + 32] + sx1) * inv_sqrt2;
-            p.vec_out[vo] = (VZ ? 0.f : p.vec[vo]) + sa0;
-            p.vec_out[vo + 32] = (VZ ? 0.f : p.vec[vo + 32]) + sa1;
-        } else {
-            p.vec_out[vo + H] = (VZ ? 0.f : p.vec[vo + H]) + sb0;
-            p.vec_out[vo + H + 32] = (VZ ? 0.f : p.vec[vo + H + 32]) + sb1;
-            p.vec_out[vo + 2 * H] = (VZ ? 0.f : p.vec[vo + 2 * H]) + sc0;
-            p.vec_out[vo + 2 * H + 32] = (VZ ? 0.f : p.vec[vo + 2 * H + 32]) + sc1;
+            if (last) {
+                // ---- finish this target: scale, cross-half reduction, residuals, one write per row
+                sx0 *= out_scale; sx1 *= out_scale;
+                sa0 = (sa0 * inv_sqrt3 + ra0) * inv_sqrt_h; sa1 = (sa1 * inv_sqrt3 + ra1) * inv_sqrt_h;
+                sb0 = (sb0 * inv_sqrt3 + rb0) * inv_sqrt_h; sb1 = (sb1 * inv_sqrt3 + rb1) * inv_sqrt_h;
+                sc0 = (sc0 * inv_sqrt3 + rc0) * inv_sqrt_h; sc1 = (sc1 * inv_sqrt3 + rc1) * inv_sqrt_h;
+                // the two half-waves hold disjoint rows of the same channels
+                sx0 += __shfl_xor(sx0, 32); sx1 += __shfl_xor(sx1, 32);
+                sa0 += __shfl_xor(sa0, 32); sa1 += __shfl_xor(sa1, 32);
+                sb0 += __shfl_xor(sb0, 32); sb1 += __shfl_xor(sb1, 32);
+                sc0 += __shfl_xor(sc0, 32); sc1 += __shfl_xor(sc1, 32);
+                // lane q owns channels c0+q and c0+32+q; half-wave 0 writes x and vec_x, half-wave 1 vec_y, vec_z
+                const size_t xo = (size_t)n * H + c0 + q;
+                const size_t vo = (size_t)n * 3 * H + c0 + q;
+                if (hi == 0) {
+                    p.x_out[xo] = (res0 + sx0) * inv_sqrt2;
+                    p.x_out[xo + 32] = (res1 + sx1) * inv_sqrt2;
+                    p.vec_out[vo] = res2 + sa0;
+                    p.vec_out[vo + 32] = res3 + sa1;
+                } else {
+                    p.vec_out[vo + H] = res0 + sb0;
+                    p.vec_out[vo + H + 32] = res1 + sb1;
+                    p.vec_out[vo + 2 * H] = res2 + sc0;
+                    p.vec_out[vo + 2 * H + 32] = res3 + sc1;
+                }
+                sx0 = sx1 = sa0 = sa1 = sb0 = sb1 = sc0 = sc1 = 0.f;
+                ra0 = ra1 = rb0 = rb1 = rc0 = rc1 = 0.f;
+                res0 = res1 = res2 = res3 = 0.f;
+                // ---- advance to the next target and request the bounds of the one after it
+                have = haveN;
+                n = nN; eb = e0N; e1 = e1N;
+                first = true;
+                if (have) {
+                    haveN = fetch_target(nN);
+                    if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
+                }
+            } else {
+                eb += 32;
+                first = false;
+            }
+            geo = geoN; src = srcN; valid = validN;
         }
     }
     if (p.kcount && lane == 0) atomicAdd(p.kcount, (unsigned long long)ksteps);
