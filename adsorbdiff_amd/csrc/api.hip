@@ -506,18 +506,36 @@ extern "C" int32_t adf_sde_init_placement(adf_painn_t h, const adf_batch* b, flo
     return adf_stepper_init(h, b, pos, tags, noise, (hipStream_t)stream);
 }
 
+static int32_t sde_step_common(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                               const int32_t* fixed, const float* f1, const float* f2, const adf_step_coef* coef,
+                               const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr, const float* z_rot,
+                               int32_t early_stop_count, int32_t* state, float* dcom, float* drot, void* stream) {
+    ADF_TRY(check_batch(h, b));
+    if (!pos || !tags || !f1 || !f2 || (!coef && !coefs_dev) || !state) { adf_set_error("null argument"); return ADF_EINVAL; }
+    ADF_TRY(ensure_capacity(h, b->num_atoms, b->num_systems));
+    adf_prof_begin(h, ADF_PROF_STEPPER, (hipStream_t)stream);
+    const int32_t st = adf_stepper_step(h, b, pos, tags, fixed, f1, f2, coef, coefs_dev, num_steps, z_tr, z_rot,
+                                        early_stop_count, state, dcom, drot, (hipStream_t)stream);
+    adf_prof_end(h, (hipStream_t)stream);
+    return st;
+}
+
 extern "C" int32_t adf_sde_step(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
                                 const int32_t* fixed, const float* f1, const float* f2, const adf_step_coef* coef,
                                 const float* z_tr, const float* z_rot, int32_t early_stop_count, int32_t* state,
                                 float* dcom, float* drot, void* stream) {
-    ADF_TRY(check_batch(h, b));
-    if (!pos || !tags || !f1 || !f2 || !coef || !state) { adf_set_error("null argument"); return ADF_EINVAL; }
-    ADF_TRY(ensure_capacity(h, b->num_atoms, b->num_systems));
-    adf_prof_begin(h, ADF_PROF_STEPPER, (hipStream_t)stream);
-    const int32_t st = adf_stepper_step(h, b, pos, tags, fixed, f1, f2, coef, z_tr, z_rot, early_stop_count, state,
-                                        dcom, drot, (hipStream_t)stream);
-    adf_prof_end(h, (hipStream_t)stream);
-    return st;
+    return sde_step_common(h, b, pos, tags, fixed, f1, f2, coef, nullptr, 0, z_tr, z_rot, early_stop_count, state, dcom,
+                           drot, stream);
+}
+
+extern "C" int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                                          const int32_t* fixed, const float* f1, const float* f2,
+                                          const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr,
+                                          const float* z_rot, int32_t early_stop_count, int32_t* state, float* dcom,
+                                          float* drot, void* stream) {
+    if (num_steps <= 0) { adf_set_error("num_steps must be positive"); return ADF_EINVAL; }
+    return sde_step_common(h, b, pos, tags, fixed, f1, f2, nullptr, coefs_dev, num_steps, z_tr, z_rot, early_stop_count,
+                           state, dcom, drot, stream);
 }
 
 extern "C" int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream) {

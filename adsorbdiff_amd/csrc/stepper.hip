@@ -29,6 +29,8 @@ struct StepParams {
     float* drot_out;
     int B;
     adf_step_coef c;
+    const adf_step_coef* coefs_dev;  // optional schedule table on the device, indexed by state[4]
+    int num_steps;
     int early_stop_count;
 };
 
@@ -108,15 +110,18 @@ __global__ __launch_bounds__(64) void adf_step_reduce_kernel(StepParams p) {
     for (int i = 0; i < 10; ++i) s[i] = wsum(s[i]);
     if (lane != 0) return;
     const float cnt = fmaxf(s[9], 1.0f);
+    // schedule scalars: by value, or (graph replay: identical launch every step) from the device table
+    adf_step_coef c = p.c;
+    if (p.coefs_dev) c = p.coefs_dev[min(p.state[4], p.num_steps - 1)];
     float com[3], dcom[3], drot[3];
     for (int k = 0; k < 3; ++k) {
         com[k] = s[k] / cnt;
         const float str = s[3 + k] / cnt;
         const float srot = s[6 + k] / cnt;
-        float d = __fmul_rn(p.c.coef_tr, str);
-        float r = __fmul_rn(__fmul_rn(__fmul_rn(p.c.rot_pre, srot), p.c.rot_dt), p.c.rot_g2);
-        if (p.z_tr) d = __fadd_rn(d, __fmul_rn(p.c.noise_tr, p.z_tr[3 * b + k]));
-        if (p.z_rot) r = __fadd_rn(r, __fmul_rn(p.c.noise_rot, p.z_rot[3 * b + k]));
+        float d = __fmul_rn(c.coef_tr, str);
+        float r = __fmul_rn(__fmul_rn(__fmul_rn(c.rot_pre, srot), c.rot_dt), c.rot_g2);
+        if (p.z_tr) d = __fadd_rn(d, __fmul_rn(c.noise_tr, p.z_tr[3 * b + k]));
+        if (p.z_rot) r = __fadd_rn(r, __fmul_rn(c.noise_rot, p.z_rot[3 * b + k]));
         dcom[k] = d;
         drot[k] = r;
     }
@@ -142,7 +147,8 @@ __global__ __launch_bounds__(64) void adf_step_reduce_kernel(StepParams p) {
 // phase 2: early-stop bookkeeping (block 0 decides, every block re-derives the same decision from
 // state[] written by the *previous* launch's decision kernel) + rigid update of each adsorbate
 __global__ void adf_step_decide_kernel(int32_t* state, int early_stop_count) {
-    // state: [0]=cumulative converged count, [1]=frozen, [2]=all-converged flag of this step, [3]=steps applied
+    // state: [0]=cumulative converged count, [1]=frozen, [2]=all-converged flag of this step, [3]=steps applied,
+    //        [4]=steps issued (index into the device schedule table)
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (!state[1]) {
             if (state[2]) {
@@ -152,6 +158,7 @@ __global__ void adf_step_decide_kernel(int32_t* state, int early_stop_count) {
             if (!state[1]) state[3] += 1;
         }
         state[2] = 1;  // re-arm for the next step
+        state[4] += 1;
     }
 }
 
@@ -194,13 +201,15 @@ int32_t adf_stepper_init(adf_painn* h, const adf_batch* b, float* pos, const int
 }
 
 int32_t adf_stepper_step(adf_painn* h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
-                         const float* f1, const float* f2, const adf_step_coef* coef, const float* z_tr,
-                         const float* z_rot, int32_t early_stop_count, int32_t* state, float* dcom, float* drot,
-                         hipStream_t s) {
+                         const float* f1, const float* f2, const adf_step_coef* coef, const adf_step_coef* coefs_dev,
+                         int num_steps, const float* z_tr, const float* z_rot, int32_t early_stop_count,
+                         int32_t* state, float* dcom, float* drot, hipStream_t s) {
     StepParams p;
     p.cell = b->cell; p.atom_offset = b->atom_offset; p.tags = tags; p.fixed = fixed; p.pos = pos;
     p.f1 = f1; p.f2 = f2; p.z_tr = z_tr; p.z_rot = z_rot; p.sys = h->sys; p.state = state;
-    p.dcom_out = dcom; p.drot_out = drot; p.B = b->num_systems; p.c = *coef; p.early_stop_count = early_stop_count;
+    p.dcom_out = dcom; p.drot_out = drot; p.B = b->num_systems; p.early_stop_count = early_stop_count;
+    if (coef) p.c = *coef; else p.c = adf_step_coef{};
+    p.coefs_dev = coefs_dev; p.num_steps = num_steps;
     hipLaunchKernelGGL(adf_step_reduce_kernel, dim3(p.B), dim3(64), 0, s, p);
     hipLaunchKernelGGL(adf_step_decide_kernel, dim3(1), dim3(64), 0, s, state, early_stop_count);
     hipLaunchKernelGGL(adf_step_apply_kernel, dim3(p.B), dim3(64), 0, s, p);

@@ -257,6 +257,18 @@ class PaiNNEngine:
                 dcom.data_ptr() if dcom is not None else None, drot.data_ptr() if drot is not None else None,
                 self._stream()))
 
+    def sde_step_scheduled(self, prep: PreparedBatch, pos, f1, f2, coefs_dev: torch.Tensor, num_steps: int, state,
+                           z_tr=None, z_rot=None, early_stop_count: int = 10) -> None:
+        """Step whose schedule scalars come from a device table indexed by state[4] (graph-capturable)."""
+        desc = prep.desc(pos)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.adf_sde_step_scheduled(
+                self.handle, C.byref(desc), pos.data_ptr(), prep.tags.data_ptr(),
+                prep.fixed.data_ptr() if prep.fixed is not None else None, f1.data_ptr(), f2.data_ptr(),
+                coefs_dev.data_ptr(), num_steps, z_tr.data_ptr() if z_tr is not None else None,
+                z_rot.data_ptr() if z_rot is not None else None, early_stop_count, state.data_ptr(), None, None,
+                self._stream()))
+
     def counters(self) -> _lib.Counters:
         c = _lib.Counters()
         with torch.cuda.device(self.device):

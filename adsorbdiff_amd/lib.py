@@ -17,7 +17,7 @@ ADF_OK, ADF_EINVAL, ADF_EOOM, ADF_ENONEIGHBOR, ADF_EHIP, ADF_EOVERFLOW = 0, 1, 2
 EXPORTS = (
     "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_check_flags",
     "adf_graph_export", "adf_painn_forward", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
-    "adf_sde_init_placement", "adf_sde_step", "adf_get_counters", "adf_profile_enable", "adf_profile_read",
+    "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_get_counters", "adf_profile_enable", "adf_profile_read",
     "adf_last_error", "adf_version",
 )
 
@@ -91,6 +91,7 @@ def load():
         "adf_painn_update_layer": [vp, i32, i32, vp, vp, vp],
         "adf_sde_init_placement": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp],
         "adf_sde_step": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, vp, C.POINTER(StepCoef), vp, vp, i32, vp, vp, vp, vp],
+        "adf_sde_step_scheduled": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp],
         "adf_get_counters": [vp, C.POINTER(Counters), vp],
         "adf_profile_enable": [vp, i32],
         "adf_profile_read": [vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64), vp],

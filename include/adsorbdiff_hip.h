@@ -169,15 +169,24 @@ int32_t adf_sde_init_placement(adf_painn_t h, const adf_batch* b, float* pos, co
  * fixed atoms, per-system adsorbate means, ODE/SDE update, COM wrap, rigid
  * rotation+translation of the adsorbate, cumulative early-stop counter.
  * z_tr,z_rot: [B,3] standard normals (SDE only, else NULL).  state: device
- * int32[4] = {cumulative converged-step count, frozen flag, all-converged flag
- * of the step in flight, steps applied}; the caller initialises it to
- * {0,0,1,0}.  Once the count reaches `early_stop_count` (>0) that step and all
+ * int32[8] = {cumulative converged-step count, frozen flag, all-converged flag
+ * of the step in flight, steps applied, steps issued, -, -, -}; the caller
+ * initialises it to {0,0,1,0,0,0,0,0}.  Once the count reaches `early_stop_count` (>0) that step and all
  * later ones leave pos untouched, which is the reference's `break`
  * (denoising_torch.py:312-320).  dcom,drot: optional [B,3] outputs. */
 int32_t adf_sde_step(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
                      const int32_t* fixed, const float* f1, const float* f2, const adf_step_coef* coef,
                      const float* z_tr, const float* z_rot, int32_t early_stop_count, int32_t* state,
                      float* dcom, float* drot, void* stream);
+
+/* Same step with the whole schedule in a DEVICE table coefs_dev[num_steps], indexed by state[4]
+ * (steps issued).  Every step is then the identical launch sequence, so forward + step can be
+ * captured once into a hipGraph and replayed (small batches are launch-bound). */
+int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                               const int32_t* fixed, const float* f1, const float* f2,
+                               const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr,
+                               const float* z_rot, int32_t early_stop_count, int32_t* state, float* dcom,
+                               float* drot, void* stream);
 
 /* Counters of the last adf_painn_forward: algorithmic bytes of the message
  * kernel, dense FLOPs, padded/real edge rows (bench.py roofline). */

@@ -260,7 +260,7 @@ def test_stepper_each_step_vs_reference_fixture(name):
         if not params["ode"]:
             z_tr = torch.normal(mean=0, std=1, size=(B, 3)).to(DEV)
             z_rot = torch.normal(mean=0, std=1, size=(B, 3)).to(DEV)
-        state = torch.tensor([0, 0, 1, 0], dtype=torch.int32, device=DEV)
+        state = torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=DEV)
         eng.forward_prepared(prep, pos, f1, f2)
         eng.sde_step(prep, pos, f1, f2, coefs[t], state, z_tr, z_rot, early_stop_count=0)
         want = log[t + 1] if t + 1 < T else torch.from_numpy(fx["pos_final"])
@@ -282,6 +282,23 @@ def test_denoiser_end_to_end_vs_reference_fixture(tmp_path):
     z = np.load(tmp_path / files[0])
     assert z["positions"].shape[0] == 8
     assert float(out.y.abs().sum()) == 0.0 and out.force.shape == out.pos.shape  # reference side effects
+
+
+def test_graph_replay_matches_eager():
+    """denoising_pos_params["use_graph"]: one captured hipGraph per step gives bit-identical positions."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("stepper_ode8.npz")
+    tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
+    outs = []
+    for use_graph in (False, True):
+        b = batch_from_fixture(fx, pos_key="pos_in")
+        torch.manual_seed(int(fx["seed"]))
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), use_graph=use_graph), device=DEV)
+        outs.append(den.run().pos.clone())
+        assert den.steps_applied == 8
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_stepper_early_stop_vs_reference_fixture():
@@ -405,3 +422,24 @@ def test_weight_update_is_picked_up():
         m.update_layers[1].xvec_proj[2].bias.sub_(0.3)
     h1, _ = m(b)
     assert rel_err(h1, f1) < 1e-6
+
+
+def test_calculator_single_structure_api():
+    """AdsorbDiffCalculator.run_diffusion on one structure == Denoiser on the same system and seed."""
+    from adsorbdiff_amd.calculator import AdsorbDiffCalculator, SimpleAtoms
+
+    fx = load_npz("stepper_ode8.npz")
+    params = _params(fx)
+    b = batch_from_fixture(fx, pos_key="pos_in")
+    one = b.to_data_list()[0]
+    atoms = SimpleAtoms(one.atomic_numbers.long().numpy(), one.pos.numpy(), one.cell[0].numpy(), one.tags.numpy(),
+                        one.fixed.numpy())
+    calc = AdsorbDiffCalculator(_stepper_model(fx), params, device=DEV, seed=11)
+    out = calc.run_diffusion(atoms)
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.data import Batch
+
+    torch.manual_seed(11)
+    ref = Denoiser(Batch.from_data_list([one]), DiffTorchCalc(calc.trainer), params, device=DEV).run()
+    np.testing.assert_allclose(out.get_positions(), ref.pos.cpu().numpy(), rtol=0, atol=1e-6)
+    assert (out.get_tags() == one.tags.numpy()).all()

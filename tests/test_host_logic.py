@@ -185,3 +185,15 @@ def test_checkpoint_ingest(tmp_path):
         if p.requires_grad:
             assert torch.all(p == 0.25), k
     assert torch.equal(dst.state_dict()["radial_basis.rbf.offset"], src.state_dict()["radial_basis.rbf.offset"])
+
+
+def test_atoms_conversions_roundtrip():
+    from adsorbdiff_amd.calculator import SimpleAtoms, atoms_to_data, batch_to_atoms
+
+    b = make_batch(1, n_slab=16, n_ads=2, seed=21)
+    a = SimpleAtoms(b.atomic_numbers.long().numpy(), b.pos.numpy(), b.cell[0].numpy(), b.tags.numpy(), b.fixed.numpy())
+    d = atoms_to_data(a, sid="s")
+    assert torch.allclose(d.pos, b.pos) and torch.equal(d.tags, b.tags) and torch.equal(d.fixed, b.fixed)
+    assert d.cell.shape == (1, 3, 3) and d.pbc.tolist() == [[True, True, True]] and int(d.natoms) == 18
+    back = batch_to_atoms(Batch.from_data_list([d]))[0]
+    assert np.allclose(back.get_positions(), b.pos.numpy()) and list(back.get_tags()) == b.tags.tolist()
