@@ -104,11 +104,14 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 
     {   // stage this slice's rbf_proj image once
         if (F16) {
-            const int R8 = p.R / 8;  // 16-B pieces per column row
+            const int R8 = p.R / 8;  // 16-B pieces per column row (R <= 128; the rest of the row is zero-filled,
+                                     // the 16-deep contraction steps may reach past R)
             const half8* src = reinterpret_cast<const half8*>(p.wpack16 + (size_t)slice * 2 * MSG_COLS * p.R);
-            for (int i = tid; i < 2 * MSG_COLS * R8; i += MSG_THREADS) {
-                const int row = i / R8, piece = i - row * R8;  // row in [0, 384): hi rows then lo rows
-                *reinterpret_cast<half8*>(Wh + (size_t)row * MSG_LDK + piece * 8) = src[i];
+            const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = tid; i < 2 * MSG_COLS * 17; i += MSG_THREADS) {
+                const int row = i / 17, piece = i - row * 17;  // row in [0, 384): hi rows then lo rows
+                *reinterpret_cast<half8*>(Wh + (size_t)row * MSG_LDK + piece * 8) =
+                    piece < R8 ? src[row * R8 + piece] : zero8;
             }
         } else {
             const float4* src = reinterpret_cast<const float4*>(p.wpack + (size_t)slice * p.R * MSG_COLS);

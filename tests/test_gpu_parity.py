@@ -443,3 +443,18 @@ def test_calculator_single_structure_api():
     ref = Denoiser(Batch.from_data_list([one]), DiffTorchCalc(calc.trainer), params, device=DEV).run()
     np.testing.assert_allclose(out.get_positions(), ref.pos.cpu().numpy(), rtol=0, atol=1e-6)
     assert (out.get_tags() == one.tags.numpy()).all()
+
+
+def test_other_hyperparameters_vs_oracle():
+    """H=256, R=64, K=30, 1 layer: exercises the generic paths (4 channel slices, 64-deep basis)."""
+    b = make_batch(2, n_slab=36, n_ads=4, seed=66)
+    from oracle import painn_oracle as O
+
+    torch.manual_seed(4)
+    m = PaiNN(None, 50, 1, hidden_channels=256, num_layers=1, num_rbf=64, cutoff=5.0, max_neighbors=30,
+              so3_denoising=True).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    r1, r2 = O.painn_forward(sd, b.pos, b.atomic_numbers, b.cell, b.natoms, hidden_channels=256, num_layers=1,
+                             num_rbf=64, cutoff=5.0, max_neighbors=30, scale_factors=[1.0])
+    f1, f2 = m.to(DEV)(b.clone().to(DEV))
+    assert rel_err(f1.cpu(), r1) < REL_TOL and rel_err(f2.cpu(), r2) < REL_TOL
