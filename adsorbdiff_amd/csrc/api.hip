@@ -149,13 +149,15 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
 
 static void free_workspaces(adf_painn* h) {
     void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
-                    h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec};
+                    h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec,
+                    h->cache_d2, h->cache_cid, h->cache_cnt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->nbr_cnt = h->nbr_src = h->nbr_shift = h->deg = h->nptr = h->cursor = h->img_cnt = h->e_src = nullptr;
     h->scan_tmp = nullptr; h->scan_tmp_bytes = 0;
     h->e_geom = nullptr;
     h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = h->rec = nullptr;
+    h->cache_d2 = nullptr; h->cache_cid = nullptr; h->cache_cnt = nullptr; h->cache_valid = false;
     h->capN = h->capB = h->capE = 0;
 }
 
@@ -269,6 +271,9 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
     ALLOC(nbr_cnt, capN);
     ALLOC(nbr_src, capN * K);
     ALLOC(nbr_shift, capN * K);
+    ALLOC(cache_d2, capN * K);
+    ALLOC(cache_cid, capN * K);
+    ALLOC(cache_cnt, capN);
     ALLOC(deg, capN + 1);
     ALLOC(nptr, capN + 1);
     ALLOC(cursor, capN);
@@ -313,6 +318,15 @@ static int32_t read_flags(adf_painn* h, hipStream_t s) {
     if (f[0]) { adf_set_error("a centre atom has more than %d in-cutoff candidates", ADF_MAX_CAND); return ADF_EOVERFLOW; }
     if (f[2]) { adf_set_error("edge buffer overflow"); return ADF_EOVERFLOW; }
     if (f[1]) { adf_set_error("An image has no neighbors"); return ADF_ENONEIGHBOR; }
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, const int32_t* mov_idx,
+                                        const int32_t* mov_off) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    if (moving && (!mov_idx || !mov_off)) { adf_set_error("moving mask needs mov_idx and mov_off"); return ADF_EINVAL; }
+    h->moving = moving; h->mov_idx = mov_idx; h->mov_off = mov_off;
+    h->cache_valid = false;
     return ADF_OK;
 }
 

@@ -97,6 +97,14 @@ struct adf_painn {
     int32_t* img_cnt;    // [B]   directed edges per image (empty-image check)
     void* scan_tmp;      // hipcub scan workspace
     size_t scan_tmp_bytes;
+    // static-atom cache of the top-K kernel (adf_graph_set_moving)
+    const int32_t* moving;   // caller-owned [N] mask, null = every atom may move (no cache)
+    const int32_t* mov_idx;  // caller-owned: indices of the moving atoms grouped by system
+    const int32_t* mov_off;  // caller-owned [B+1]
+    float* cache_d2;         // [capN*K]
+    int32_t* cache_cid;      // [capN*K]
+    int32_t* cache_cnt;      // [capN]
+    bool cache_valid;
     int32_t* e_src;      // [capE] source atom of every edge, grouped by target, sorted by distance
     float4* e_geom;      // [capE] (ux,uy,uz,d): unit vector target->source, distance
     int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}

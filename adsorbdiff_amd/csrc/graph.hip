@@ -38,6 +38,13 @@ struct GraphParams {
     int32_t* nbr_shift;
     int32_t* img_cnt;
     int32_t* flags;
+    // static-atom cache (optional)
+    const int32_t* moving;   // [N] 1 = atom moves between graph builds
+    const int32_t* mov_idx;  // moving atoms, grouped by system
+    const int32_t* mov_off;  // [B+1]
+    float* cache_d2;         // [N,K]
+    int32_t* cache_cid;      // [N,K]
+    int32_t* cache_cnt;      // [N]
 };
 
 __device__ __forceinline__ void decode_shift(int c, int r0, int r1, int r2, float& sa, float& sb, float& sc) {
@@ -56,11 +63,56 @@ __device__ __forceinline__ void decode_shift(int c, int r0, int r1, int r2, floa
 // ballot + prefix popcount (no atomics).  Selection of the K smallest keys (d^2, candidate index):
 // every lane keeps its candidates in registers and counts, for each of them, how many list entries
 // are smaller (entries are broadcast from LDS).  Survivors are emitted in candidate order.
+//
+// Static-atom cache (sampling: only adsorbate atoms move between reverse steps).  MODE 1 additionally
+// stores, for every static centre, its K nearest *static* candidates; MODE 2 then rebuilds a static
+// centre's list from that cache plus the candidates of the system's few moving atoms — any static
+// candidate among the K nearest overall is among the K nearest static ones, so the result is
+// identical to the full evaluation (same d^2 arithmetic, same keys) at ~1/50 of the work.  Moving
+// centres are always evaluated in full.
 #define TOPK_CAP 1024  // in-cutoff candidates per centre (a 12 A sphere in a dense bulk holds ~630)
+#define MOVBIT 0x40000000
+
+struct TopkLds {
+    float d2[4][TOPK_CAP];
+    int32_t id[4][TOPK_CAP];     // candidate index j*C + c, | MOVBIT when atom j moves
+    float off[4][3 * 128];       // Cartesian offsets of the shift table (<= 125 shifts cached)
+    int32_t kept[4][ADF_MAX_K];
+};
+
+// rank selection among entries with (id & skip_mask) == 0; returns per-lane keep bits for e = lane + 64 t
+__device__ __forceinline__ unsigned int topk_select(const TopkLds& L, int w, int lane, int M, int K, int skip_mask) {
+    const int T = (M + 63) >> 6;  // <= 16
+    unsigned int keepbits = 0;
+    for (int t0 = 0; t0 < T; t0 += 4) {  // 4 entries of this lane at a time
+        float d[4]; int id[4]; int rank[4]; bool use[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = lane + 64 * (t0 + u);
+            const int raw = e < M ? L.id[w][e] : 0;
+            use[u] = e < M && (raw & skip_mask) == 0;
+            d[u] = use[u] ? L.d2[w][e] : 3.0e38f;
+            id[u] = raw & ~MOVBIT;
+            rank[u] = 0;
+        }
+        for (int f = 0; f < M; ++f) {
+            const int rawf = L.id[w][f];
+            if (rawf & skip_mask) continue;  // wave-uniform
+            const float df = L.d2[w][f];
+            const int idf = rawf & ~MOVBIT;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank[u] += ((df < d[u]) || (df == d[u] && idf < id[u])) ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (use[u] && rank[u] < K) keepbits |= 1u << (t0 + u);
+    }
+    return keepbits;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void adf_topk_kernel(GraphParams p) {
-    __shared__ float s_d2[4][TOPK_CAP];
-    __shared__ int32_t s_id[4][TOPK_CAP];
-    __shared__ float s_off[4][3 * 128];  // Cartesian offsets of the shift table (<= 125 shifts cached)
+    __shared__ TopkLds L;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + w;
     if (i >= p.N) return;
@@ -68,6 +120,7 @@ __global__ __launch_bounds__(256) void adf_topk_kernel(GraphParams p) {
     const int a0 = p.atom_offset[b];
     const int n = p.atom_offset[b + 1] - a0;
     const int C = (2 * p.r0 + 1) * (2 * p.r1 + 1) * (2 * p.r2 + 1);
+    const int K = p.K;
     const float* cl = p.cell + 9 * b;
     const float c00 = cl[0], c01 = cl[1], c02 = cl[2];
     const float c10 = cl[3], c11 = cl[4], c12 = cl[5];
@@ -78,42 +131,67 @@ __global__ __launch_bounds__(256) void adf_topk_kernel(GraphParams p) {
             float sa, sb, sc;
             decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
             // offset = cell^T . shift, summed in k order without FMA (utils.py:680-681)
-            s_off[w][3 * c] = __fadd_rn(__fadd_rn(__fmul_rn(c00, sa), __fmul_rn(c10, sb)), __fmul_rn(c20, sc));
-            s_off[w][3 * c + 1] = __fadd_rn(__fadd_rn(__fmul_rn(c01, sa), __fmul_rn(c11, sb)), __fmul_rn(c21, sc));
-            s_off[w][3 * c + 2] = __fadd_rn(__fadd_rn(__fmul_rn(c02, sa), __fmul_rn(c12, sb)), __fmul_rn(c22, sc));
+            L.off[w][3 * c] = __fadd_rn(__fadd_rn(__fmul_rn(c00, sa), __fmul_rn(c10, sb)), __fmul_rn(c20, sc));
+            L.off[w][3 * c + 1] = __fadd_rn(__fadd_rn(__fmul_rn(c01, sa), __fmul_rn(c11, sb)), __fmul_rn(c21, sc));
+            L.off[w][3 * c + 2] = __fadd_rn(__fadd_rn(__fmul_rn(c02, sa), __fmul_rn(c12, sb)), __fmul_rn(c22, sc));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
     const float pix = p.pos[3 * i], piy = p.pos[3 * i + 1], piz = p.pos[3 * i + 2];
     int M = 0;  // wave-uniform count of in-cutoff candidates
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        const bool jv = j < n;
-        const float* pj = p.pos + 3 * (size_t)(a0 + (jv ? j : 0));
-        const float pjx = pj[0], pjy = pj[1], pjz = pj[2];
-        for (int c = 0; c < C; ++c) {
-            float ox, oy, oz;
-            if (cached) {
-                ox = s_off[w][3 * c]; oy = s_off[w][3 * c + 1]; oz = s_off[w][3 * c + 2];
-            } else {
-                float sa, sb, sc;
-                decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
-                ox = __fadd_rn(__fadd_rn(__fmul_rn(c00, sa), __fmul_rn(c10, sb)), __fmul_rn(c20, sc));
-                oy = __fadd_rn(__fadd_rn(__fmul_rn(c01, sa), __fmul_rn(c11, sb)), __fmul_rn(c21, sc));
-                oz = __fadd_rn(__fadd_rn(__fmul_rn(c02, sa), __fmul_rn(c12, sb)), __fmul_rn(c22, sc));
-            }
-            const float dx = __fsub_rn(pix, __fadd_rn(pjx, ox));
-            const float dy = __fsub_rn(piy, __fadd_rn(pjy, oy));
-            const float dz = __fsub_rn(piz, __fadd_rn(pjz, oz));
-            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            const bool in = jv && d2 <= p.rc2 && d2 > 0.0001f;
-            const unsigned long long mask = __ballot(in);
-            if (in) {
-                const int slot = M + __popcll(mask & ((1ull << lane) - 1ull));
-                if (slot < TOPK_CAP) { s_d2[w][slot] = d2; s_id[w][slot] = j * C + c; }
-            }
-            M += __popcll(mask);
+
+    // candidate (atom j of this system, shift c): evaluate with the reference's op order and append
+    auto consider = [&](bool active, int j, int c, int movbit) {
+        float ox, oy, oz;
+        if (cached) {
+            ox = L.off[w][3 * c]; oy = L.off[w][3 * c + 1]; oz = L.off[w][3 * c + 2];
+        } else {
+            float sa, sb, sc;
+            decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
+            ox = __fadd_rn(__fadd_rn(__fmul_rn(c00, sa), __fmul_rn(c10, sb)), __fmul_rn(c20, sc));
+            oy = __fadd_rn(__fadd_rn(__fmul_rn(c01, sa), __fmul_rn(c11, sb)), __fmul_rn(c21, sc));
+            oz = __fadd_rn(__fadd_rn(__fmul_rn(c02, sa), __fmul_rn(c12, sb)), __fmul_rn(c22, sc));
+        }
+        const float* pj = p.pos + 3 * (size_t)(a0 + (active ? j : 0));
+        const float dx = __fsub_rn(pix, __fadd_rn(pj[0], ox));
+        const float dy = __fsub_rn(piy, __fadd_rn(pj[1], oy));
+        const float dz = __fsub_rn(piz, __fadd_rn(pj[2], oz));
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const bool in = active && d2 <= p.rc2 && d2 > 0.0001f;
+        const unsigned long long mask = __ballot(in);
+        if (in) {
+            const int slot = M + __popcll(mask & ((1ull << lane) - 1ull));
+            if (slot < TOPK_CAP) { L.d2[w][slot] = d2; L.id[w][slot] = (j * C + c) | movbit; }
+        }
+        M += __popcll(mask);
+    };
+
+    const bool centre_moves = MODE == 0 ? true : (p.moving[i] != 0);
+    if (MODE == 2 && !centre_moves) {
+        // cached K nearest static candidates + every candidate of the system's moving atoms
+        const int cnt = p.cache_cnt[i];
+        for (int t = lane; t < cnt; t += 64) {
+            L.d2[w][t] = p.cache_d2[(size_t)i * K + t];
+            L.id[w][t] = p.cache_cid[(size_t)i * K + t];
+        }
+        M = cnt;
+        const int m0 = p.mov_off[b], nm = p.mov_off[b + 1] - m0;
+        const int npairs = nm * C;
+        for (int q0 = 0; q0 < npairs; q0 += 64) {
+            const int q = q0 + lane;
+            const bool act = q < npairs;
+            const int m = act ? q / C : 0;
+            const int c = act ? q - m * C : 0;
+            const int j = p.mov_idx[m0 + m] - a0;
+            consider(act, j, c, MOVBIT);
+        }
+    } else {
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            const bool jv = j < n;
+            const int movbit = (MODE == 1 && jv && p.moving[a0 + j]) ? MOVBIT : 0;
+            for (int c = 0; c < C; ++c) consider(jv, j, c, movbit);
         }
     }
     if (M > TOPK_CAP) {
@@ -122,49 +200,41 @@ __global__ __launch_bounds__(256) void adf_topk_kernel(GraphParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int K = p.K;
-    // keep[e] for the lane's entries e = lane + 64*t
-    unsigned int keepbits = 0;  // bit t
-    const int T = (M + 63) >> 6;  // <= 16
-    if (M <= K) {
-        keepbits = 0xFFFFu;
-    } else {
-        for (int t0 = 0; t0 < T; t0 += 4) {  // 4 entries of this lane at a time
-            float d[4]; int id[4]; int rank[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = lane + 64 * (t0 + u);
-                d[u] = e < M ? s_d2[w][e] : 3.0e38f;
-                id[u] = e < M ? s_id[w][e] : 0x7fffffff;
-                rank[u] = 0;
+    const int T = (M + 63) >> 6;
+
+    if (MODE == 1 && !centre_moves) {  // cache: the K nearest among static candidates
+        const unsigned int kb = topk_select(L, w, lane, M, K, MOVBIT);
+        int nc = 0;
+        for (int t = 0; t < T; ++t) {
+            const int e = lane + 64 * t;
+            const bool kp = e < M && ((kb >> t) & 1u);
+            const unsigned long long mask = __ballot(kp);
+            if (kp) {
+                const int slot = nc + __popcll(mask & ((1ull << lane) - 1ull));
+                p.cache_d2[(size_t)i * K + slot] = L.d2[w][e];
+                p.cache_cid[(size_t)i * K + slot] = L.id[w][e];
             }
-            for (int f = 0; f < M; ++f) {
-                const float df = s_d2[w][f];
-                const int idf = s_id[w][f];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rank[u] += ((df < d[u]) || (df == d[u] && idf < id[u])) ? 1 : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (rank[u] < K) keepbits |= 1u << (t0 + u);
+            nc += __popcll(mask);
         }
+        if (lane == 0) p.cache_cnt[i] = nc;
     }
+
+    const unsigned int keepbits = M <= K ? 0xFFFFu : topk_select(L, w, lane, M, K, 0);
     // survivors in candidate order: position = number of survivors with a smaller candidate index
-    __shared__ int32_t s_kept[4][ADF_MAX_K];
     int nk = 0;
     for (int t = 0; t < T; ++t) {
         const int e = lane + 64 * t;
         const bool kp = e < M && ((keepbits >> t) & 1u);
         const unsigned long long mask = __ballot(kp);
-        if (kp) s_kept[w][nk + __popcll(mask & ((1ull << lane) - 1ull))] = s_id[w][e];
+        if (kp) L.kept[w][nk + __popcll(mask & ((1ull << lane) - 1ull))] = L.id[w][e] & ~MOVBIT;
         nk += __popcll(mask);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int t = lane; t < nk; t += 64) {
-        const int id = s_kept[w][t];
+        const int id = L.kept[w][t];
         int posn = 0;
-        for (int f = 0; f < nk; ++f) posn += s_kept[w][f] < id;
+        for (int f = 0; f < nk; ++f) posn += L.kept[w][f] < id;
         const int j = id / C;
         p.nbr_src[(size_t)i * K + posn] = a0 + j;
         p.nbr_shift[(size_t)i * K + posn] = id - j * C;
@@ -286,7 +356,18 @@ int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
     ADF_HIP_CHECK(hipMemsetAsync(h->cursor, 0, sizeof(int32_t) * N, s));
     ADF_HIP_CHECK(hipMemsetAsync(h->img_cnt, 0, sizeof(int32_t) * B, s));
     ADF_HIP_CHECK(hipMemsetAsync(h->flags, 0, sizeof(int32_t) * 4, s));
-    hipLaunchKernelGGL(adf_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, s, p);
+    // static-atom cache: valid for the same batch as long as only atoms flagged `moving` moved
+    p.moving = h->moving; p.mov_idx = h->mov_idx; p.mov_off = h->mov_off;
+    p.cache_d2 = h->cache_d2; p.cache_cid = h->cache_cid; p.cache_cnt = h->cache_cnt;
+    const dim3 tg((N + 3) / 4);
+    if (!h->moving) {
+        hipLaunchKernelGGL(adf_topk_kernel<0>, tg, dim3(256), 0, s, p);
+    } else if (!h->cache_valid) {
+        hipLaunchKernelGGL(adf_topk_kernel<1>, tg, dim3(256), 0, s, p);
+        h->cache_valid = true;
+    } else {
+        hipLaunchKernelGGL(adf_topk_kernel<2>, tg, dim3(256), 0, s, p);
+    }
     const long long slots = (long long)N * K;
     const unsigned nb = (unsigned)((slots + 255) / 256);
     hipLaunchKernelGGL(adf_count_kernel, dim3(nb), dim3(256), 0, s, p, h->deg);

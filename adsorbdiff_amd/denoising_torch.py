@@ -165,6 +165,8 @@ class Denoiser:
             # initial placement: uniform noise from the CPU global generator (reference :215)
             noise = torch.rand(B, 3)
             eng.init_placement(prep, pos, noise.to(dev))
+            # from here on only the adsorbate (tag 2) moves: the graph builder may cache the slab-slab part
+            eng.set_moving_atoms(prep, prep.tags == 2)
 
             f1 = torch.empty(N, 3, dtype=torch.float32, device=dev)
             f2 = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -227,6 +229,10 @@ class Denoiser:
             batch.y = torch.zeros(B_, device=dev)
             batch.force = torch.zeros(N, 3, device=dev)
         finally:
+            try:
+                self._engine().set_moving_atoms(None, None)
+            except Exception:
+                pass
             if ema:
                 ema.restore()
 

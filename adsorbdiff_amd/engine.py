@@ -171,6 +171,21 @@ class PaiNNEngine:
             prep.fixed = data.fixed.to(dev, torch.int32).contiguous()
         return prep
 
+    def set_moving_atoms(self, prep: Optional[PreparedBatch], moving_mask: Optional[torch.Tensor]) -> None:
+        """Declare which atoms may move between the next graph builds of ``prep`` (None switches the
+        static-atom cache off).  The arrays are kept alive on the engine until the next call."""
+        if moving_mask is None or prep is None:
+            self._moving_keepalive = None
+            _lib.check(self.lib.adf_graph_set_moving(self.handle, None, None, None))
+            return
+        mask = moving_mask.to(self.device, torch.int32).contiguous()
+        idx = torch.nonzero(mask).reshape(-1).to(torch.int32).contiguous()
+        per_sys = torch.bincount(prep.batch[idx.long()].long(), minlength=prep.num_systems)
+        off = torch.zeros(prep.num_systems + 1, dtype=torch.int32, device=self.device)
+        off[1:] = torch.cumsum(per_sys, 0).to(torch.int32)
+        self._moving_keepalive = (mask, idx, off)
+        _lib.check(self.lib.adf_graph_set_moving(self.handle, mask.data_ptr(), idx.data_ptr(), off.data_ptr()))
+
     # ------------------------------------------------------------------ calls
     def forward_prepared(self, prep: PreparedBatch, pos: torch.Tensor, f1: torch.Tensor, f2: Optional[torch.Tensor]) -> None:
         """Enqueue one forward; no host synchronisation."""

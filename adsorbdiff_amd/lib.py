@@ -15,7 +15,8 @@ from pathlib import Path
 ADF_OK, ADF_EINVAL, ADF_EOOM, ADF_ENONEIGHBOR, ADF_EHIP, ADF_EOVERFLOW = 0, 1, 2, 3, 4, 5
 
 EXPORTS = (
-    "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_check_flags",
+    "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_graph_set_moving",
+    "adf_check_flags",
     "adf_graph_export", "adf_painn_forward", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_get_counters", "adf_profile_enable", "adf_profile_read",
     "adf_last_error", "adf_version",
@@ -83,6 +84,7 @@ def load():
         "adf_painn_destroy": [vp],
         "adf_painn_set_weights": [vp, i32, C.POINTER(vp), C.POINTER(C.c_float), vp],
         "adf_graph_build": [vp, C.POINTER(BatchDesc), vp, C.POINTER(i64)],
+        "adf_graph_set_moving": [vp, vp, vp, vp],
         "adf_check_flags": [vp, vp],
         "adf_graph_export": [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.POINTER(i64), vp],
         "adf_painn_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp],

@@ -108,6 +108,15 @@ typedef struct {
  * (HOST, may be NULL) forces a stream sync when non-NULL. */
 int32_t adf_graph_build(adf_painn_t h, const adf_batch* b, void* stream, int64_t* num_edges);
 
+/* Static-atom cache for repeated graph builds of the SAME batch in which only some atoms move
+ * (sampling: the adsorbate; denoising_torch.py:353 only rewrites pos[tags == 2]).  moving: [N] int32
+ * mask (1 = may move), mov_idx: indices of the moving atoms grouped by system, mov_off: [B+1] offsets
+ * into mov_idx; all caller-owned device arrays that must stay valid until reset.  The next build
+ * evaluates everything and caches each static centre's K nearest static candidates; later builds
+ * only re-evaluate candidates that involve a moving atom — results are identical to a full build.
+ * Pass NULLs to switch the cache off (default).  Any call invalidates the cache. */
+int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, const int32_t* mov_idx, const int32_t* mov_off);
+
 /* Read the device-side error flags of the last graph build (candidate overflow,
  * empty image).  Synchronises the stream.  adf_painn_forward does not check
  * them itself so that a sampling loop stays free of host round trips. */

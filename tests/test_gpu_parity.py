@@ -458,3 +458,33 @@ def test_other_hyperparameters_vs_oracle():
                              num_rbf=64, cutoff=5.0, max_neighbors=30, scale_factors=[1.0])
     f1, f2 = m.to(DEV)(b.clone().to(DEV))
     assert rel_err(f1.cpu(), r1) < REL_TOL and rel_err(f2.cpu(), r2) < REL_TOL
+
+
+@pytest.mark.parametrize("shape", [dict(n_slab=36, n_ads=4, cutoff=6.0, K=20), dict(n_slab=196, n_ads=4, cutoff=10.0, K=50)])
+def test_static_atom_cache_gives_identical_graph(shape):
+    """adf_graph_set_moving: after the adsorbate moved, the cached incremental top-K equals a full rebuild."""
+    b = make_batch(3, n_slab=shape["n_slab"], n_ads=shape["n_ads"], seed=71).to(DEV)
+    m = graph_model(shape["cutoff"], shape["K"])
+    eng = m.engine()
+    prep = eng.prepare(b)
+    eng.set_moving_atoms(prep, b.tags == 2)
+    eng.build_graph(b)  # full evaluation + cache fill
+    g = torch.Generator().manual_seed(5)
+    for trial in range(3):
+        moved = b.clone()
+        ads = moved.tags == 2
+        moved.pos[ads] = moved.pos[ads] + (torch.rand(int(ads.sum()), 3, generator=g).to(DEV) - 0.5) * torch.tensor(
+            [6.0, 6.0, 1.5], device=DEV)
+        E_inc = eng.build_graph(moved)  # incremental
+        inc = [t.clone() for t in eng.export_graph()]
+        eng.set_moving_atoms(None, None)
+        E_full = eng.build_graph(moved)
+        full = eng.export_graph()
+        assert E_inc == E_full
+        for a, f in zip(inc[:3], full[:3]):
+            assert torch.equal(a, f)
+        for a, f in zip(inc[3:], full[3:]):
+            assert torch.equal(a, f)  # edges are sorted per target, so even the order matches
+        eng.set_moving_atoms(prep, b.tags == 2)
+        eng.build_graph(b)  # refill the cache from the reference positions
+    eng.set_moving_atoms(None, None)
