@@ -327,28 +327,43 @@ def test_ml_diffuse_and_trainer_entry(tmp_path):
 
 
 def test_full_size_properties():
-    """BASELINE-size properties that do not need the oracle: translation of a whole system by a
-    lattice vector and permutation of the systems in the batch leave the per-system scores
-    unchanged (up to fp32 rounding)."""
-    from oracle import painn_oracle as O  # only ads_mean helper (checker side)
+    """BASELINE-size batch (1000 systems x 200 atoms, 10 A, K=50, H=512).  Size-independent properties:
+    (1) reversing the order of the systems permutes the per-system scores and nothing else;
+    (2) a rigid in-plane shift of every atom leaves them unchanged (up to re-rounded positions);
+    (3) two systems picked from the middle of the batch agree with the CPU oracle run on them alone."""
+    from oracle import painn_oracle as O
 
     torch.manual_seed(0)
     m = PaiNN(None, 50, 1, cutoff=10.0, max_neighbors=50, scale_file=PAINN_NB6_SCALE_FACTORS,
-              so3_denoising=True).to(DEV).eval()
-    b = make_batch(16, seed=1234)
+              so3_denoising=True).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV)
+    B = 1000
+    b = make_batch(B, seed=1234)
     f1, f2 = m(b.clone().to(DEV))
-    s1 = O.ads_mean(f1.cpu(), b.tags, b.batch, 16)
-    # reverse the order of the systems
+    assert bool(torch.isfinite(f1).all()) and bool(torch.isfinite(f2).all())
+    s1 = O.ads_mean(f1.cpu(), b.tags, b.batch, B)
+    # (1) reverse the order of the systems
     rev = type(b).from_data_list(list(reversed(b.to_data_list())))
     g1, _ = m(rev.clone().to(DEV))
-    t1 = O.ads_mean(g1.cpu(), rev.tags, rev.batch, 16)
+    t1 = O.ads_mean(g1.cpu(), rev.tags, rev.batch, B)
     assert rel_err(t1.flip(0), s1) < REL_TOL
-    # rigid shift of everything by 0.37 A in x/y keeps all interatomic vectors
+    # (2) rigid shift of everything by 0.37 A in x / -0.21 A in y keeps all interatomic vectors
     sh = b.clone()
     sh.pos = sh.pos + torch.tensor([0.37, -0.21, 0.0])
     h1, _ = m(sh.to(DEV))
-    u1 = O.ads_mean(h1.cpu(), b.tags, b.batch, 16)
-    assert rel_err(u1, s1) < 5e-4  # positions are re-rounded, neighbours at the K-th place may tie-flip
+    u1 = O.ads_mean(h1.cpu(), b.tags, b.batch, B)
+    per_sys = (u1 - s1).norm(dim=1) / s1.norm(dim=1)
+    # positions are re-rounded, so a K-th-neighbour near-tie can flip in a handful of systems
+    assert float(per_sys.median()) < 1e-4 and float((per_sys > 1e-3).float().mean()) < 0.01
+    # (3) systems 500 and 777 against the oracle evaluated on them alone
+    data = b.to_data_list()
+    for k in (500, 777):
+        one = type(b).from_data_list([data[k]])
+        r1, r2 = O.painn_forward(sd, one.pos, one.atomic_numbers, one.cell, one.natoms, cutoff=10.0, max_neighbors=50,
+                                 scale_factors=m.scale_factors())
+        sl = slice(200 * k, 200 * (k + 1))
+        assert rel_err(f1[sl].cpu(), r1) < REL_TOL and rel_err(f2[sl].cpu(), r2) < REL_TOL
 
 
 def _oracle_vs_hip(b, hp, seed=0, so3=True, pbc=None, scale=None):
