@@ -163,6 +163,43 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
 
     const float isc = *inv_scale;
     if constexpr (EPI == 0) {
+        if (((N | ldc) & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && NJ % 2 == 0) {
+            // Transpose 32 x 64 pieces of the accumulators through the (now idle) staging LDS so that each lane
+            // stores 16 B: 4 rows x 256 B per wave instruction instead of 2 rows x 128 B with 4-B stores.
+            const int q = lane & 31;
+            __syncthreads();  // all waves are done reading the operand tiles
+            float* T = reinterpret_cast<float*>(lds) + wave * (32 * 68);  // [32 rows][64 + 4 pad] floats
+#pragma unroll
+            for (int jj = 0; jj < NJ / 2; ++jj) {
+                const int cb = n0 + wn + 64 * jj;
+                const float bv0 = (bias && cb + q < N) ? bias[cb + q] : 0.f;
+                const float bv1 = (bias && cb + 32 + q < N) ? bias[cb + 32 + q] : 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        float v0 = acc[i][2 * jj][r] * isc + bv0, v1 = acc[i][2 * jj + 1][r] * isc + bv1;
+                        if (ACT) { v0 = ssilu16(v0); v1 = ssilu16(v1); }
+                        T[lr * 68 + q] = v0;
+                        T[lr * 68 + 32 + q] = v1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int item = lane + 64 * it;
+                        const int lr = item >> 4, c4 = item & 15;
+                        const int row = m0 + wm + 32 * i + lr, col = cb + 4 * c4;
+                        if (row < M && col < N)
+                            *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) =
+                                *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
+                    }
+                    __builtin_amdgcn_wave_barrier();  // T is rewritten by the next piece
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int col = n0 + wn + 32 * j + (lane & 31);
