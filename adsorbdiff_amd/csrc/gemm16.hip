@@ -252,20 +252,25 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                     const float4 p2 = *reinterpret_cast<const float4*>(T + lr * 100 + 64 + 4 * c4);
                     const int c = 32 * g + 4 * c4;
                     if constexpr (EPI == 1) {
-                        // half-record of (atom n, group g): [32 x (xa, xc)] then [32 x (P0, P1, P2)]
+                        // half-record of (atom n, group g): [32 x (xa, xc, P0, P1)] then [32 x P2]
                         float* rec = ep.rec + ((size_t)n * (H / 32) + g) * 160;
-                        float4* ra_ = reinterpret_cast<float4*>(rec + 8 * c4);
-                        ra_[0] = make_float4(p0.x, p2.x, p0.y, p2.y);
-                        ra_[1] = make_float4(p0.z, p2.z, p0.w, p2.w);
+                        float4* ra_ = reinterpret_cast<float4*>(rec + 16 * c4);
                         if (!ep.vec_is_zero) {
                             const float* vr = ep.vec_in + (size_t)n * 3 * H + c;
                             const float4 v0 = *reinterpret_cast<const float4*>(vr);
                             const float4 v1 = *reinterpret_cast<const float4*>(vr + H);
                             const float4 v2 = *reinterpret_cast<const float4*>(vr + 2 * H);
-                            float4* pr = reinterpret_cast<float4*>(rec + 64 + 12 * c4);
-                            pr[0] = make_float4(v0.x * p1.x, v1.x * p1.x, v2.x * p1.x, v0.y * p1.y);
-                            pr[1] = make_float4(v1.y * p1.y, v2.y * p1.y, v0.z * p1.z, v1.z * p1.z);
-                            pr[2] = make_float4(v2.z * p1.z, v0.w * p1.w, v1.w * p1.w, v2.w * p1.w);
+                            ra_[0] = make_float4(p0.x, p2.x, v0.x * p1.x, v1.x * p1.x);
+                            ra_[1] = make_float4(p0.y, p2.y, v0.y * p1.y, v1.y * p1.y);
+                            ra_[2] = make_float4(p0.z, p2.z, v0.z * p1.z, v1.z * p1.z);
+                            ra_[3] = make_float4(p0.w, p2.w, v0.w * p1.w, v1.w * p1.w);
+                            *reinterpret_cast<float4*>(rec + 128 + 4 * c4) =
+                                make_float4(v2.x * p1.x, v2.y * p1.y, v2.z * p1.z, v2.w * p1.w);
+                        } else {
+                            ra_[0] = make_float4(p0.x, p2.x, 0.f, 0.f);
+                            ra_[1] = make_float4(p0.y, p2.y, 0.f, 0.f);
+                            ra_[2] = make_float4(p0.z, p2.z, 0.f, 0.f);
+                            ra_[3] = make_float4(p0.w, p2.w, 0.f, 0.f);
                         }
                     } else {
                         const size_t xo = (size_t)n * H + c;

@@ -59,7 +59,7 @@ struct MsgParams {
     const float* inv_scale;  // device scalar (f16 mode)
     const float* mu;
     int N, H, R, G, nslices;
-    float inv_cutoff, coeff, env_a, env_b, env_c;
+    float inv_cutoff, coeff, sarg, env_a, env_b, env_c;
     int env_pi;
     unsigned long long* kcount;  // optional: sum over 32-row blocks of the contracted k length (profiling)
 };
@@ -108,10 +108,14 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                                      // the 16-deep contraction steps may reach past R)
             const half8* src = reinterpret_cast<const half8*>(p.wpack16 + (size_t)slice * 2 * MSG_COLS * p.R);
             const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            // k slots 128/129 of the hi image (the row padding) hold the bias as an fp16 hi/lo pair: the
+            // accumulators are initialised by one MFMA against a constant A instead of 96 v_mov per block
+            const _Float16* b16 = reinterpret_cast<const _Float16*>(p.bpack) + (size_t)slice * MSG_COLS * 2;
             for (int i = tid; i < 2 * MSG_COLS * 17; i += MSG_THREADS) {
                 const int row = i / 17, piece = i - row * 17;  // row in [0, 384): hi rows then lo rows
-                *reinterpret_cast<half8*>(Wh + (size_t)row * MSG_LDK + piece * 8) =
-                    piece < R8 ? src[row * R8 + piece] : zero8;
+                half8 v = piece < R8 ? src[row * R8 + piece] : zero8;
+                if (piece == 16 && row < MSG_COLS) { v[0] = b16[2 * row]; v[1] = b16[2 * row + 1]; }
+                *reinterpret_cast<half8*>(Wh + (size_t)row * MSG_LDK + piece * 8) = v;
             }
         } else {
             const float4* src = reinterpret_cast<const float4*>(p.wpack + (size_t)slice * p.R * MSG_COLS);
@@ -119,8 +123,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             const int n4 = p.R * MSG_COLS / 4;
             for (int i = tid; i < n4; i += MSG_THREADS) dst[i] = src[i];
         }
-        if (tid < MSG_COLS) Bl[tid] = p.bpack[slice * MSG_COLS + tid];
-        if (tid < 128) Mu[tid] = tid < p.R ? p.mu[tid] : 2.0f;
+        if (!F16 && tid < MSG_COLS) Bl[tid] = p.bpack[slice * MSG_COLS + tid];
+        // f16 mode: centres pre-multiplied by sqrt(-coeff*log2 e), so that a Gaussian is exp2(-(xs' - mu')^2)
+        if (tid < 128) Mu[tid] = (tid < p.R ? p.mu[tid] : 2.0f) * (F16 ? p.sarg : 1.0f);
         if (tid == 0) *Ctr = 0;
     }
     __syncthreads();
@@ -131,11 +136,12 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const float inv_sqrt_h = out_scale / sqrtf((float)H);
     const float umax_scale = (float)(p.R - 1);
     const float coeff2 = p.coeff * 1.44269504088896341f;  // exp(c z) = exp2(c log2e z)
-    // one record row = H/32 half-records of 640 B: [32 x (xa, xc)] + [32 x (P0, P1, P2)] for 32 channels.
+    // one record row = H/32 half-records of 640 B: [32 x (xa, xc, P0, P1)] + [32 x P2] for 32 channels, read as one
+    // dwordx4 + one dword per lane (12-B-per-lane loads gather at 0.7x the rate of this split: measured 20 vs 28 TB/s).
     // Lane q owns channels c0+q (half-record 2*slice) and c0+32+q (half-record 2*slice+1).
     const unsigned int row_bytes = (unsigned int)p.nslices * 1280u;
-    const char* recA = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 8;
-    const char* recP = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + 256 + (size_t)q * 12;
+    const char* recA = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 16;
+    const char* recP = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + 512 + (size_t)q * 4;
 
     unsigned int ksteps = 0;  // wave-uniform; one global atomic per wave at the very end (profiling)
 
@@ -214,11 +220,14 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // k-window of this block
+            // a target's edges are sorted by distance (graph.hip), so the block's first and last valid rows
+            // bound its window
             const float u = xs * umax_scale;
-            const float umin = wave_min(valid ? u : 1e30f);
-            const float umax = wave_max(valid ? u : -1e30f);
+            const int nvalid = __builtin_amdgcn_readfirstlane(min(32, e1 - eb));
+            const float umin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), 0));
+            const float umax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), max(nvalid, 1) - 1));
             int klo, khi;
-            if (!(umax >= 0.f)) {  // target without incoming edges: one dummy step on all-zero A (env = 0)
+            if (nvalid <= 0) {  // target without incoming edges: one dummy step on all-zero A (env = 0)
                 klo = 0; khi = 16;
             } else if (F16) {
                 klo = max(0, (int)floorf(umin) - 7) & ~7;
@@ -238,23 +247,28 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 #define GATHER(r)                                                                               \
     const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
     const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
-    const float2 ga0##r = *reinterpret_cast<const float2*>(recA + o##r);          /* xa xc (j=0) */ \
-    const float2 ga1##r = *reinterpret_cast<const float2*>(recA + o##r + 640);    /* xa xc (j=1) */ \
-    float3 gp0##r = make_float3(0.f, 0.f, 0.f), gp1##r = gp0##r;                  /* P0 P1 P2 */    \
+    float4 ga0##r, ga1##r;                                     /* xa xc P0 P1 of channel j = 0, 1 */ \
+    float gz0##r = 0.f, gz1##r = 0.f;                          /* P2 */                               \
     if (!VZ) {                                                                                  \
-        gp0##r = *reinterpret_cast<const float3*>(recP + o##r);                                 \
-        gp1##r = *reinterpret_cast<const float3*>(recP + o##r + 640);                           \
+        ga0##r = *reinterpret_cast<const float4*>(recA + o##r);                                 \
+        ga1##r = *reinterpret_cast<const float4*>(recA + o##r + 640);                           \
+        gz0##r = *reinterpret_cast<const float*>(recP + o##r);                                  \
+        gz1##r = *reinterpret_cast<const float*>(recP + o##r + 640);                            \
+    } else {                                                                                    \
+        const float2 t0 = *reinterpret_cast<const float2*>(recA + o##r);                        \
+        const float2 t1 = *reinterpret_cast<const float2*>(recA + o##r + 640);                  \
+        ga0##r = make_float4(t0.x, t0.y, 0.f, 0.f); ga1##r = make_float4(t1.x, t1.y, 0.f, 0.f); \
     }
 #define CONSUME(r)                                                                              \
     {                                                                                           \
         const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
         const float t3 = ga0##r.y * acc[4][r];                                                  \
         sx0 += ga0##r.x * acc[0][r];                                                            \
-        if (!VZ) { sa0 += gp0##r.x * acc[2][r]; sb0 += gp0##r.y * acc[2][r]; sc0 += gp0##r.z * acc[2][r]; } \
+        if (!VZ) { sa0 += ga0##r.z * acc[2][r]; sb0 += ga0##r.w * acc[2][r]; sc0 += gz0##r * acc[2][r]; } \
         ra0 += t3 * ux; rb0 += t3 * uy; rc0 += t3 * uz;                                         \
         const float u3 = ga1##r.y * acc[5][r];                                                  \
         sx1 += ga1##r.x * acc[1][r];                                                            \
-        if (!VZ) { sa1 += gp1##r.x * acc[3][r]; sb1 += gp1##r.y * acc[3][r]; sc1 += gp1##r.z * acc[3][r]; } \
+        if (!VZ) { sa1 += ga1##r.z * acc[3][r]; sb1 += ga1##r.w * acc[3][r]; sc1 += gz1##r * acc[3][r]; } \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
             // rows 0-3: issued before the MFMA loop, they land while the matrix pipe is busy
@@ -262,13 +276,26 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 
             const float env256 = env * 256.0f;
             f32x16 acc[6];
+            if (F16) {
+                // acc = 256 * (b_hi + b_lo): A = 256 at k slots 0 and 1 (half-wave 0 only), B = image slots 128.. of each column
+                half8 aone = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (hi == 0) { aone[0] = (_Float16)256.0f; aone[1] = (_Float16)256.0f; }
+                const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const float bv = Bl[b * 32 + q];
+                for (int b = 0; b < 6; ++b) {
+                    const half8 bb = *reinterpret_cast<const half8*>(Wh + (size_t)(b * 32 + q) * MSG_LDK + 128);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aone, bb, zero16, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[b][r] = bv;
+                for (int b = 0; b < 6; ++b) {
+                    const float bv = Bl[b * 32 + q];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][r] = bv;
+                }
             }
             if (F16) {
+                const float xsq = xs * p.sarg;
                 int k0 = klo;
                 do {  // at least one step: lets the accumulators live in place across the loop
                     // A fragment: lane (row q, half hi) holds k = k0 + 8*hi + j, j = 0..7
@@ -278,10 +305,10 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                     half8 ah, al;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float dm = xs - mus[j];
+                        const float dm = xsq - mus[j];
                         // a in [0,1] is lifted by 2^8 before the split so that a_lo is a normal fp16 number
                         // for every term that matters (the matrix core flushes fp16 subnormals)
-                        const float a = env256 * __builtin_amdgcn_exp2f(coeff2 * (dm * dm));
+                        const float a = env256 * __builtin_amdgcn_exp2f(-(dm * dm));
                         const _Float16 h = (_Float16)a;
                         ah[j] = h;
                         al[j] = (_Float16)(a - (float)h);
@@ -409,7 +436,12 @@ __global__ void adf_pack_rbf16_kernel(const float* __restrict__ w, const float* 
         const size_t base = (size_t)slice * 2 * MSG_COLS * R;
         wpack16[base + (size_t)col * R + k] = h;
         wpack16[base + (size_t)(MSG_COLS + col) * R + k] = (_Float16)(v - (float)h);
-        if (k == 0) bpack16[slice * MSG_COLS + col] = b[part * H + ch] * scale * 256.0f;  // matches the 2^8 lift of A
+        if (k == 0) {  // bias * scale as an fp16 hi/lo pair in the 4 bytes of the column's slot
+            const float bv = b[part * H + ch] * scale;
+            const _Float16 bh = (_Float16)bv;
+            _Float16* o = reinterpret_cast<_Float16*>(bpack16 + slice * MSG_COLS + col);
+            o[0] = bh; o[1] = (_Float16)(bv - (float)bh);
+        }
     }
 }
 
@@ -417,7 +449,7 @@ __global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsi
 
 // Gather records of the message kernel (stand-alone producer, used by the exact-f32 mode; the f16x3
 // mode writes the same layout from the x_proj.2 GEMM epilogue, gemm16.hip EPI 1).  Per source atom n and
-// group g of 32 channels, 640 B:  [32 lanes][xa(c), xc(c)]  then  [32 lanes][P0(c), P1(c), P2(c)],
+// group g of 32 channels, 640 B:  [32 lanes][xa(c), xc(c), P0(c), P1(c)]  then  [32 lanes][P2(c)],
 // c = 32 g + lane, xa/xb/xc = the three H-wide parts of xh, P_i = vec_i * xb.  vec*xb is the only place
 // vec[src] and xb[src] enter the message (painn_denoising.py:549-552), so the per-edge gather shrinks
 // from 6 to 5 floats per channel and every piece a half-wave reads is one contiguous run of the source row.
@@ -434,11 +466,12 @@ __global__ void adf_pack_records_kernel(const float* __restrict__ xh, const floa
         const float* xr = xh + (size_t)n * 3 * H;
         const float xa = xr[c], xb = xr[H + c], xc = xr[2 * H + c];
         float* out = rec + ((size_t)n * ng + g) * 160;
-        reinterpret_cast<float2*>(out)[qq] = make_float2(xa, xc);
         if (!vec_is_zero) {
             const float* vr = vec + (size_t)n * 3 * H;
-            float* pr = out + 64 + 3 * qq;
-            pr[0] = vr[c] * xb; pr[1] = vr[H + c] * xb; pr[2] = vr[2 * H + c] * xb;
+            reinterpret_cast<float4*>(out)[qq] = make_float4(xa, xc, vr[c] * xb, vr[H + c] * xb);
+            out[128 + qq] = vr[2 * H + c] * xb;
+        } else {
+            reinterpret_cast<float4*>(out)[qq] = make_float4(xa, xc, 0.f, 0.f);
         }
     }
 }
@@ -467,6 +500,9 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
                            h->rbf_pack + l * per_layer, h->rbf_bias_pack + l * per_layer_b, H, R);
         ADF_HIP_CHECK(hipMemsetAsync(h->w16_scratch, 0, sizeof(unsigned int), s));
         hipLaunchKernelGGL(adf_absmax_kernel, dim3(64), dim3(256), 0, s, h->layer[l].rbf_w, (long long)3 * H * R,
+                           h->w16_scratch);
+        // the bias shares the scale (it enters the same accumulators through the matrix core)
+        hipLaunchKernelGGL(adf_absmax_kernel, dim3(8), dim3(256), 0, s, h->layer[l].rbf_b, (long long)3 * H,
                            h->w16_scratch);
         hipLaunchKernelGGL(adf_pack_rbf16_kernel, dim3(256), dim3(256), 0, s, h->layer[l].rbf_w, h->layer[l].rbf_b,
                            h->w16_scratch, reinterpret_cast<_Float16*>(h->rbf_pack16) + l * 2 * per_layer,
@@ -507,6 +543,7 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     p.inv_cutoff = 1.0f / h->hp.cutoff;
     const double step = 1.0 / (R - 1);
     p.coeff = (float)(-0.5 / (step * step));
+    p.sarg = (float)sqrt(0.5 / (step * step) * 1.4426950408889634);  // exp(coeff z^2) = exp2(-(sarg z)^2)
     const double pe = (double)h->hp.envelope_exponent;
     p.env_pi = h->hp.envelope_exponent;
     p.env_a = (float)(-(pe + 1) * (pe + 2) / 2);
