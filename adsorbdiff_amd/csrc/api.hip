@@ -216,7 +216,8 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
         unsigned char* cur = h->w16_arena;
         int nscale = 0;
         float* bperm = h->w16_bias_perm;
-        auto split = [&](const float* w, long long n, adf_w16* out, const float* fused_bias = nullptr) -> int32_t {
+        auto split = [&](const float* w, long long n, adf_w16* out, const float* fused_bias = nullptr,
+                         bool pair_perm = false) -> int32_t {
             out->hi = cur; cur += n * 2;
             out->lo = cur; cur += n * 2;
             out->inv_scale = h->w16_scales + nscale++;
@@ -225,13 +226,15 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
                 out->bias_perm = bperm; bperm += 3 * H;
                 return adf_split_weight(w, n, out, h->w16_scratch, s, (int)H, (int)H, fused_bias);
             }
+            if (pair_perm)  // vec_proj [2H, H]: (v1, v2) rows of the same channels side by side (gemm16.hip EPI 3)
+                return adf_split_weight(w, n, out, h->w16_scratch, s, (int)H, (int)H, nullptr, 2);
             return adf_split_weight(w, n, out, h->w16_scratch, s);
         };
         for (int l = 0; l < L; ++l) {
             adf_layer_weights& lw = h->layer[l];
             ADF_TRY(split(lw.xp0_w, HH, &lw.xp0_16));
             ADF_TRY(split(lw.xp2_w, 3 * HH, &lw.xp2_16, lw.xp2_b));
-            ADF_TRY(split(lw.vp_w, 2 * HH, &lw.vp_16));
+            ADF_TRY(split(lw.vp_w, 2 * HH, &lw.vp_16, nullptr, true));
             ADF_TRY(split(lw.xv0_w, 2 * HH, &lw.xv0_16));
             ADF_TRY(split(lw.xv2_w, 3 * HH, &lw.xv2_16, lw.xv2_b));
         }
@@ -426,8 +429,14 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
     const int H = h->hp.hidden_channels;
     const adf_layer_weights& w = h->layer[l];
     adf_prof_begin(h, ADF_PROF_NODE, s);
-    ADF_TRY(adf_linear(h, vec, H, w.vp_w, &w.vp_16, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
-    ADF_TRY(adf_nodewise_update_prep(h->vv, x, h->cat, h->dot, N, H, s));
+    if (h->gemm_f32) {
+        ADF_TRY(adf_launch_gemm(vec, H, w.vp_w, H, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
+        ADF_TRY(adf_nodewise_update_prep(h->vv, x, h->cat, h->dot, N, H, s));
+    } else {  // vec_proj with dot / |v2| / [x | |v2|] formed on the accumulators; v1 -> vv [N,3,H]
+        adf_epi ep = {};
+        ep.x = x; ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H;
+        ADF_TRY(adf_launch_gemm16_fused(vec, H, &w.vp_16, N, H, H, 3, &ep, s));
+    }
     ADF_TRY(adf_linear(h, h->cat, 2 * H, w.xv0_w, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
     int32_t st;
     if (h->gemm_f32) {

@@ -46,7 +46,10 @@ struct adf_epi {
     float* x;             // EPI 2
     float* vec;           // EPI 2
     const float* dot;     // EPI 2
-    const float* vv;      // EPI 2: vec_proj output [N,3,2H], v1 = first H columns
+    const float* vv;      // EPI 2: v1 [N,3,H] (written by EPI 3)
+    float* v1;            // EPI 3: v1 out [N,3,H]
+    float* dotw;          // EPI 3: dot out [N,H]
+    float* cat;           // EPI 3: xvec_proj input [N,2H] = [x | |v2|]  (x copied from ep.x)
     float scale;          // EPI 2: ScaleFactor
     int H;
     int vec_is_zero;      // EPI 1
@@ -133,7 +136,7 @@ int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const 
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s);
 int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
-                         int perm_H = 0, int K = 0, const float* bias = nullptr);
+                         int perm_H = 0, int K = 0, const float* bias = nullptr, int parts = 3);
 int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
                                 const adf_epi* ep, hipStream_t s);
 // C = act(A . W^T + b): f16x3 split MFMA by default, exact-f32 MFMA when h->gemm_f32 (ADF_GEMM=f32)

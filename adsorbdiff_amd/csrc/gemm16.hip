@@ -42,6 +42,11 @@ __device__ __forceinline__ float ssilu16(float x) {
 //   work runs on the accumulators and the 3H-wide intermediate never goes to HBM:
 //     EPI 1  x_proj.2 -> gather records of the message kernel (xa, xc, P_i = vec_i * xb; message.hip)
 //     EPI 2  xvec_proj.2 -> PaiNNUpdate gating + residuals + ScaleFactor (painn_denoising.py:614-623,449-451)
+//   MI=3, NJ=2 with EPI 3: vec_proj of PaiNNUpdate (painn_denoising.py:602-611).  The A rows of vec [N,3,H] are
+//   staged component-major (LDS row = component*32 + atom), so accumulator block i of a wave is component i of
+//   its 32 atoms; the two column blocks are v1 and v2 of the same 32 channels (weights row-permuted: column
+//   g*64 + part*32 + q  <->  row part*H + 32g + q).  dot = sum_xyz v1*v2 / sqrt(H) and |v2| are formed on the
+//   accumulators: v2 (1.2 GB per layer at N = 200k) never goes to HBM and the separate reduction pass is gone.
 template <int ACT, int MI, int NJ, int EPI>
 __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const float* __restrict__ A, int lda, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const int qd = id >> 3;
     const int tile_m = (qd / tiles_n) * 8 + xcd;
     const int tile_n = qd % tiles_n;
-    const int m0 = tile_m * TM;
+    const int m0 = tile_m * (EPI == 3 ? TM / 3 : TM);  // EPI 3: M counts atoms, a tile holds TM/3 of them
     const int n0 = tile_n * TN;
     if (m0 >= M) return;
 
@@ -77,6 +82,10 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
         const int row = f >> 3, kq = f & 7;
+        if constexpr (EPI == 3) {  // LDS row = (wave row)*96 + component*32 + atom
+            const int atom = m0 + (row / 96) * 32 + (row & 31), ax = (row % 96) >> 5;
+            a_ptr[i] = A + ((size_t)min(atom, M - 1) * 3 + ax) * lda + kq * 4;
+        } else
         a_ptr[i] = A + (size_t)min(m0 + row, M - 1) * lda + kq * 4;
         a_off[i] = row * HLD + kq * 4;
     }
@@ -218,12 +227,72 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 }
             }
         }
+    } else if constexpr (EPI == 3) {
+        static_assert(EPI != 3 || (NJ == 2 && MI == 3), "vec_proj epilogue: 3 components x (v1, v2)");
+        const int q = lane & 31;
+        const int g = (n0 + wn) / 64;
+        const int H = ep.H;
+        const float inv_sqrt_h = 1.0f / sqrtf((float)H);
+        __syncthreads();  // all waves are done reading the operand tiles
+        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][100] floats
+        const int a0 = m0 + (wave >> 1) * 32;                    // first atom of this wave
+        float dv[16], nv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float d = 0.f, qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float v1 = acc[i][0][r] * isc, v2 = acc[i][1][r] * isc;
+                d += v1 * v2;
+                qq += v2 * v2;
+                T[lr * 100 + i * 32 + q] = v1;
+            }
+            dv[r] = d * inv_sqrt_h;
+            nv[r] = sqrtf(qq + 1e-8f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = lane + 64 * it;
+            const int lr = item >> 3, c4 = item & 7;
+            const int n = a0 + lr;
+            if (n < M) {
+                float* vo = ep.v1 + (size_t)n * 3 * H + 32 * g + 4 * c4;
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax)
+                    *reinterpret_cast<float4*>(vo + ax * H) = *reinterpret_cast<const float4*>(T + lr * 100 + ax * 32 + 4 * c4);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            T[lr * 100 + q] = dv[r];
+            T[lr * 100 + 32 + q] = nv[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = lane + 64 * it;
+            const int lr = item >> 3, c4 = item & 7;
+            const int n = a0 + lr;
+            if (n < M) {
+                const int c = 32 * g + 4 * c4;
+                *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
+                float* cr = ep.cat + (size_t)n * 2 * H + c;   // xvec_proj input: [x | |v2|]
+                *reinterpret_cast<float4*>(cr) = *reinterpret_cast<const float4*>(ep.x + (size_t)n * H + c);
+                *reinterpret_cast<float4*>(cr + H) = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
+            }
+        }
     } else {
         // Columns of this wave: parts 0,1,2 of the 32 channels of group g.  The accumulators (lane =
         // channel, 16 rows) are transposed through the wave's share of the now idle staging LDS so
         // that every lane then owns 4 consecutive channels of one row: 16-B global accesses, 8 rows x
         // 128 B per wave instruction instead of 2 rows x 128 B.
-        static_assert(NJ == 3 && MI == 2, "fused epilogues are written for the 64 x 96 wave tile");
+        static_assert(EPI == 3 || (NJ == 3 && MI == 2), "fused epilogues are written for the 64 x 96 wave tile");
         const int q = lane & 31;
         const int g = (n0 + wn) / 96;
         const int H = ep.H;
@@ -283,10 +352,10 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                         xv.w = (xv.w + (p0.w + p1.w * d.w) * k2) * sc;
                         *reinterpret_cast<float4*>(ep.x + xo) = xv;
                         float* vr = ep.vec + (size_t)n * 3 * H + c;
-                        const float* v1p = ep.vv + (size_t)n * 6 * H + c;
+                        const float* v1p = ep.vv + (size_t)n * 3 * H + c;  // v1 [N,3,H] written by EPI 3
 #pragma unroll
                         for (int ax = 0; ax < 3; ++ax) {
-                            const float4 v1 = *reinterpret_cast<const float4*>(v1p + ax * 2 * H);
+                            const float4 v1 = *reinterpret_cast<const float4*>(v1p + ax * H);
                             float4 t = *reinterpret_cast<const float4*>(vr + ax * H);
                             t.x += p2.x * v1.x; t.y += p2.y * v1.y; t.z += p2.z * v1.z; t.w += p2.w * v1.w;
                             *reinterpret_cast<float4*>(vr + ax * H) = t;
@@ -309,10 +378,10 @@ __global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsi
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));  // non-negative floats order like uints
 }
 
-// perm_H > 0: the matrix is [3*perm_H, K]; output row g*96 + part*32 + q takes input row part*perm_H + 32g + q
+// perm_H > 0: the matrix is [parts*perm_H, K]; output row g*32*parts + part*32 + q takes input row part*perm_H + 32g + q
 __global__ void adf_split_kernel(const float* __restrict__ w, long long n, const unsigned int* absmax_bits,
                                  _Float16* __restrict__ hi, _Float16* __restrict__ lo, float* inv_scale, int perm_H,
-                                 int K, const float* __restrict__ bias, float* __restrict__ bias_perm) {
+                                 int K, const float* __restrict__ bias, float* __restrict__ bias_perm, int parts) {
     const float amax = __uint_as_float(*absmax_bits);
     // scale = 2^(9 - floor(log2(amax)))  ->  |w*scale| in [2^9, 2^10)
     int e = 0;
@@ -324,7 +393,8 @@ __global__ void adf_split_kernel(const float* __restrict__ w, long long n, const
         if (perm_H > 0) {
             const long long prow = i / K;
             const int k = (int)(i - prow * K);
-            const int g = (int)(prow / 96), part = (int)((prow % 96) / 32), qq = (int)(prow % 32);
+            const int gw = 32 * parts;
+            const int g = (int)(prow / gw), part = (int)((prow % gw) / 32), qq = (int)(prow % 32);
             const long long orow = (long long)part * perm_H + 32 * g + qq;
             src = orow * K + k;
             if (k == 0 && bias_perm) bias_perm[prow] = bias ? bias[orow] : 0.f;
@@ -337,11 +407,11 @@ __global__ void adf_split_kernel(const float* __restrict__ w, long long n, const
 }
 
 int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
-                         int perm_H, int K, const float* bias) {
+                         int perm_H, int K, const float* bias, int parts) {
     ADF_HIP_CHECK(hipMemsetAsync(scratch_bits, 0, sizeof(unsigned int), s));
     hipLaunchKernelGGL(adf_absmax_kernel, dim3(64), dim3(256), 0, s, w, n, scratch_bits);
     hipLaunchKernelGGL(adf_split_kernel, dim3(64), dim3(256), 0, s, w, n, scratch_bits, (_Float16*)out->hi,
-                       (_Float16*)out->lo, out->inv_scale, perm_H, K, bias, out->bias_perm);
+                       (_Float16*)out->lo, out->inv_scale, perm_H, K, bias, out->bias_perm, parts);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
@@ -376,7 +446,7 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
 int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
                                 const adf_epi* ep, hipStream_t s) {
     if (M <= 0) return ADF_OK;
-    if (K % HK != 0 || (lda & 3) || H % 64 != 0 || !W->bias_perm) {
+    if (K % HK != 0 || (lda & 3) || H % 64 != 0 || (epi != 3 && !W->bias_perm)) {
         adf_set_error("gemm16_fused: bad shape");
         return ADF_EINVAL;
     }
@@ -385,6 +455,14 @@ int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M
     const int tiles_m = (M + TM - 1) / TM;
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
+    if (epi == 3) {  // vec_proj: A = vec [N,3,H], weights [2H, K] permuted in (v1, v2) pairs; M = atoms
+        const int tn = 2 * H / 128, tm8 = ((M + 63) / 64 + 7) / 8 * 8;
+        hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 3>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
+                           (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, (const float*)nullptr,
+                           (float*)nullptr, 0, M, 2 * H, K, tn, *ep);
+        ADF_HIP_CHECK(hipGetLastError());
+        return ADF_OK;
+    }
     if (epi == 1)
         hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 2, 3, 1>), grid, dim3(256), 0, s, A, lda, (const _Float16*)W->hi,
                            (const _Float16*)W->lo, W->inv_scale, W->bias_perm, (float*)nullptr, 0, M, N, K, tiles_n, *ep);
