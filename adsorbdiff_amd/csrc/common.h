@@ -137,6 +137,8 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
                           int N, int K, int act_ssilu, hipStream_t s);
 int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
                          int perm_H = 0, int K = 0, const float* bias = nullptr, int parts = 3);
+int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, const float* x, float* cat, int M, int N,
+                                  int K, hipStream_t s);
 int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
                                 const adf_epi* ep, hipStream_t s);
 // C = act(A . W^T + b): f16x3 split MFMA by default, exact-f32 MFMA when h->gemm_f32 (ADF_GEMM=f32)

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const int qd = id >> 3;
     const int tile_m = (qd / tiles_n) * 8 + xcd;
     const int tile_n = qd % tiles_n;
-    const int m0 = tile_m * (EPI == 3 ? TM / 3 : TM);  // EPI 3: M counts atoms, a tile holds TM/3 of them
+    const int m0 = tile_m * (EPI >= 3 ? TM / 3 : TM);  // EPI 3, 4: M counts atoms, a tile holds TM/3 of them
     const int n0 = tile_n * TN;
     if (m0 >= M) return;
 
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
         const int row = f >> 3, kq = f & 7;
-        if constexpr (EPI == 3) {  // LDS row = (wave row)*96 + component*32 + atom
+        if constexpr (EPI >= 3) {  // LDS row = (wave row)*96 + component*32 + atom
             const int atom = m0 + (row / 96) * 32 + (row & 31), ax = (row % 96) >> 5;
             a_ptr[i] = A + ((size_t)min(atom, M - 1) * 3 + ax) * lda + kq * 4;
         } else
@@ -287,12 +287,44 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 *reinterpret_cast<float4*>(cr + H) = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
             }
         }
+    } else if constexpr (EPI == 4) {
+        // GatedEquivariantBlock.vec1_proj (painn_denoising.py:687-692): only ||W1 v||_xyz is used downstream, so the
+        // three component blocks are reduced on the accumulators and the [3N, C] product never goes to HBM.
+        // Output: cat [M, 2N] = [x | norm], x [M, N] copied alongside.
+        static_assert(EPI != 4 || (NJ == 2 && MI == 3), "norm epilogue: 3 components x 64 columns per wave");
+        const int q = lane & 31;
+        const int cb = n0 + wn;
+        __syncthreads();  // all waves are done reading the operand tiles
+        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][68] floats used
+        const int a0 = m0 + (wave >> 1) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float a = acc[0][j][r] * isc, b = acc[1][j][r] * isc, d = acc[2][j][r] * isc;
+                T[lr * 68 + j * 32 + q] = sqrtf(a * a + b * b + d * d);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = lane + 64 * it;
+            const int lr = item >> 4, c4 = item & 15;
+            const int n = a0 + lr, c = cb + 4 * c4;
+            if (n < M && c < N) {
+                float* cr = ep.cat + (size_t)n * 2 * N + c;
+                *reinterpret_cast<float4*>(cr) = *reinterpret_cast<const float4*>(ep.x + (size_t)n * N + c);
+                *reinterpret_cast<float4*>(cr + N) = *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
+            }
+        }
     } else {
         // Columns of this wave: parts 0,1,2 of the 32 channels of group g.  The accumulators (lane =
         // channel, 16 rows) are transposed through the wave's share of the now idle staging LDS so
         // that every lane then owns 4 consecutive channels of one row: 16-B global accesses, 8 rows x
         // 128 B per wave instruction instead of 2 rows x 128 B.
-        static_assert(EPI == 3 || (NJ == 3 && MI == 2), "fused epilogues are written for the 64 x 96 wave tile");
+        static_assert(EPI >= 3 || (NJ == 3 && MI == 2), "fused epilogues are written for the 64 x 96 wave tile");
         const int q = lane & 31;
         const int g = (n0 + wn) / 96;
         const int H = ep.H;
@@ -438,6 +470,21 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     if (mi == 4) { if (act_ssilu) LAUNCH16(1, 4); else LAUNCH16(0, 4); }
     else { if (act_ssilu) LAUNCH16(1, 2); else LAUNCH16(0, 2); }
 #undef LAUNCH16
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ||W v||_xyz of a [M,3,K] vector field into cat [M, 2N] = [x | norm]  (EPI 4; N % 4 == 0)
+int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, const float* x, float* cat, int M, int N,
+                                  int K, hipStream_t s) {
+    if (M <= 0) return ADF_OK;
+    if (K % HK != 0 || (lda & 3) || (N & 3)) { adf_set_error("gemm16_vecnorm: bad shape"); return ADF_EINVAL; }
+    adf_epi ep = {};
+    ep.x = const_cast<float*>(x); ep.cat = cat;
+    const int tn = (N + 127) / 128, tm8 = ((M + 63) / 64 + 7) / 8 * 8;
+    hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 4>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
+                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, (const float*)nullptr,
+                       (float*)nullptr, 0, M, N, K, tn, ep);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
