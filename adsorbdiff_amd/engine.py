@@ -306,6 +306,13 @@ class PaiNNEngine:
         out["message_ksteps"] = int(ksteps.value)
         return out
 
+    def measure_peaks(self):
+        """On-box peaks for the roofline fractions: HBM stream copy (GB/s), f16 and f32 MFMA (TFLOP/s)."""
+        out = (C.c_float * 3)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.adf_measure_peaks(out, self._stream()))
+        return {"hbm_copy_gbps": float(out[0]), "mfma_f16_tflops": float(out[1]), "mfma_f32_tflops": float(out[2])}
+
     def close(self) -> None:
         if getattr(self, "handle", None) is not None and self.handle:
             with torch.cuda.device(self.device):

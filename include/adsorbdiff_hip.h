@@ -218,6 +218,11 @@ int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream);
 int32_t adf_profile_enable(adf_painn_t h, int32_t on);
 int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, int64_t* message_ksteps, void* stream);
 
+/* On-box peaks for the roofline fractions: out_host3[0] = HBM stream copy GB/s (read + write bytes of a
+ * 1 GiB -> 1 GiB copy), [1] = v_mfma_f32_32x32x16_f16 TFLOP/s, [2] = v_mfma_f32_32x32x2_f32 TFLOP/s, both from a
+ * register-resident loop on every CU with non-zero operands.  Measurement aid of bench.py, not on the sampling path. */
+int32_t adf_measure_peaks(float* out_host3, void* stream);
+
 const char* adf_last_error(void);
 const char* adf_version(void);
 
