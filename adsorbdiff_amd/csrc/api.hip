@@ -166,6 +166,9 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     free_workspaces(h);
     if (h->rbf_pack) (void)hipFree(h->rbf_pack);
     if (h->rbf_bias_pack) (void)hipFree(h->rbf_bias_pack);
+    if (h->sub_x) (void)hipFree(h->sub_x);
+    if (h->sub_vec) (void)hipFree(h->sub_vec);
+    if (h->sub_f) (void)hipFree(h->sub_f);
     if (h->rbf_pack16) (void)hipFree(h->rbf_pack16);
     if (h->rbf_bias_pack16) (void)hipFree(h->rbf_bias_pack16);
     if (h->rbf_scales) (void)hipFree(h->rbf_scales);
@@ -402,8 +405,10 @@ static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
     return ADF_OK;
 }
 
+// tlist != null: only the listed targets are evaluated and x_out / vec_out are compact [n_targets, ...] rows
 static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const float* vec, float* x_out,
-                             float* vec_out, bool vec_is_zero, hipStream_t s) {
+                             float* vec_out, bool vec_is_zero, hipStream_t s, const int32_t* tlist = nullptr,
+                             int n_targets = 0) {
     const int H = h->hp.hidden_channels;
     const adf_layer_weights& w = h->layer[l];
     // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
@@ -420,7 +425,7 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
     }
     adf_prof_end(h, s);
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
-    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s);
+    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets);
     adf_prof_end(h, s);
     return st;
 }
@@ -472,7 +477,27 @@ extern "C" int32_t adf_painn_update_layer(adf_painn_t h, int32_t layer, int32_t 
     return update_layer(h, layer, N, x, vec, (hipStream_t)stream);
 }
 
+__global__ void adf_scatter_rows3_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int n,
+                                         float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * n) dst[(size_t)idx[i / 3] * 3 + i % 3] = src[i];
+}
+
+static int32_t forward_impl(adf_painn_t h, const adf_batch* b, const int32_t* out_idx, int32_t n_out, float* f1,
+                            float* f2, void* stream);
+
 extern "C" int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f1, float* f2, void* stream) {
+    return forward_impl(h, b, nullptr, 0, f1, f2, stream);
+}
+
+extern "C" int32_t adf_painn_forward_subset(adf_painn_t h, const adf_batch* b, const int32_t* out_idx, int32_t n_out,
+                                            float* f1, float* f2, void* stream) {
+    if (!out_idx || n_out < 0) { adf_set_error("forward_subset: null index list"); return ADF_EINVAL; }
+    return forward_impl(h, b, out_idx, n_out, f1, f2, stream);
+}
+
+static int32_t forward_impl(adf_painn_t h, const adf_batch* b, const int32_t* out_idx, int32_t n_out, float* f1,
+                            float* f2, void* stream) {
     ADF_TRY(check_batch(h, b));
     if (!h->weights_set) { adf_set_error("weights not set"); return ADF_EINVAL; }
     if (!b->atomic_numbers || !f1 || (h->hp.num_heads == 2 && !f2)) { adf_set_error("null argument"); return ADF_EINVAL; }
@@ -486,14 +511,49 @@ extern "C" int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f
     ADF_TRY(adf_nodewise_embed(h, b->atomic_numbers, N, h->x, s));  // vec = 0 is implicit in layer 0
     float* vin = h->vecA;
     float* vout = h->vecB;
-    for (int l = 0; l < h->hp.num_layers; ++l) {
+    const int L = h->hp.num_layers, H = h->hp.hidden_channels;
+    if (!out_idx) {
+        for (int l = 0; l < L; ++l) {
+            ADF_TRY(message_layer(h, l, N, h->x, vin, h->x, vout, l == 0, s));
+            ADF_TRY(update_layer(h, l, N, h->x, vout, s));
+            float* t = vin; vin = vout; vout = t;
+        }
+        adf_prof_begin(h, ADF_PROF_HEADS, s);
+        ADF_TRY(adf_head_forward(h, 0, N, h->x, vin, f1, s));
+        if (h->hp.num_heads == 2) ADF_TRY(adf_head_forward(h, 1, N, h->x, vin, f2, s));
+        adf_prof_end(h, s);
+        return ADF_OK;
+    }
+    // Outputs wanted on a subset only.  Every layer but the last is needed in full (the listed atoms' messages
+    // gather from all their neighbours); in the last layer only the listed atoms are message targets, and their
+    // update and the heads run on compact rows.  Per-row arithmetic is unchanged, so the listed rows of f1 / f2
+    // are bit-identical to adf_painn_forward's.
+    if (n_out == 0) return ADF_OK;
+    if (n_out > h->capS) {
+        const int64_t cap = (int64_t)n_out + n_out / 4 + 64;
+        if (h->sub_x) (void)hipFree(h->sub_x);
+        if (h->sub_vec) (void)hipFree(h->sub_vec);
+        if (h->sub_f) (void)hipFree(h->sub_f);
+        h->sub_x = h->sub_vec = h->sub_f = nullptr; h->capS = 0;
+        ADF_TRY(dev_alloc(&h->sub_x, (size_t)cap * H));
+        ADF_TRY(dev_alloc(&h->sub_vec, (size_t)cap * 3 * H));
+        ADF_TRY(dev_alloc(&h->sub_f, (size_t)cap * 3));
+        h->capS = cap;
+    }
+    for (int l = 0; l + 1 < L; ++l) {
         ADF_TRY(message_layer(h, l, N, h->x, vin, h->x, vout, l == 0, s));
         ADF_TRY(update_layer(h, l, N, h->x, vout, s));
         float* t = vin; vin = vout; vout = t;
     }
+    ADF_TRY(message_layer(h, L - 1, N, h->x, vin, h->sub_x, h->sub_vec, L == 1, s, out_idx, n_out));
+    ADF_TRY(update_layer(h, L - 1, n_out, h->sub_x, h->sub_vec, s));
     adf_prof_begin(h, ADF_PROF_HEADS, s);
-    ADF_TRY(adf_head_forward(h, 0, N, h->x, vin, f1, s));
-    if (h->hp.num_heads == 2) ADF_TRY(adf_head_forward(h, 1, N, h->x, vin, f2, s));
+    for (int hd = 0; hd < h->hp.num_heads; ++hd) {
+        ADF_TRY(adf_head_forward(h, hd, n_out, h->sub_x, h->sub_vec, h->sub_f, s));
+        hipLaunchKernelGGL(adf_scatter_rows3_kernel, dim3((3 * n_out + 255) / 256), dim3(256), 0, s, h->sub_f, out_idx,
+                           n_out, hd == 0 ? f1 : f2);
+    }
+    ADF_HIP_CHECK(hipGetLastError());
     adf_prof_end(h, s);
     return ADF_OK;
 }

@@ -113,6 +113,8 @@ struct adf_painn {
     int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}
     float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
     float* rec;          // [(N+1)][H/64][320] gather records of the message kernel (message.hip)
+    float *sub_x, *sub_vec, *sub_f;  // compact rows of adf_painn_forward_subset: [capS,H], [capS,3,H], [capS,3]
+    int64_t capS;
     float* sys;          // [B*16] per-system scratch of the stepper
     // last graph
     int64_t lastN, lastB;
@@ -150,7 +152,8 @@ static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, co
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
 size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
-                         float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s);
+                         float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s,
+                         const int32_t* tlist = nullptr, int n_targets = 0);
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
 int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s);
 int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s);

@@ -50,6 +50,8 @@ struct MsgParams {
     const float* x;
     float* x_out;
     float* vec_out;
+    const int32_t* tlist;    // optional: targets to evaluate (ascending atom indices); outputs are then compact rows
+    int items;               // number of targets: N, or the length of tlist
     const int32_t* nptr;
     const int32_t* e_src;
     const float4* e_geom;
@@ -151,15 +153,16 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     // block's edge records (and, one target ahead, the next target's CSR bounds and residual rows)
     // are requested before the current block is processed, so a block exposes no dependent
     // HBM/L2 round trip of its own.
-    auto fetch_target = [&](int& n_out) -> bool {
+    // n_out = target atom (CSR row, residual row); o_out = output row (= n_out unless a target list is given)
+    auto fetch_target = [&](int& n_out, int& o_out) -> bool {
         while (true) {
             int t = 0;
             if (lane == 0) t = atomicAdd(Ctr, 1);
             t = __builtin_amdgcn_readfirstlane(t);
             const int g = worker + (t >> 5) * nworkers;
             if (g >= p.G) return false;
-            const int n = g * ADF_GROUP_NODES + (t & 31);
-            if (n < p.N) { n_out = n; return true; }
+            const int e = g * ADF_GROUP_NODES + (t & 31);
+            if (e < p.items) { o_out = e; n_out = p.tlist ? p.tlist[e] : e; return true; }
         }
     };
     auto load_block = [&](int eb, int e1, float4& geo, int& src, bool& valid) {
@@ -170,11 +173,11 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
         if (valid) { geo = p.e_geom[e]; src = p.e_src[e]; }
     };
 
-    int n = 0, eb = 0, e1 = 0;           // current block
-    bool have = fetch_target(n);
+    int n = 0, orow = 0, eb = 0, e1 = 0;  // current block
+    bool have = fetch_target(n, orow);
     if (have) { eb = p.nptr[n]; e1 = p.nptr[n + 1]; }
-    int nN = 0, e0N = 0, e1N = 0;        // next target (bounds requested one target ahead)
-    bool haveN = have && fetch_target(nN);
+    int nN = 0, oN = 0, e0N = 0, e1N = 0;  // next target (bounds requested one target ahead)
+    bool haveN = have && fetch_target(nN, oN);
     if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
     float4 geo; int src; bool valid;
     if (have) load_block(eb, e1, geo, src, valid);
@@ -363,8 +366,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                 sb0 += __shfl_xor(sb0, 32); sb1 += __shfl_xor(sb1, 32);
                 sc0 += __shfl_xor(sc0, 32); sc1 += __shfl_xor(sc1, 32);
                 // lane q owns channels c0+q and c0+32+q; half-wave 0 writes x and vec_x, half-wave 1 vec_y, vec_z
-                const size_t xo = (size_t)n * H + c0 + q;
-                const size_t vo = (size_t)n * 3 * H + c0 + q;
+                const size_t xo = (size_t)orow * H + c0 + q;
+                const size_t vo = (size_t)orow * 3 * H + c0 + q;
                 if (hi == 0) {
                     p.x_out[xo] = (res0 + sx0) * inv_sqrt2;
                     p.x_out[xo + 32] = (res1 + sx1) * inv_sqrt2;
@@ -381,10 +384,10 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                 res0 = res1 = res2 = res3 = 0.f;
                 // ---- advance to the next target and request the bounds of the one after it
                 have = haveN;
-                n = nN; eb = e0N; e1 = e1N;
+                n = nN; orow = oN; eb = e0N; e1 = e1N;
                 first = true;
                 if (have) {
-                    haveN = fetch_target(nN);
+                    haveN = fetch_target(nN, oN);
                     if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
                 }
             } else {
@@ -522,7 +525,8 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
 }
 
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
-                         float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s) {
+                         float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s, const int32_t* tlist,
+                         int n_targets) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
     if ((unsigned long long)(N + 1) * 5ull * H * sizeof(float) >= (1ull << 32)) {
         adf_set_error("message kernel uses 32-bit byte offsets into the node tables: N=%d is too large, split the batch", N);
@@ -539,7 +543,9 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     p.inv_scale = h->rbf_scales + layer;
     p.mu = h->rbf_offset;
     p.N = N; p.H = H; p.R = R;
-    p.G = (N + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
+    p.tlist = tlist; p.items = tlist ? n_targets : N;
+    if (p.items <= 0) return ADF_OK;
+    p.G = (p.items + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
     p.inv_cutoff = 1.0f / h->hp.cutoff;
     const double step = 1.0 / (R - 1);
     p.coeff = (float)(-0.5 / (step * step));

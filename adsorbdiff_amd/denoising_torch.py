@@ -16,6 +16,9 @@ Extensions (all optional, defaults reproduce the reference):
   * ``denoising_pos_params["early_stop"]`` (default True): ``False`` disables the allclose
     early stop so that exactly ``num_steps`` steps run (used by bench.py).
   * ``denoising_pos_params["use_graph"]`` (default False): replay one captured hipGraph per step.
+  * ``denoising_pos_params["scores_on_adsorbate_only"]`` (default False): the update only ever reads the
+    model output on tag-2 atoms (reference :263-268, :460-467), so the last layer and the heads can be
+    evaluated for those atoms alone (``adf_painn_forward_subset``).  Sampled positions are bit-identical.
   * ``traj_dir=None`` is allowed (the reference crashes in ``write``); with a ``traj_dir`` the
     frames are kept on the device during the loop and written once at the end.
 """
@@ -168,8 +171,11 @@ class Denoiser:
             # from here on only the adsorbate (tag 2) moves: the graph builder may cache the slab-slab part
             eng.set_moving_atoms(prep, prep.tags == 2)
 
-            f1 = torch.empty(N, 3, dtype=torch.float32, device=dev)
-            f2 = torch.empty(N, 3, dtype=torch.float32, device=dev)
+            f1 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+            f2 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+            out_idx = None
+            if params.get("scores_on_adsorbate_only", False):
+                out_idx = torch.nonzero(prep.tags == 2).reshape(-1).to(torch.int32).contiguous()
             state = torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
             frames = [] if self.traj_dir else None
             check_every = 1 if B <= 8 else 5
@@ -187,7 +193,7 @@ class Denoiser:
             graph = None
 
             def one_step():
-                eng.forward_prepared(prep, pos, f1, f2)
+                eng.forward_prepared(prep, pos, f1, f2, out_idx)
                 eng.sde_step_scheduled(prep, pos, f1, f2, coefs_dev, T, state, z_tr, z_rot, early_stop_count=early)
 
             for t_idx in range(T):

@@ -187,12 +187,21 @@ class PaiNNEngine:
         _lib.check(self.lib.adf_graph_set_moving(self.handle, mask.data_ptr(), idx.data_ptr(), off.data_ptr()))
 
     # ------------------------------------------------------------------ calls
-    def forward_prepared(self, prep: PreparedBatch, pos: torch.Tensor, f1: torch.Tensor, f2: Optional[torch.Tensor]) -> None:
-        """Enqueue one forward; no host synchronisation."""
+    def forward_prepared(self, prep: PreparedBatch, pos: torch.Tensor, f1: torch.Tensor, f2: Optional[torch.Tensor],
+                         out_idx: Optional[torch.Tensor] = None) -> None:
+        """Enqueue one forward; no host synchronisation.  ``out_idx`` (ascending int32 atom indices on the
+        device): evaluate the outputs of these atoms only — their rows of f1 / f2 are bit-identical to the full
+        forward's, the other rows are left untouched (``adf_painn_forward_subset``)."""
         desc = prep.desc(pos)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.adf_painn_forward(
-                self.handle, C.byref(desc), f1.data_ptr(), f2.data_ptr() if f2 is not None else None, self._stream()))
+            if out_idx is None:
+                _lib.check(self.lib.adf_painn_forward(
+                    self.handle, C.byref(desc), f1.data_ptr(), f2.data_ptr() if f2 is not None else None, self._stream()))
+            else:
+                assert out_idx.dtype == torch.int32 and out_idx.is_contiguous() and out_idx.device == pos.device
+                _lib.check(self.lib.adf_painn_forward_subset(
+                    self.handle, C.byref(desc), out_idx.data_ptr(), int(out_idx.numel()), f1.data_ptr(),
+                    f2.data_ptr() if f2 is not None else None, self._stream()))
 
     def check_flags(self) -> None:
         with torch.cuda.device(self.device):

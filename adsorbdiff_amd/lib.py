@@ -17,7 +17,7 @@ ADF_OK, ADF_EINVAL, ADF_EOOM, ADF_ENONEIGHBOR, ADF_EHIP, ADF_EOVERFLOW = 0, 1, 2
 EXPORTS = (
     "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_graph_set_moving",
     "adf_check_flags",
-    "adf_graph_export", "adf_painn_forward", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
+    "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_last_error", "adf_version",
 )
@@ -88,6 +88,7 @@ def load():
         "adf_check_flags": [vp, vp],
         "adf_graph_export": [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.POINTER(i64), vp],
         "adf_painn_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp],
+        "adf_painn_forward_subset": [vp, C.POINTER(BatchDesc), vp, i32, vp, vp, vp],
         "adf_painn_message_layer": [vp, i32, i32, vp, vp, vp, vp, vp],
         "adf_linear_forward": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
         "adf_painn_update_layer": [vp, i32, i32, vp, vp, vp],

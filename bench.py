@@ -138,10 +138,10 @@ def main():
                   ode=True, early_stop=False)
     eng = model.engine(dev)
 
-    def one_pass():
+    def one_pass(extra=None):
         b = batch0.clone()
         torch.manual_seed(0)
-        den = Denoiser(b, DiffTorchCalc(trainer), params, device=str(dev))
+        den = Denoiser(b, DiffTorchCalc(trainer), dict(params, **(extra or {})), device=str(dev))
         out = den.run()
         assert den.steps_applied == args.num_steps, den.steps_applied
         return gather_sites(out, world)
@@ -167,6 +167,21 @@ def main():
     prof = eng.profile_read()
     eng.profile_enable(False)
     counters = eng.counters()
+
+    # Secondary measurement, N = 1 only, never `value`: the same pass with the model outputs evaluated on the
+    # adsorbate atoms only (the stepper reads nothing else; sampled positions are bit-identical, checked here).
+    ads_only = None
+    if world == 1:
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        sites_ads = one_pass({"scores_on_adsorbate_only": True})
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        ads_only = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
+                    "identical_sites": bool(torch.equal(sites_ads, sites)),
+                    "note": "opt-in denoising_pos_params['scores_on_adsorbate_only']: last layer's message targets, its "
+                            "update and the heads evaluated for tag-2 atoms only (adf_painn_forward_subset); one pass, "
+                            "not part of `value`"}
 
     if rank == 0:
         assert sites.shape[0] == total_systems, (sites.shape, total_systems)
@@ -248,6 +263,7 @@ def main():
                         "pattern alone sustains ~28 TB/s) - see DESIGN.md 4.",
             },
             "measured_peaks": measured,
+            "scores_on_adsorbate_only": ads_only,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_sd, scale_factors, args.cpu_systems, args.cpu_steps, params)

@@ -136,6 +136,14 @@ int32_t adf_graph_export(adf_painn_t h, int32_t* nbr_count, int32_t* nbr_src, in
  * (f2 may be NULL when num_heads == 1). */
 int32_t adf_painn_forward(adf_painn_t h, const adf_batch* b, float* f1, float* f2, void* stream);
 
+/* The same forward when the caller reads the outputs of a subset of atoms only — the sampler: the per-system score
+ * is the mean over the adsorbate atoms (denoising_torch.py:263-268, 460-467), the slab rows of f1 / f2 are never
+ * read.  out_idx: n_out ascending atom indices (device int32).  All layers but the last run in full; the last
+ * layer's message targets, its update and the heads are evaluated for the listed atoms only.  Rows out_idx[*] of
+ * f1 / f2 are bit-identical to adf_painn_forward's; the other rows are NOT written. */
+int32_t adf_painn_forward_subset(adf_painn_t h, const adf_batch* b, const int32_t* out_idx, int32_t n_out, float* f1,
+                                 float* f2, void* stream);
+
 /* Unit-testable pieces of the forward on the handle's current graph
  * (PaiNNMessage.forward, painn_denoising.py:530-567, fused with the residual
  * of :443-445):  x_out = (x + dx)/sqrt2 [N,H],  vec_out = vec + dvec [N,3,H]. */

@@ -503,3 +503,54 @@ def test_static_atom_cache_gives_identical_graph(shape):
         eng.set_moving_atoms(prep, b.tags == 2)
         eng.build_graph(b)  # refill the cache from the reference positions
     eng.set_moving_atoms(None, None)
+
+
+def test_forward_subset_rows_are_bit_identical():
+    """adf_painn_forward_subset: the listed atoms' outputs equal the full forward's bit for bit (last layer and
+    heads evaluated on compact rows); the other rows are not written."""
+    b = make_batch(3, n_slab=60, n_ads=4, seed=17).to(DEV)
+    torch.manual_seed(3)
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=3, num_rbf=32, cutoff=6.0, max_neighbors=20,
+              so3_denoising=True, scale_file={f"upd_out_scalar_scale_{i}": 1.0 for i in range(3)}).to(DEV).eval()
+    eng = m.engine()
+    prep = eng.prepare(b)
+    N = b.pos.shape[0]
+    full1, full2 = torch.empty(N, 3, device=DEV), torch.empty(N, 3, device=DEV)
+    eng.forward_prepared(prep, b.pos, full1, full2)
+    idx = torch.nonzero(b.tags == 2).reshape(-1).to(torch.int32)
+    sub1, sub2 = torch.full((N, 3), 7.0, device=DEV), torch.full((N, 3), 7.0, device=DEV)
+    eng.forward_prepared(prep, b.pos, sub1, sub2, idx)
+    torch.cuda.synchronize()
+    sel = idx.long()
+    assert torch.equal(sub1[sel], full1[sel]) and torch.equal(sub2[sel], full2[sel])
+    rest = torch.ones(N, dtype=torch.bool, device=DEV)
+    rest[sel] = False
+    assert bool((sub1[rest] == 7.0).all()) and bool((sub2[rest] == 7.0).all())
+    # a scattered, non-adsorbate subset as well (single-layer model: the subset path starts at layer 0)
+    torch.manual_seed(4)
+    m1 = PaiNN(None, 50, 1, hidden_channels=128, num_layers=1, num_rbf=32, cutoff=6.0, max_neighbors=20,
+               so3_denoising=True, scale_file={"upd_out_scalar_scale_0": 1.0}).to(DEV).eval()
+    e1 = m1.engine()
+    p1 = e1.prepare(b)
+    e1.forward_prepared(p1, b.pos, full1, full2)
+    idx2 = torch.arange(1, N, 5, dtype=torch.int32, device=DEV)
+    e1.forward_prepared(p1, b.pos, sub1, sub2, idx2)
+    torch.cuda.synchronize()
+    assert torch.equal(sub1[idx2.long()], full1[idx2.long()]) and torch.equal(sub2[idx2.long()], full2[idx2.long()])
+
+
+def test_scores_on_adsorbate_only_gives_identical_samples():
+    """denoising_pos_params["scores_on_adsorbate_only"]: same sampled positions, bit for bit."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("stepper_ode8.npz")
+    tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
+    outs = []
+    for flag in (False, True):
+        b = batch_from_fixture(fx, pos_key="pos_in")
+        torch.manual_seed(int(fx["seed"]))
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), scores_on_adsorbate_only=flag), device=DEV)
+        outs.append(den.run().pos.clone())
+        assert den.steps_applied == 8
+    assert torch.equal(outs[0], outs[1])
