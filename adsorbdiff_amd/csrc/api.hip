@@ -621,6 +621,32 @@ extern "C" int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, flo
                            state, dcom, drot, stream);
 }
 
+// The whole reverse loop (denoising_torch.py:235-356) in one call: num_steps x (graph build + forward + step), all
+// on `stream`, no host round trip unless poll_every > 0 (then the frozen flag is read back every poll_every steps and
+// the loop ends early, exactly like the reference's `break`).
+extern "C" int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                              const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
+                              const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
+                              const int32_t* out_idx, int32_t n_out, float* f1, float* f2, void* stream) {
+    if (num_steps <= 0 || !f1 || !f2 || !state) { adf_set_error("sample: bad argument"); return ADF_EINVAL; }
+    if ((z_tr_all == nullptr) != (z_rot_all == nullptr)) { adf_set_error("sample: need both noise tables or none"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t zs = (size_t)b->num_systems * 3;
+    for (int t = 0; t < num_steps; ++t) {
+        ADF_TRY(forward_impl(h, b, out_idx, out_idx ? n_out : 0, f1, f2, stream));
+        ADF_TRY(sde_step_common(h, b, pos, tags, fixed, f1, f2, nullptr, coefs_dev, num_steps,
+                                z_tr_all ? z_tr_all + t * zs : nullptr, z_rot_all ? z_rot_all + t * zs : nullptr,
+                                early_stop_count, state, nullptr, nullptr, stream));
+        if (early_stop_count > 0 && poll_every > 0 && (t % poll_every) == poll_every - 1 && t + 1 < num_steps) {
+            int32_t frozen = 0;
+            ADF_HIP_CHECK(hipMemcpyAsync(&frozen, state + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            ADF_HIP_CHECK(hipStreamSynchronize(s));
+            if (frozen) break;
+        }
+    }
+    return ADF_OK;
+}
+
 extern "C" int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream) {
     if (!h || !out || h->lastN <= 0) { adf_set_error("no forward has run"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;

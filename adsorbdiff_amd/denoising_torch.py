@@ -5,8 +5,9 @@ adsorbdiff/relaxation/diffusers/denoising_torch.py:18-511): same class names, co
 signatures and ``run() -> batch`` contract (positions updated in place; ``batch.y`` /
 ``batch.force`` zeroed as the reference's ``write`` does, :470).
 
-What differs is where the work happens: the whole loop is device resident.  Per step the host
-only enqueues ``adf_painn_forward`` + ``adf_sde_step`` on the current HIP stream; the per-system
+What differs is where the work happens: the whole loop is device resident.  The host enqueues
+``adf_painn_forward`` + ``adf_sde_step`` per step on the current HIP stream — as one ``adf_sample`` call
+when nothing has to be handed to the host between steps; the per-system
 Python loop, the ``torch.linalg.solve``/``%``/``einsum`` wrap and the per-step device->host
 trajectory dump of the reference (:296-367) are replaced by two tiny kernels.  The cumulative
 early-stop counter lives on the device; once it fires, later steps are no-ops on the positions,
@@ -196,7 +197,20 @@ class Denoiser:
                 eng.forward_prepared(prep, pos, f1, f2, out_idx)
                 eng.sde_step_scheduled(prep, pos, f1, f2, coefs_dev, T, state, z_tr, z_rot, early_stop_count=early)
 
-            for t_idx in range(T):
+            # Nothing to hand to the host between steps (no per-step frames, no host noise hook, no graph replay):
+            # the whole loop is one library call (adf_sample), polling the early-stop flag every `check_every` steps.
+            fused_loop = (not use_graph) and self.noise_fn is None and (frames is None or not self.save_full)
+            if fused_loop:
+                zt = zr = None
+                if not ode:  # device generator, drawn in the reference's order (:274-289): z_tr then z_rot, per step
+                    zt = torch.empty(T, B, 3, dtype=torch.float32, device=dev)
+                    zr = torch.empty(T, B, 3, dtype=torch.float32, device=dev)
+                    for t_idx in range(T):
+                        zt[t_idx].normal_()
+                        zr[t_idx].normal_()
+                eng.sample(prep, pos, f1, f2, coefs_dev, T, state, zt, zr, early_stop_count=early,
+                           poll_every=check_every if early else 0, out_idx=out_idx)
+            for t_idx in range(0 if fused_loop else T):  # per-step path
                 if not ode:
                     if self.noise_fn is not None:
                         a, b_ = self.noise_fn(t_idx, B)
@@ -223,6 +237,8 @@ class Denoiser:
                 if early and (t_idx % check_every == check_every - 1):
                     if int(state[1].item()):
                         break
+            if frames is not None and not frames:
+                frames.append(pos.clone())
             eng.check_flags()
             st = state.tolist()
             self.steps_applied = st[3]

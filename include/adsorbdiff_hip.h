@@ -207,6 +207,18 @@ int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, float* pos, co
 
 /* Counters of the last adf_painn_forward: algorithmic bytes of the message
  * kernel, dense FLOPs, padded/real edge rows (bench.py roofline). */
+/* The whole reverse loop of Denoiser.reverse_sde_sampling_rot after the initial placement (denoising_torch.py:
+ * 235-356) in one call: num_steps x (adf_painn_forward[_subset] + adf_sde_step_scheduled), enqueued on `stream`.
+ * z_tr_all, z_rot_all: [num_steps][B][3] standard normals (SDE) or both NULL (ODE).  poll_every > 0 (and
+ * early_stop_count > 0): every poll_every steps the frozen flag state[1] is read back (one stream synchronisation)
+ * and the loop ends once it is set — the reference's `break`; 0 = never synchronise (steps after the stop are
+ * no-ops on pos).  out_idx / n_out: optional subset of atoms whose model outputs are evaluated (see
+ * adf_painn_forward_subset), NULL = all.  f1, f2: [N,3] work arrays (last step's outputs on return). */
+int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                   const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
+                   int32_t early_stop_count, int32_t poll_every, int32_t* state, const int32_t* out_idx,
+                   int32_t n_out, float* f1, float* f2, void* stream);
+
 typedef struct {
     int64_t num_edges;
     int64_t num_atoms;
