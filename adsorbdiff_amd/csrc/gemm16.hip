@@ -274,17 +274,23 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        {
+            const int c4 = lane & 7;
+            const int c = 32 * g + 4 * c4;
+            float4 xin[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int item = lane + 64 * it;
-            const int lr = item >> 3, c4 = item & 7;
-            const int n = a0 + lr;
-            if (n < M) {
-                const int c = 32 * g + 4 * c4;
-                *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
-                float* cr = ep.cat + (size_t)n * 2 * H + c;   // xvec_proj input: [x | |v2|]
-                *reinterpret_cast<float4*>(cr) = *reinterpret_cast<const float4*>(ep.x + (size_t)n * H + c);
-                *reinterpret_cast<float4*>(cr + H) = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
+            for (int it = 0; it < 4; ++it)
+                xin[it] = *reinterpret_cast<const float4*>(ep.x + (size_t)min(a0 + it * 8 + (lane >> 3), M - 1) * H + c);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int lr = it * 8 + (lane >> 3);
+                const int n = a0 + lr;
+                if (n < M) {
+                    *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
+                    float* cr = ep.cat + (size_t)n * 2 * H + c;   // xvec_proj input: [x | |v2|]
+                    *reinterpret_cast<float4*>(cr) = xin[it];
+                    *reinterpret_cast<float4*>(cr + H) = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
+                }
             }
         }
     } else if constexpr (EPI == 4) {
@@ -308,15 +314,22 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        {
+            const int c4 = lane & 15;
+            const int c = min(cb + 4 * c4, N - 4);
+            float4 xin[8];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int item = lane + 64 * it;
-            const int lr = item >> 4, c4 = item & 15;
-            const int n = a0 + lr, c = cb + 4 * c4;
-            if (n < M && c < N) {
-                float* cr = ep.cat + (size_t)n * 2 * N + c;
-                *reinterpret_cast<float4*>(cr) = *reinterpret_cast<const float4*>(ep.x + (size_t)n * N + c);
-                *reinterpret_cast<float4*>(cr + N) = *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
+            for (int it = 0; it < 8; ++it)
+                xin[it] = *reinterpret_cast<const float4*>(ep.x + (size_t)min(a0 + it * 4 + (lane >> 4), M - 1) * N + c);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lr = it * 4 + (lane >> 4);
+                const int n = a0 + lr;
+                if (n < M && cb + 4 * c4 < N) {
+                    float* cr = ep.cat + (size_t)n * 2 * N + c;
+                    *reinterpret_cast<float4*>(cr) = xin[it];
+                    *reinterpret_cast<float4*>(cr + N) = *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
+                }
             }
         }
     } else {
@@ -342,53 +355,85 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // The 4 items of a lane (row lr = it*8 + lane/8, channels 4*c4..) : every global load of the block is
+            // issued before the first store (rows clamped, stores predicated) — written item by item the stores,
+            // which may alias the next loads, turn the epilogue into 16 dependent HBM round trips per block.
+            const int c4 = lane & 7;
+            const int c = 32 * g + 4 * c4;
+            if constexpr (EPI == 1) {
+                float4 v0[4], v1[4], v2[4];
+                if (!ep.vec_is_zero) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int item = lane + 64 * it;
-                const int lr = item >> 3, c4 = item & 7;
-                const int n = m0 + wm + 32 * i + lr;
-                if (n < M) {
+                    for (int it = 0; it < 4; ++it) {
+                        const int n = min(m0 + wm + 32 * i + it * 8 + (lane >> 3), M - 1);
+                        const float* vr = ep.vec_in + (size_t)n * 3 * H + c;
+                        v0[it] = *reinterpret_cast<const float4*>(vr);
+                        v1[it] = *reinterpret_cast<const float4*>(vr + H);
+                        v2[it] = *reinterpret_cast<const float4*>(vr + 2 * H);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int lr = it * 8 + (lane >> 3);
+                    const int n = m0 + wm + 32 * i + lr;
                     const float4 p0 = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
                     const float4 p1 = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
                     const float4 p2 = *reinterpret_cast<const float4*>(T + lr * 100 + 64 + 4 * c4);
-                    const int c = 32 * g + 4 * c4;
-                    if constexpr (EPI == 1) {
+                    if (n < M) {
                         // half-record of (atom n, group g): [32 x (xa, xc, P0, P1)] then [32 x P2]
                         float* rec = ep.rec + ((size_t)n * (H / 32) + g) * 160;
                         float4* ra_ = reinterpret_cast<float4*>(rec + 16 * c4);
                         if (!ep.vec_is_zero) {
-                            const float* vr = ep.vec_in + (size_t)n * 3 * H + c;
-                            const float4 v0 = *reinterpret_cast<const float4*>(vr);
-                            const float4 v1 = *reinterpret_cast<const float4*>(vr + H);
-                            const float4 v2 = *reinterpret_cast<const float4*>(vr + 2 * H);
-                            ra_[0] = make_float4(p0.x, p2.x, v0.x * p1.x, v1.x * p1.x);
-                            ra_[1] = make_float4(p0.y, p2.y, v0.y * p1.y, v1.y * p1.y);
-                            ra_[2] = make_float4(p0.z, p2.z, v0.z * p1.z, v1.z * p1.z);
-                            ra_[3] = make_float4(p0.w, p2.w, v0.w * p1.w, v1.w * p1.w);
+                            ra_[0] = make_float4(p0.x, p2.x, v0[it].x * p1.x, v1[it].x * p1.x);
+                            ra_[1] = make_float4(p0.y, p2.y, v0[it].y * p1.y, v1[it].y * p1.y);
+                            ra_[2] = make_float4(p0.z, p2.z, v0[it].z * p1.z, v1[it].z * p1.z);
+                            ra_[3] = make_float4(p0.w, p2.w, v0[it].w * p1.w, v1[it].w * p1.w);
                             *reinterpret_cast<float4*>(rec + 128 + 4 * c4) =
-                                make_float4(v2.x * p1.x, v2.y * p1.y, v2.z * p1.z, v2.w * p1.w);
+                                make_float4(v2[it].x * p1.x, v2[it].y * p1.y, v2[it].z * p1.z, v2[it].w * p1.w);
                         } else {
                             ra_[0] = make_float4(p0.x, p2.x, 0.f, 0.f);
                             ra_[1] = make_float4(p0.y, p2.y, 0.f, 0.f);
                             ra_[2] = make_float4(p0.z, p2.z, 0.f, 0.f);
                             ra_[3] = make_float4(p0.w, p2.w, 0.f, 0.f);
                         }
-                    } else {
-                        const size_t xo = (size_t)n * H + c;
-                        const float4 d = *reinterpret_cast<const float4*>(ep.dot + xo);
-                        float4 xv = *reinterpret_cast<const float4*>(ep.x + xo);
-                        const float k2 = 0.70710678118654752f, sc = ep.scale;
-                        xv.x = (xv.x + (p0.x + p1.x * d.x) * k2) * sc;
-                        xv.y = (xv.y + (p0.y + p1.y * d.y) * k2) * sc;
-                        xv.z = (xv.z + (p0.z + p1.z * d.z) * k2) * sc;
-                        xv.w = (xv.w + (p0.w + p1.w * d.w) * k2) * sc;
-                        *reinterpret_cast<float4*>(ep.x + xo) = xv;
+                    }
+                }
+            } else {
+                float4 d[4], xv[4], w1[4][3], tv[4][3];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int n = min(m0 + wm + 32 * i + it * 8 + (lane >> 3), M - 1);
+                    const size_t xo = (size_t)n * H + c;
+                    d[it] = *reinterpret_cast<const float4*>(ep.dot + xo);
+                    xv[it] = *reinterpret_cast<const float4*>(ep.x + xo);
+                    const float* vr = ep.vec + (size_t)n * 3 * H + c;
+                    const float* v1p = ep.vv + (size_t)n * 3 * H + c;  // v1 [N,3,H] written by EPI 3
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        w1[it][ax] = *reinterpret_cast<const float4*>(v1p + ax * H);
+                        tv[it][ax] = *reinterpret_cast<const float4*>(vr + ax * H);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int lr = it * 8 + (lane >> 3);
+                    const int n = m0 + wm + 32 * i + lr;
+                    const float4 p0 = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
+                    const float4 p1 = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
+                    const float4 p2 = *reinterpret_cast<const float4*>(T + lr * 100 + 64 + 4 * c4);
+                    const float k2 = 0.70710678118654752f, sc = ep.scale;
+                    float4 xo4 = xv[it];
+                    xo4.x = (xo4.x + (p0.x + p1.x * d[it].x) * k2) * sc;
+                    xo4.y = (xo4.y + (p0.y + p1.y * d[it].y) * k2) * sc;
+                    xo4.z = (xo4.z + (p0.z + p1.z * d[it].z) * k2) * sc;
+                    xo4.w = (xo4.w + (p0.w + p1.w * d[it].w) * k2) * sc;
+                    if (n < M) {
+                        *reinterpret_cast<float4*>(ep.x + (size_t)n * H + c) = xo4;
                         float* vr = ep.vec + (size_t)n * 3 * H + c;
-                        const float* v1p = ep.vv + (size_t)n * 3 * H + c;  // v1 [N,3,H] written by EPI 3
 #pragma unroll
                         for (int ax = 0; ax < 3; ++ax) {
-                            const float4 v1 = *reinterpret_cast<const float4*>(v1p + ax * H);
-                            float4 t = *reinterpret_cast<const float4*>(vr + ax * H);
+                            float4 t = tv[it][ax];
+                            const float4 v1 = w1[it][ax];
                             t.x += p2.x * v1.x; t.y += p2.y * v1.y; t.z += p2.z * v1.z; t.w += p2.w * v1.w;
                             *reinterpret_cast<float4*>(vr + ax * H) = t;
                         }
