@@ -554,3 +554,24 @@ def test_scores_on_adsorbate_only_gives_identical_samples():
         outs.append(den.run().pos.clone())
         assert den.steps_applied == 8
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("ode", [True, False])
+def test_fused_loop_matches_per_step_loop(tmp_path, ode):
+    """adf_sample (whole loop in one call) vs the per-step host loop (taken when every frame is kept): identical
+    positions, ODE and SDE — the SDE noise is drawn from the device generator in the same order on both paths."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("stepper_ode8.npz")
+    tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
+    outs = []
+    for per_step in (False, True):
+        b = batch_from_fixture(fx, pos_key="pos_in")
+        torch.manual_seed(int(fx["seed"]))
+        torch.cuda.manual_seed(1234)
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), ode=ode, early_stop=False), device=DEV,
+                       traj_dir=(tmp_path / f"p{int(per_step)}") if per_step else None, traj_names=b.sid)
+        outs.append(den.run().pos.clone())
+        assert den.steps_applied == 8
+    assert torch.equal(outs[0], outs[1])
