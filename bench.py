@@ -251,11 +251,15 @@ def main():
                 "launches": msg_launches,
                 "flops_per_launch": issued_flops_per_launch,
                 "dense_equivalent_tflops": dense_equiv,
+                "algorithmic_f16x3_tflops": dense_equiv * products,
                 "l2_gather_tbps": gathered_bytes / avg_s / 1e12 if avg_s > 0 else 0.0,
                 "hbm_algorithmic_gbps": hbm_alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0,
                 "hbm_algorithmic_frac": (hbm_alg_bytes / avg_s / 1e9) / PEAK_HBM_GBS if avg_s > 0 else 0.0,
                 "note": "achieved = matrix-core flops the kernel issues (k-window x 32 x 192 x 2 per 32-edge row "
                         "block, padded rows and the 3 split products included) / launch time from HIP events on the "
+                        "launch stream. This is the conservative count: the algorithm's dense contraction (SURVEY 8d: "
+                        "2*R*3H*E per layer, x3 products in this arithmetic = algorithmic_f16x3_tflops) is ~1.9x larger, "
+                        "the k-window skips Gaussian terms below 2.3e-11. Timed on the "
                         "launch stream; measured_peak = the same MFMA instruction in a register-resident loop on this "
                         "box (non-zero operands). rbfh is never materialised, so neither SURVEY 8d roofline binds alone: "
                         "per 32-edge block the kernel issues ~600 VALU instructions (8 FMA per gathered channel-row) "
