@@ -166,6 +166,7 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     free_workspaces(h);
     if (h->rbf_pack) (void)hipFree(h->rbf_pack);
     if (h->rbf_bias_pack) (void)hipFree(h->rbf_bias_pack);
+    if (h->rec0) (void)hipFree(h->rec0);
     if (h->sub_x) (void)hipFree(h->sub_x);
     if (h->sub_vec) (void)hipFree(h->sub_vec);
     if (h->sub_f) (void)hipFree(h->sub_f);
@@ -257,6 +258,7 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
         }
     }
     h->weights_set = true;
+    h->rec0_valid = false;
     return ADF_OK;
 }
 
@@ -333,6 +335,7 @@ extern "C" int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, co
     if (moving && (!mov_idx || !mov_off)) { adf_set_error("moving mask needs mov_idx and mov_off"); return ADF_EINVAL; }
     h->moving = moving; h->mov_idx = mov_idx; h->mov_off = mov_off;
     h->cache_valid = false;
+    h->rec0_valid = false;
     return ADF_OK;
 }
 
@@ -406,26 +409,29 @@ static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
 }
 
 // tlist != null: only the listed targets are evaluated and x_out / vec_out are compact [n_targets, ...] rows
+// rec != null: gather records go to / come from this buffer instead of h->rec; records_ready: they are already there
 static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const float* vec, float* x_out,
                              float* vec_out, bool vec_is_zero, hipStream_t s, const int32_t* tlist = nullptr,
-                             int n_targets = 0) {
+                             int n_targets = 0, float* rec = nullptr, bool records_ready = false) {
     const int H = h->hp.hidden_channels;
     const adf_layer_weights& w = h->layer[l];
-    // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
-    adf_prof_begin(h, ADF_PROF_NODE, s);
-    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
-    ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, N, H, H, 1, s));
-    if (h->gemm_f32) {
-        ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
-        ADF_TRY(adf_pack_records(h, N, h->xh, vec, vec_is_zero, s));
-    } else {  // x_proj.2 with the gather records written from the accumulators (xh never materialised)
-        adf_epi ep = {};
-        ep.vec_in = vec; ep.rec = h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
-        ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, N, H, H, 1, &ep, s));
+    if (!records_ready) {
+        // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
+        adf_prof_begin(h, ADF_PROF_NODE, s);
+        ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
+        ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, N, H, H, 1, s));
+        if (h->gemm_f32) {
+            ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
+            ADF_TRY(adf_pack_records(h, N, h->xh, vec, vec_is_zero, s, rec));
+        } else {  // x_proj.2 with the gather records written from the accumulators (xh never materialised)
+            adf_epi ep = {};
+            ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
+            ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, N, H, H, 1, &ep, s));
+        }
+        adf_prof_end(h, s);
     }
-    adf_prof_end(h, s);
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
-    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets);
+    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec);
     adf_prof_end(h, s);
     return st;
 }
@@ -512,8 +518,26 @@ static int32_t forward_impl(adf_painn_t h, const adf_batch* b, const int32_t* ou
     float* vin = h->vecA;
     float* vout = h->vecB;
     const int L = h->hp.num_layers, H = h->hp.hidden_channels;
+    // layer-0 records: invariant while the static-atom promise holds (same batch and weights)
+    float* rec0 = nullptr;
+    bool rec0_ready = false;
+    if (h->moving) {
+        const size_t row = (size_t)5 * H;
+        if ((int64_t)N + 1 > h->rec0_cap) {
+            if (h->rec0) { (void)hipFree(h->rec0); h->rec0 = nullptr; }
+            h->rec0_cap = 0; h->rec0_valid = false;
+            ADF_TRY(dev_alloc(&h->rec0, ((size_t)N + 1) * row));
+            h->rec0_cap = (int64_t)N + 1;
+        }
+        rec0 = h->rec0;
+        rec0_ready = h->rec0_valid && h->rec0_N == N;
+        if (!rec0_ready) ADF_HIP_CHECK(hipMemsetAsync(rec0 + (size_t)N * row, 0, sizeof(float) * row, s));
+        h->rec0_valid = true; h->rec0_N = N;
+    }
     if (!out_idx) {
         for (int l = 0; l < L; ++l) {
+            if (l == 0) ADF_TRY(message_layer(h, 0, N, h->x, vin, h->x, vout, true, s, nullptr, 0, rec0, rec0_ready));
+            else
             ADF_TRY(message_layer(h, l, N, h->x, vin, h->x, vout, l == 0, s));
             ADF_TRY(update_layer(h, l, N, h->x, vout, s));
             float* t = vin; vin = vout; vout = t;
@@ -541,11 +565,14 @@ static int32_t forward_impl(adf_painn_t h, const adf_batch* b, const int32_t* ou
         h->capS = cap;
     }
     for (int l = 0; l + 1 < L; ++l) {
+        if (l == 0) ADF_TRY(message_layer(h, 0, N, h->x, vin, h->x, vout, true, s, nullptr, 0, rec0, rec0_ready));
+        else
         ADF_TRY(message_layer(h, l, N, h->x, vin, h->x, vout, l == 0, s));
         ADF_TRY(update_layer(h, l, N, h->x, vout, s));
         float* t = vin; vin = vout; vout = t;
     }
-    ADF_TRY(message_layer(h, L - 1, N, h->x, vin, h->sub_x, h->sub_vec, L == 1, s, out_idx, n_out));
+    ADF_TRY(message_layer(h, L - 1, N, h->x, vin, h->sub_x, h->sub_vec, L == 1, s, out_idx, n_out,
+                          L == 1 ? rec0 : nullptr, L == 1 && rec0_ready));
     ADF_TRY(update_layer(h, L - 1, n_out, h->sub_x, h->sub_vec, s));
     adf_prof_begin(h, ADF_PROF_HEADS, s);
     for (int hd = 0; hd < h->hp.num_heads; ++hd) {

@@ -113,6 +113,11 @@ struct adf_painn {
     int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}
     float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
     float* rec;          // [(N+1)][H/64][320] gather records of the message kernel (message.hip)
+    // Layer-0 gather records depend on the atomic numbers only (x0 = emb(Z), vec0 = 0).  While a static-atom
+    // promise is in force (adf_graph_set_moving: same batch, only flagged atoms move) they are computed once.
+    float* rec0;
+    int64_t rec0_cap, rec0_N;
+    bool rec0_valid;
     float *sub_x, *sub_vec, *sub_f;  // compact rows of adf_painn_forward_subset: [capS,H], [capS,3,H], [capS,3]
     int64_t capS;
     float* sys;          // [B*16] per-system scratch of the stepper
@@ -153,9 +158,10 @@ int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
 size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s,
-                         const int32_t* tlist = nullptr, int n_targets = 0);
+                         const int32_t* tlist = nullptr, int n_targets = 0, const float* rec = nullptr);
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
-int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s);
+int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s,
+                         float* rec = nullptr);
 int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s);
 int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s);
 int32_t adf_nodewise_update_prep(const float* vv, const float* x, float* cat, float* dot, int N, int H, hipStream_t s);

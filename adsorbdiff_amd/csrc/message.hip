@@ -479,11 +479,12 @@ __global__ void adf_pack_records_kernel(const float* __restrict__ xh, const floa
     }
 }
 
-int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s) {
+int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s,
+                         float* rec) {
     const int H = h->hp.hidden_channels;
     long long blocks = ((long long)N * H + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(adf_pack_records_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xh, vec, h->rec, N, H,
+    hipLaunchKernelGGL(adf_pack_records_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xh, vec, rec ? rec : h->rec, N, H,
                        vec_is_zero ? 1 : 0);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
@@ -526,14 +527,14 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
 
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s, const int32_t* tlist,
-                         int n_targets) {
+                         int n_targets, const float* rec) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
     if ((unsigned long long)(N + 1) * 5ull * H * sizeof(float) >= (1ull << 32)) {
         adf_set_error("message kernel uses 32-bit byte offsets into the node tables: N=%d is too large, split the batch", N);
         return ADF_EOOM;  // surfaces as RuntimeError -> ml_diffuse splits the batch
     }
     MsgParams p;
-    p.rec = h->rec; p.vec = vec; p.x = x; p.x_out = x_out; p.vec_out = vec_out;
+    p.rec = rec ? rec : h->rec; p.vec = vec; p.x = x; p.x_out = x_out; p.vec_out = vec_out;
     p.nptr = h->nptr; p.e_src = h->e_src; p.e_geom = h->e_geom;
     p.nslices = H / ADF_SLICE_CH;
     const bool f16 = !h->msg_f32;

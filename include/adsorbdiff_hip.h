@@ -114,7 +114,9 @@ int32_t adf_graph_build(adf_painn_t h, const adf_batch* b, void* stream, int64_t
  * into mov_idx; all caller-owned device arrays that must stay valid until reset.  The next build
  * evaluates everything and caches each static centre's K nearest static candidates; later builds
  * only re-evaluate candidates that involve a moving atom — results are identical to a full build.
- * Pass NULLs to switch the cache off (default).  Any call invalidates the cache. */
+ * While the promise is in force adf_painn_forward also keeps the layer-0 gather records across calls: they depend
+ * on the atomic numbers only (x0 = emb(Z), vec0 = 0), so the batch's atomic numbers and the weights must not change
+ * either (adf_painn_set_weights invalidates).  Pass NULLs to switch the cache off (default).  Any call invalidates. */
 int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, const int32_t* mov_idx, const int32_t* mov_off);
 
 /* Read the device-side error flags of the last graph build (candidate overflow,

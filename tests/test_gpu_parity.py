@@ -575,3 +575,31 @@ def test_fused_loop_matches_per_step_loop(tmp_path, ode):
         outs.append(den.run().pos.clone())
         assert den.steps_applied == 8
     assert torch.equal(outs[0], outs[1])
+
+
+def test_static_promise_forward_is_bit_identical():
+    """adf_graph_set_moving also lets the forward keep the layer-0 gather records (they depend on the atomic
+    numbers only): after the adsorbate moved, the outputs equal those of a forward without any promise."""
+    b = make_batch(3, n_slab=60, n_ads=4, seed=23).to(DEV)
+    torch.manual_seed(5)
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=2, num_rbf=32, cutoff=6.0, max_neighbors=20,
+              so3_denoising=True, scale_file={f"upd_out_scalar_scale_{i}": 1.0 for i in range(2)}).to(DEV).eval()
+    eng = m.engine()
+    prep = eng.prepare(b)
+    N = b.pos.shape[0]
+    g = torch.Generator().manual_seed(9)
+    ads = b.tags == 2
+    eng.set_moving_atoms(prep, ads)
+    pos = b.pos.clone()
+    cached = []
+    for trial in range(3):
+        f1, f2 = torch.empty(N, 3, device=DEV), torch.empty(N, 3, device=DEV)
+        eng.forward_prepared(prep, pos, f1, f2)
+        cached.append((pos.clone(), f1, f2))
+        pos = pos.clone()
+        pos[ads] = pos[ads] + (torch.rand(int(ads.sum()), 3, generator=g).to(DEV) - 0.5) * 2.0
+    eng.set_moving_atoms(None, None)
+    for p_, c1, c2 in cached:
+        f1, f2 = torch.empty(N, 3, device=DEV), torch.empty(N, 3, device=DEV)
+        eng.forward_prepared(prep, p_, f1, f2)
+        assert torch.equal(f1, c1) and torch.equal(f2, c2)
