@@ -13,11 +13,12 @@
 // while they are staged into LDS.  The exact-f32 kernel (gemm.hip) stays selectable
 // (ADF_GEMM=f32) and is what this kernel is tested against.
 //
-// Tiling: 256(M) x 256(N) x 32(K) per 256-thread workgroup, 4 waves as 2(M) x 2(N), each wave 128x128 =
-// 4x4 MFMA 32x32 accumulators.  LDS holds A_hi, A_lo [256][32+8] and W_hi, W_lo [256][32+8] halves
-// (row stride 80 B: the 16 lanes of a ds_read_b128 lane group land on 16 distinct 16-B bank quads).
+// Tiling (default): 128(M) x 256(N) x 32(K) per 256-thread workgroup, 4 waves as 2(M) x 2(N), each wave 64 x 128 =
+// 2 x 4 MFMA 32x32 accumulators, two workgroups per CU.  LDS holds A_hi, A_lo [128][32+8] and W_hi, W_lo [256][32+8]
+// halves (row stride 80 B: the 16 lanes of a ds_read_b128 lane group land on 16 distinct 16-B bank quads).
 // Global loads are 16 B per lane, prefetched one K-tile ahead in registers; XCD-aware tile map as in
-// gemm.hip (all N-tiles of an M-panel on one XCD's L2).
+// gemm.hip (all N-tiles of an M-panel on one XCD's L2).  Every epilogue transposes the accumulators through the
+// idle staging LDS so that global accesses are 16 B per lane, and issues all its loads before its first store.
 #include <stdlib.h>
 
 #include "common.h"

@@ -10,24 +10,25 @@
 // and gemnet_oc/layers/radial_basis.py:18-43,64-82,235-244 for edge_rbf = env(d/rc)*gauss_k(d/rc).
 //
 // MI355X mapping.  rbfh ([E,3H] fp32, 6 KB per edge) is never materialised: a persistent
-// 512-thread workgroup owns one 64-channel slice (3 x 64 = 192 columns of rbf_proj, k-major in
-// 96 KB of LDS).  Its 8 waves pull *target atoms* from an LDS work counter; one wave owns all
+// 512-thread workgroup owns one 64-channel slice (3 x 64 = 192 columns of rbf_proj, 104 KB of LDS
+// as fp16 hi/lo images, 96 KB k-major in exact-f32 mode).  Its 8 waves pull *target atoms* from an LDS work counter; one wave owns all
 // incoming edges of its target (CSR over targets, edges pre-sorted by distance), in 32-row blocks:
 //   1. the MFMA A operand is built in registers — lane (row, k) evaluates env(d_row)*exp(..) for its
-//      own k — and v_mfma_f32_32x32x2_f32 runs over 6 column blocks, but only over the k-window where
+//      own k — and the MFMA runs over 6 column blocks, but only over the k-window where
 //      some row's Gaussian is non-negligible: |k - (R-1) d/rc| <= 7 (dropped terms < exp(-24.5) =
 //      2.3e-11 of the leading term, far below f32 rounding).  Because a target's edges are sorted by
 //      distance, a 32-row block spans a narrow band and the 128-deep contraction shrinks to ~35;
 //   2. the 16 accumulator rows of each lane gather their source's packed record (xa, xc and
-//      P_i = vec_i * xb for the lane's channels c0+q and c0+32+q; 40 B per lane and row, contiguous
-//      per half-wave), served by the XCD's L2: slice = blockIdx % 8 = XCD under round-robin
+//      P_i = vec_i * xb for the lane's channels c0+q and c0+32+q; 40 B per lane and row as
+//      dwordx4 + dword pieces, each contiguous per half-wave), served by the XCD's L2: slice = blockIdx % 8 = XCD under round-robin
 //      dispatch, so one XCD only touches its own 64-channel columns of the record table;
 //   3. the messages are summed in registers (wavefront segmented sum: the 16 rows of a lane, then
 //      one cross-half shuffle), and x_out / vec_out rows are written once with the residual fused.
 // No LDS atomics (ds_add_f32 measured 4x slower than the whole rest of the kernel), no barriers
 // after the weight image is staged, no zero-initialised outputs.  HBM traffic per layer = record
-// table + residual rows once + 20 B per edge (vs 6 KB per edge if rbfh were materialised).  Measured
-// (PMC): VALU ~50 % busy, matrix pipe ~25 %, gathers ~10 TB/s out of L2 at a 93 % hit rate.
+// table + residual rows once + 20 B per edge (vs 6 KB per edge if rbfh were materialised).  Measured:
+// matrix pipe ~30 % of nominal (0.42 of the on-box MFMA peak), gathers ~15 TB/s out of L2 at a 93 % hit
+// rate; the contraction path and the gather path are about equally long and overlap.
 //
 // Two arithmetic modes for step 1, same structure otherwise:
 //   F16 = true  (default): f16x3 split (see gemm16.hip) — A = a_hi + a_lo generated in registers,
