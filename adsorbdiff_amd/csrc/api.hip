@@ -443,12 +443,14 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
     if (h->gemm_f32) {
         ADF_TRY(adf_launch_gemm(vec, H, w.vp_w, H, nullptr, h->vv, 2 * H, 3 * N, 2 * H, H, 0, s));
         ADF_TRY(adf_nodewise_update_prep(h->vv, x, h->cat, h->dot, N, H, s));
-    } else {  // vec_proj with dot / |v2| / [x | |v2|] formed on the accumulators; v1 -> vv [N,3,H]
+        ADF_TRY(adf_linear(h, h->cat, 2 * H, w.xv0_w, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
+    } else {  // vec_proj with dot and |v2| formed on the accumulators (v1 -> vv [N,3,H], |v2| -> cat [N,H]);
+              // xvec_proj.0 then reads its [x | |v2|] input from the two arrays
         adf_epi ep = {};
-        ep.x = x; ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H;
+        ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H;
         ADF_TRY(adf_launch_gemm16_fused(vec, H, &w.vp_16, N, H, H, 3, &ep, s));
+        ADF_TRY(adf_launch_gemm16(x, H, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H));
     }
-    ADF_TRY(adf_linear(h, h->cat, 2 * H, w.xv0_w, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s));
     int32_t st;
     if (h->gemm_f32) {
         ADF_TRY(adf_launch_gemm(h->y, H, w.xv2_w, H, w.xv2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));

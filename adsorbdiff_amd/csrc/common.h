@@ -49,10 +49,12 @@ struct adf_epi {
     const float* vv;      // EPI 2: v1 [N,3,H] (written by EPI 3)
     float* v1;            // EPI 3: v1 out [N,3,H]
     float* dotw;          // EPI 3: dot out [N,H]
-    float* cat;           // EPI 3: xvec_proj input [N,2H] = [x | |v2|]  (x copied from ep.x)
+    float* cat;           // EPI 3: |v2| [N,H] ; EPI 4: norm [M,N]
     float scale;          // EPI 2: ScaleFactor
     int H;
     int vec_is_zero;      // EPI 1
+    const float* A2;      // any EPI: second source of the A operand for columns [K1, K) (same row stride), K1 % 32 == 0
+    int K1;               // 0 = single source
 };
 struct adf_layer_weights {
     const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
@@ -141,11 +143,11 @@ void adf_prof_end(adf_painn* h, hipStream_t s);
 int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                         int M, int N, int K, int act_ssilu, hipStream_t s);
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
-                          int N, int K, int act_ssilu, hipStream_t s);
+                          int N, int K, int act_ssilu, hipStream_t s, const float* A2 = nullptr, int K1 = 0);
 int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
                          int perm_H = 0, int K = 0, const float* bias = nullptr, int parts = 3);
-int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, const float* x, float* cat, int M, int N,
-                                  int K, hipStream_t s);
+int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, float* nrm, int M, int N, int K,
+                                  hipStream_t s);
 int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
                                 const adf_epi* ep, hipStream_t s);
 // C = act(A . W^T + b): f16x3 split MFMA by default, exact-f32 MFMA when h->gemm_f32 (ADF_GEMM=f32)

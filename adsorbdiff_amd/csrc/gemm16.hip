@@ -46,8 +46,8 @@ __device__ __forceinline__ float ssilu16(float x) {
 //   MI=3, NJ=2 with EPI 3: vec_proj of PaiNNUpdate (painn_denoising.py:602-611).  The A rows of vec [N,3,H] are
 //   staged component-major (LDS row = component*32 + atom), so accumulator block i of a wave is component i of
 //   its 32 atoms; the two column blocks are v1 and v2 of the same 32 channels (weights row-permuted: column
-//   g*64 + part*32 + q  <->  row part*H + 32g + q).  dot = sum_xyz v1*v2 / sqrt(H) and |v2| are formed on the
-//   accumulators: v2 (1.2 GB per layer at N = 200k) never goes to HBM and the separate reduction pass is gone.
+//   g*64 + part*32 + q  <->  row part*H + 32g + q).  dot = sum_xyz v1*v2 / sqrt(H) and |v2| ([N,H] each) are formed
+//   on the accumulators: v2 (1.2 GB per layer at N = 200k) never goes to HBM and the separate reduction pass is gone.
 template <int ACT, int MI, int NJ, int EPI>
 __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const float* __restrict__ A, int lda, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
@@ -76,35 +76,43 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const int n0 = tile_n * TN;
     if (m0 >= M) return;
 
-    // A staging: NA float4 per thread (8 lanes per 128-B row segment, 32 rows per pass)
-    const float* a_ptr[NA];
+    // A staging: NA float4 per thread (8 lanes per 128-B row segment, 32 rows per pass).  Addresses are a
+    // wave-uniform base + a 32-bit byte offset per lane (the launchers check rows*lda*4 < 2^32), which also lets
+    // the K range be split over two sources of equal row stride: columns [0,K1) from A, [K1,K) from ep.A2
+    // (the [x | norm] inputs of the update / head MLPs are never concatenated in memory).
+    unsigned int a_goff[NA];
     int a_off[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
         const int row = f >> 3, kq = f & 7;
+        unsigned int grow;
         if constexpr (EPI >= 3) {  // LDS row = (wave row)*96 + component*32 + atom
             const int atom = m0 + (row / 96) * 32 + (row & 31), ax = (row % 96) >> 5;
-            a_ptr[i] = A + ((size_t)min(atom, M - 1) * 3 + ax) * lda + kq * 4;
-        } else
-        a_ptr[i] = A + (size_t)min(m0 + row, M - 1) * lda + kq * 4;
+            grow = (unsigned int)min(atom, M - 1) * 3u + ax;
+        } else {
+            grow = (unsigned int)min(m0 + row, M - 1);
+        }
+        a_goff[i] = (grow * (unsigned int)lda + kq * 4) * 4u;
         a_off[i] = row * HLD + kq * 4;
     }
+    const char* const A1b = reinterpret_cast<const char*>(A);
+    const char* const A2b = reinterpret_cast<const char*>(ep.A2) - (size_t)ep.K1 * 4;
     // W staging: NJ pieces of 16 B (8 halves) of hi and of lo per thread (4 lanes per 64-B row)
-    size_t w_src[NJ];
+    int w_src[NJ];
     int w_off[NJ];
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         const int f = tid + 256 * i;
         const int row = f >> 2, part = f & 3;
-        w_src[i] = (size_t)min(n0 + row, N - 1) * K + part * 8;
+        w_src[i] = min(n0 + row, N - 1) * K + part * 8;
         w_off[i] = row * HLD + part * 8;
     }
 
     float4 ra[NA];
     half8 rwh[NJ], rwl[NJ];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(A1b + a_goff[i]);
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i]);
@@ -140,12 +148,14 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         }
         __syncthreads();
         if (kt + 1 < nk) {
+            const int k1 = (kt + 1) * HK;
+            const char* ab = ((ep.K1 > 0 && k1 >= ep.K1) ? A2b : A1b) + (size_t)k1 * 4;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + (size_t)(kt + 1) * HK);
+            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ab + a_goff[i]);
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
-                rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + (size_t)(kt + 1) * HK);
-                rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + (size_t)(kt + 1) * HK);
+                rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + k1);
+                rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + k1);
             }
         }
 #pragma unroll
@@ -275,29 +285,19 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        {
-            const int c4 = lane & 7;
-            const int c = 32 * g + 4 * c4;
-            float4 xin[4];
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
-                xin[it] = *reinterpret_cast<const float4*>(ep.x + (size_t)min(a0 + it * 8 + (lane >> 3), M - 1) * H + c);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int lr = it * 8 + (lane >> 3);
-                const int n = a0 + lr;
-                if (n < M) {
-                    *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
-                    float* cr = ep.cat + (size_t)n * 2 * H + c;   // xvec_proj input: [x | |v2|]
-                    *reinterpret_cast<float4*>(cr) = xin[it];
-                    *reinterpret_cast<float4*>(cr + H) = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
-                }
+        for (int it = 0; it < 4; ++it) {
+            const int lr = it * 8 + (lane >> 3), c4 = lane & 7;
+            const int n = a0 + lr, c = 32 * g + 4 * c4;
+            if (n < M) {
+                *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
+                *reinterpret_cast<float4*>(ep.cat + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
             }
         }
     } else if constexpr (EPI == 4) {
         // GatedEquivariantBlock.vec1_proj (painn_denoising.py:687-692): only ||W1 v||_xyz is used downstream, so the
         // three component blocks are reduced on the accumulators and the [3N, C] product never goes to HBM.
-        // Output: cat [M, 2N] = [x | norm], x [M, N] copied alongside.
+        // Output: norm [M, N]; the consumer GEMM reads [x | norm] from two sources (ep.A2).
         static_assert(EPI != 4 || (NJ == 2 && MI == 3), "norm epilogue: 3 components x 64 columns per wave");
         const int q = lane & 31;
         const int cb = n0 + wn;
@@ -315,23 +315,12 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        {
-            const int c4 = lane & 15;
-            const int c = min(cb + 4 * c4, N - 4);
-            float4 xin[8];
 #pragma unroll
-            for (int it = 0; it < 8; ++it)
-                xin[it] = *reinterpret_cast<const float4*>(ep.x + (size_t)min(a0 + it * 4 + (lane >> 4), M - 1) * N + c);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int lr = it * 4 + (lane >> 4);
-                const int n = a0 + lr;
-                if (n < M && cb + 4 * c4 < N) {
-                    float* cr = ep.cat + (size_t)n * 2 * N + c;
-                    *reinterpret_cast<float4*>(cr) = xin[it];
-                    *reinterpret_cast<float4*>(cr + N) = *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
-                }
-            }
+        for (int it = 0; it < 8; ++it) {
+            const int lr = it * 4 + (lane >> 4), c4 = lane & 15;
+            const int n = a0 + lr, c = cb + 4 * c4;
+            if (n < M && c < N)
+                *reinterpret_cast<float4*>(ep.cat + (size_t)n * N + c) = *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
         }
     } else {
         // Columns of this wave: parts 0,1,2 of the 32 channels of group g.  The accumulators (lane =
@@ -494,13 +483,23 @@ int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int
     return ADF_OK;
 }
 
+// the kernels address A with 32-bit byte offsets
+static int32_t check_a_span(long long rows, int lda) {
+    if (rows * (long long)lda * 4 >= (1ll << 32)) {
+        adf_set_error("gemm16: A operand of %lld rows x %d exceeds the 32-bit offset range, split the batch", rows, lda);
+        return ADF_EOOM;  // surfaces as RuntimeError -> ml_diffuse splits the batch
+    }
+    return ADF_OK;
+}
+
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
-                          int N, int K, int act_ssilu, hipStream_t s) {
+                          int N, int K, int act_ssilu, hipStream_t s, const float* A2, int K1) {
     if (M <= 0) return ADF_OK;
-    if (K % HK != 0 || (lda & 3)) {
-        adf_set_error("gemm16: K=%d must be a multiple of %d and lda a multiple of 4", K, HK);
+    if (K % HK != 0 || (lda & 3) || (A2 && (K1 <= 0 || K1 % HK != 0 || K1 >= K))) {
+        adf_set_error("gemm16: K=%d (K1=%d) must be multiples of %d and lda a multiple of 4", K, K1, HK);
         return ADF_EINVAL;
     }
+    ADF_TRY(check_a_span(M, lda));
     static int mi = 0;
     if (!mi) { const char* e = getenv("ADF_GEMM16_MI"); mi = e ? atoi(e) : 2; if (mi != 4) mi = 2; }
     const int TM = 64 * mi, TN = 256;
@@ -509,6 +508,7 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
     adf_epi ep = {};
+    ep.A2 = A2; ep.K1 = A2 ? K1 : 0;
 #define LAUNCH16(ACT_, MI_)                                                                                  \
     hipLaunchKernelGGL((adf_gemm_f16x3_kernel<ACT_, MI_, 4, 0>), grid, dim3(256), 0, s, A, lda,              \
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, \
@@ -520,13 +520,14 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     return ADF_OK;
 }
 
-// ||W v||_xyz of a [M,3,K] vector field into cat [M, 2N] = [x | norm]  (EPI 4; N % 4 == 0)
-int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, const float* x, float* cat, int M, int N,
-                                  int K, hipStream_t s) {
+// ||W v||_xyz of a [M,3,K] vector field -> nrm [M, N]  (EPI 4; N % 4 == 0)
+int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, float* nrm, int M, int N, int K,
+                                  hipStream_t s) {
     if (M <= 0) return ADF_OK;
     if (K % HK != 0 || (lda & 3) || (N & 3)) { adf_set_error("gemm16_vecnorm: bad shape"); return ADF_EINVAL; }
+    ADF_TRY(check_a_span(3ll * M, lda));
     adf_epi ep = {};
-    ep.x = const_cast<float*>(x); ep.cat = cat;
+    ep.cat = nrm;
     const int tn = (N + 127) / 128, tm8 = ((M + 63) / 64 + 7) / 8 * 8;
     hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 4>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, (const float*)nullptr,
@@ -543,6 +544,7 @@ int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M
         adf_set_error("gemm16_fused: bad shape");
         return ADF_EINVAL;
     }
+    ADF_TRY(check_a_span(epi == 3 ? 3ll * M : (long long)M, lda));
     const int N = 3 * H, TM = 128, TN = 192;
     const int tiles_n = N / TN;  // H % 64 == 0
     const int tiles_m = (M + TM - 1) / TM;

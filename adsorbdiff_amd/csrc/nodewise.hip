@@ -240,21 +240,23 @@ int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const fl
     if (h->gemm_f32) {
         ADF_TRY(adf_linear(h, vec, H, b0.vec1_w, &b0.vec1_16, nullptr, t1, H, 3 * N, H, H, 0, s));
         hipLaunchKernelGGL(adf_head_norm_cat_kernel, dim3(ew_grid((long long)N * H / 4)), dim3(256), 0, s, x, t1, h->cat, N, H);
-    } else {  // cat = [x | ||vec1_proj(vec)||] straight from the accumulators
-        ADF_TRY(adf_launch_gemm16_vecnorm(vec, H, &b0.vec1_16, x, h->cat, N, H, H, s));
+    } else {  // ||vec1_proj(vec)|| straight from the accumulators into cat [N,H]
+        ADF_TRY(adf_launch_gemm16_vecnorm(vec, H, &b0.vec1_16, h->cat, N, H, H, s));
     }
     ADF_TRY(adf_linear(h, vec, H, b0.vec2_w, &b0.vec2_16, nullptr, t2, H2, 3 * N, H2, H, 0, s));
-    ADF_TRY(adf_linear(h, h->cat, 2 * H, b0.un0_w, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s));
+    if (h->gemm_f32) ADF_TRY(adf_linear(h, h->cat, 2 * H, b0.un0_w, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s));
+    else ADF_TRY(adf_launch_gemm16(x, H, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H));  // [x | norm]
     ADF_TRY(adf_linear(h, h->y, H, b0.un2_w, &b0.un2_16, b0.un2_b, o, H, N, H, H, 0, s));
     hipLaunchKernelGGL(adf_head_gate_kernel, dim3(ew_grid((long long)N * H2 / 4)), dim3(256), 0, s, o, t2, x1, v1, N, H2);
     // block 1: H/2 -> 1
     if (h->gemm_f32) {
         ADF_TRY(adf_linear(h, v1, H2, b1.vec1_w, &b1.vec1_16, nullptr, t1b, H2, 3 * N, H2, H2, 0, s));
         hipLaunchKernelGGL(adf_head_norm_cat_kernel, dim3(ew_grid((long long)N * H2 / 4)), dim3(256), 0, s, x1, t1b, cat1, N, H2);
+        ADF_TRY(adf_linear(h, cat1, H, b1.un0_w, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s));
     } else {
-        ADF_TRY(adf_launch_gemm16_vecnorm(v1, H2, &b1.vec1_16, x1, cat1, N, H2, H2, s));
+        ADF_TRY(adf_launch_gemm16_vecnorm(v1, H2, &b1.vec1_16, cat1, N, H2, H2, s));
+        ADF_TRY(adf_launch_gemm16(x1, H2, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s, cat1, H2));
     }
-    ADF_TRY(adf_linear(h, cat1, H, b1.un0_w, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s));
     hipLaunchKernelGGL(adf_head_final_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->y, v1, b1.vec2_w, b1.un2_w,
                        b1.un2_b, out, N, H2);
     ADF_HIP_CHECK(hipGetLastError());
