@@ -233,6 +233,10 @@ def main():
                 "edges_per_system": round(E / max(n_local, 1), 1),
                 "weights": "reference initialisers, seed 0, shipped scale factors",
                 "parallelism": "systems sharded over %d GPU(s), one all_gather of sites per pass" % world,
+                "loop_invariant_reuse": "slab-slab top-K candidates and layer-0 gather records (functions of the static "
+                                        "slab / atomic numbers only) are computed at the first of the 50 steps of each "
+                                        "pass and reused; every pass starts cold; bit-identical to recomputing "
+                                        "(denoising_pos_params['static_atom_cache']=False)",
             },
             "system_steps_per_s": total_systems * args.steps * args.num_steps / elapsed,
             "gpu_ms_per_pass": gpu_ms,

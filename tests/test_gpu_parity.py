@@ -603,3 +603,19 @@ def test_static_promise_forward_is_bit_identical():
         f1, f2 = torch.empty(N, 3, device=DEV), torch.empty(N, 3, device=DEV)
         eng.forward_prepared(prep, p_, f1, f2)
         assert torch.equal(f1, c1) and torch.equal(f2, c2)
+
+
+def test_static_atom_cache_switch_gives_identical_samples():
+    """denoising_pos_params["static_atom_cache"]=False recomputes everything every step: same positions."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("stepper_ode8.npz")
+    tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
+    outs = []
+    for flag in (True, False):
+        b = batch_from_fixture(fx, pos_key="pos_in")
+        torch.manual_seed(int(fx["seed"]))
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), static_atom_cache=flag), device=DEV)
+        outs.append(den.run().pos.clone())
+    assert torch.equal(outs[0], outs[1])
