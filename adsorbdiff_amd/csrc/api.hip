@@ -110,9 +110,12 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     h->hp = *hp;
     h->prof_ev = new std::vector<hipEvent_t>();
     h->prof_cat = new std::vector<int>();
-    ADF_HIP_CHECK(hipGetDevice(&h->device));
     hipDeviceProp_t prop;
-    ADF_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
+    if (hipGetDevice(&h->device) != hipSuccess || hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
+        adf_set_error("no usable HIP device: %s", hipGetErrorString(hipGetLastError()));
+        adf_painn_destroy(h);
+        return ADF_EHIP;
+    }
     h->num_cus = prop.multiProcessorCount;
     const int H = hp->hidden_channels, R = hp->num_rbf, L = hp->num_layers;
     int32_t st = dev_alloc(&h->rbf_pack, (size_t)L * (H / ADF_SLICE_CH) * R * 192);
