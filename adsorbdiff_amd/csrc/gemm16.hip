@@ -28,6 +28,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 #define HK 32
+// Row strides (floats) of the epilogues' transposition buffers.  Unpadded on purpose: with the lane groups of
+// ds_read_b128 ({0-3,12-15,20-27}, ...) a stride of 96 (= 32 mod 64 banks) resp. 64 puts the four rows a group
+// touches on disjoint 16-bank ranges; the +4 paddings one would add by habit (100, 68) made 2-way conflicts.
+#define TLD3 96
+#define TLD2 64
 #define HLD 40  // halves per LDS row (32 + 8 pad)
 
 __device__ __forceinline__ float ssilu16(float x) {
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             // stores 16 B: 4 rows x 256 B per wave instruction instead of 2 rows x 128 B with 4-B stores.
             const int q = lane & 31;
             __syncthreads();  // all waves are done reading the operand tiles
-            float* T = reinterpret_cast<float*>(lds) + wave * (32 * 68);  // [32 rows][64 + 4 pad] floats
+            float* T = reinterpret_cast<float*>(lds) + wave * (32 * TLD2);  // [32 rows][64] floats
 #pragma unroll
             for (int jj = 0; jj < NJ / 2; ++jj) {
                 const int cb = n0 + wn + 64 * jj;
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                         const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                         float v0 = acc[i][2 * jj][r] * isc + bv0, v1 = acc[i][2 * jj + 1][r] * isc + bv1;
                         if (ACT) { v0 = ssilu16(v0); v1 = ssilu16(v1); }
-                        T[lr * 68 + q] = v0;
-                        T[lr * 68 + 32 + q] = v1;
+                        T[lr * TLD2 + q] = v0;
+                        T[lr * TLD2 + 32 + q] = v1;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                         const int row = m0 + wm + 32 * i + lr, col = cb + 4 * c4;
                         if (row < M && col < N)
                             *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) =
-                                *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
+                                *reinterpret_cast<const float4*>(T + lr * TLD2 + 4 * c4);
                     }
                     __builtin_amdgcn_wave_barrier();  // T is rewritten by the next piece
                 }
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         const int H = ep.H;
         const float inv_sqrt_h = 1.0f / sqrtf((float)H);
         __syncthreads();  // all waves are done reading the operand tiles
-        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][100] floats
+        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][TLD3] floats
         const int a0 = m0 + (wave >> 1) * 32;                    // first atom of this wave
         float dv[16], nv[16];
 #pragma unroll
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 const float v1 = acc[i][0][r] * isc, v2 = acc[i][1][r] * isc;
                 d += v1 * v2;
                 qq += v2 * v2;
-                T[lr * 100 + i * 32 + q] = v1;
+                T[lr * TLD3 + i * 32 + q] = v1;
             }
             dv[r] = d * inv_sqrt_h;
             nv[r] = sqrtf(qq + 1e-8f);
@@ -273,15 +278,15 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 float* vo = ep.v1 + (size_t)n * 3 * H + 32 * g + 4 * c4;
 #pragma unroll
                 for (int ax = 0; ax < 3; ++ax)
-                    *reinterpret_cast<float4*>(vo + ax * H) = *reinterpret_cast<const float4*>(T + lr * 100 + ax * 32 + 4 * c4);
+                    *reinterpret_cast<float4*>(vo + ax * H) = *reinterpret_cast<const float4*>(T + lr * TLD3 + ax * 32 + 4 * c4);
             }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            T[lr * 100 + q] = dv[r];
-            T[lr * 100 + 32 + q] = nv[r];
+            T[lr * TLD3 + q] = dv[r];
+            T[lr * TLD3 + 32 + q] = nv[r];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -290,8 +295,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             const int lr = it * 8 + (lane >> 3), c4 = lane & 7;
             const int n = a0 + lr, c = 32 * g + 4 * c4;
             if (n < M) {
-                *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
-                *reinterpret_cast<float4*>(ep.cat + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
+                *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * TLD3 + 4 * c4);
+                *reinterpret_cast<float4*>(ep.cat + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * TLD3 + 32 + 4 * c4);
             }
         }
     } else if constexpr (EPI == 4) {
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         const int q = lane & 31;
         const int cb = n0 + wn;
         __syncthreads();  // all waves are done reading the operand tiles
-        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][68] floats used
+        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][TLD2] floats used
         const int a0 = m0 + (wave >> 1) * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float a = acc[0][j][r] * isc, b = acc[1][j][r] * isc, d = acc[2][j][r] * isc;
-                T[lr * 68 + j * 32 + q] = sqrtf(a * a + b * b + d * d);
+                T[lr * TLD2 + j * 32 + q] = sqrtf(a * a + b * b + d * d);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             const int lr = it * 4 + (lane >> 4), c4 = lane & 15;
             const int n = a0 + lr, c = cb + 4 * c4;
             if (n < M && c < N)
-                *reinterpret_cast<float4*>(ep.cat + (size_t)n * N + c) = *reinterpret_cast<const float4*>(T + lr * 68 + 4 * c4);
+                *reinterpret_cast<float4*>(ep.cat + (size_t)n * N + c) = *reinterpret_cast<const float4*>(T + lr * TLD2 + 4 * c4);
         }
     } else {
         // Columns of this wave: parts 0,1,2 of the 32 channels of group g.  The accumulators (lane =
@@ -333,15 +338,15 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         const int H = ep.H;
         const float b0 = bias[n0 + wn + q], b1 = bias[n0 + wn + 32 + q], b2 = bias[n0 + wn + 64 + q];
         __syncthreads();  // all waves are done reading the operand tiles
-        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 rows][100] floats (96 + 4 pad)
+        float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 rows][TLD3] floats
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                T[lr * 100 + q] = acc[i][0][r] * isc + b0;
-                T[lr * 100 + 32 + q] = acc[i][1][r] * isc + b1;
-                T[lr * 100 + 64 + q] = acc[i][2][r] * isc + b2;
+                T[lr * TLD3 + q] = acc[i][0][r] * isc + b0;
+                T[lr * TLD3 + 32 + q] = acc[i][1][r] * isc + b1;
+                T[lr * TLD3 + 64 + q] = acc[i][2][r] * isc + b2;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -366,9 +371,9 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 for (int it = 0; it < 4; ++it) {
                     const int lr = it * 8 + (lane >> 3);
                     const int n = m0 + wm + 32 * i + lr;
-                    const float4 p0 = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
-                    const float4 p1 = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
-                    const float4 p2 = *reinterpret_cast<const float4*>(T + lr * 100 + 64 + 4 * c4);
+                    const float4 p0 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 4 * c4);
+                    const float4 p1 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 32 + 4 * c4);
+                    const float4 p2 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 64 + 4 * c4);
                     if (n < M) {
                         // half-record of (atom n, group g): [32 x (xa, xc, P0, P1)] then [32 x P2]
                         float* rec = ep.rec + ((size_t)n * (H / 32) + g) * 160;
@@ -408,9 +413,9 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 for (int it = 0; it < 4; ++it) {
                     const int lr = it * 8 + (lane >> 3);
                     const int n = m0 + wm + 32 * i + lr;
-                    const float4 p0 = *reinterpret_cast<const float4*>(T + lr * 100 + 4 * c4);
-                    const float4 p1 = *reinterpret_cast<const float4*>(T + lr * 100 + 32 + 4 * c4);
-                    const float4 p2 = *reinterpret_cast<const float4*>(T + lr * 100 + 64 + 4 * c4);
+                    const float4 p0 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 4 * c4);
+                    const float4 p1 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 32 + 4 * c4);
+                    const float4 p2 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 64 + 4 * c4);
                     const float k2 = 0.70710678118654752f, sc = ep.scale;
                     float4 xo4 = xv[it];
                     xo4.x = (xo4.x + (p0.x + p1.x * d[it].x) * k2) * sc;
