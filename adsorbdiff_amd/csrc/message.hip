@@ -15,8 +15,8 @@
 // incoming edges of its target (CSR over targets, edges pre-sorted by distance), in 32-row blocks:
 //   1. the MFMA A operand is built in registers — lane (row, k) evaluates env(d_row)*exp(..) for its
 //      own k — and the MFMA runs over 6 column blocks, but only over the k-window where
-//      some row's Gaussian is non-negligible: |k - (R-1) d/rc| <= 7 (dropped terms < exp(-24.5) =
-//      2.3e-11 of the leading term, far below f32 rounding).  Because a target's edges are sorted by
+//      some row's Gaussian is non-negligible: terms with |k - (R-1) d/rc| >= 6 are dropped (each
+//      < exp(-18) = 1.5e-8 of the leading term, below f32 rounding; the exact-f32 mode keeps |..| < 8).  Because a target's edges are sorted by
 //      distance, a 32-row block spans a narrow band and the 128-deep contraction shrinks to ~35;
 //   2. the 16 accumulator rows of each lane gather their source's packed record (xa, xc and
 //      P_i = vec_i * xb for the lane's channels c0+q and c0+32+q; 40 B per lane and row as
@@ -234,8 +234,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             if (nvalid <= 0) {  // target without incoming edges: one dummy step on all-zero A (env = 0)
                 klo = 0; khi = 16;
             } else if (F16) {
-                klo = max(0, (int)floorf(umin) - 7) & ~7;
-                khi = min(p.R, (int)ceilf(umax) + 8);
+                // keep every k with |k - u| < 6 for every row of the block
+                klo = max(0, (int)floorf(umin) - 5) & ~7;
+                khi = min(p.R, (int)ceilf(umax) + 6);
                 khi = klo + ((khi - klo + 15) & ~15);       // whole 16-deep MFMA steps
                 if (khi > 128) { klo -= khi - 128; khi = 128; }  // keep the LDS reads inside the image
             } else {

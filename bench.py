@@ -263,7 +263,7 @@ def main():
                         "block, padded rows and the 3 split products included) / launch time from HIP events on the "
                         "launch stream. This is the conservative count: the algorithm's dense contraction (SURVEY 8d: "
                         "2*R*3H*E per layer, x3 products in this arithmetic = algorithmic_f16x3_tflops) is ~1.9x larger, "
-                        "the k-window skips Gaussian terms below 2.3e-11. Timed on the "
+                        "the k-window skips Gaussian terms below 1.5e-8 of the leading one. Timed on the "
                         "launch stream; measured_peak = the same MFMA instruction in a register-resident loop on this "
                         "box (non-zero operands). rbfh is never materialised, so neither SURVEY 8d roofline binds alone: "
                         "per 32-edge block the kernel issues ~600 VALU instructions (8 FMA per gathered channel-row) "
