@@ -26,37 +26,48 @@ __global__ void adf_embed_kernel(const float* __restrict__ emb, const int32_t* _
     }
 }
 
-// torch.nn.LayerNorm(H), eps = 1e-5, biased variance.  One wave per row.
+// torch.nn.LayerNorm(H), eps = 1e-5, biased variance.  One wave per row, 16 B per lane and access.
 __global__ __launch_bounds__(256) void adf_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ y,
                                                              int N, int H) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
-    const float* xr = x + (size_t)row * H;
-    float vals[16];  // H <= 1024
-    const int per = H / 64;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * H);
+    const int h4 = H / 4;  // H <= 1024: at most 4 float4 per lane
+    float4 vals[4];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < per) { vals[i] = xr[lane + 64 * i]; sum += vals[i]; }
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        vals[i] = c < h4 ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sum += (vals[i].x + vals[i].y) + (vals[i].z + vals[i].w);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float)H;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < per) { const float d = vals[i] - mean; sq += d * d; }
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < h4) {
+            const float dx = vals[i].x - mean, dy = vals[i].y - mean, dz = vals[i].z - mean, dw = vals[i].w - mean;
+            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     const float rstd = 1.0f / sqrtf(sq / (float)H + 1e-5f);
-    float* yr = y + (size_t)row * H;
+    float4* yr = reinterpret_cast<float4*>(y + (size_t)row * H);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < per) {
-            const int c = lane + 64 * i;
-            yr[c] = (vals[i] - mean) * rstd * w[c] + b[c];
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < h4) {
+            const float4 ww = w4[c], bb = b4[c];
+            yr[c] = make_float4((vals[i].x - mean) * rstd * ww.x + bb.x, (vals[i].y - mean) * rstd * ww.y + bb.y,
+                                (vals[i].z - mean) * rstd * ww.z + bb.z, (vals[i].w - mean) * rstd * ww.w + bb.w);
         }
+    }
 }
 
 // PaiNNUpdate, first half (painn_denoising.py:602-613): vv = vec_proj(vec) as [N,3,2H] (v1|v2)
