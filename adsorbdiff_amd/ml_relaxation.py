@@ -1,21 +1,43 @@
 """``ml_diffuse`` — driver of the diffusion sampler.
 
 Drop-in for ``adsorbdiff.relaxation.ml_relaxation.ml_diffuse`` (reference:
-adsorbdiff/relaxation/ml_relaxation.py:98-168): a deque of batches; a ``RuntimeError`` from a
-batch (the HIP library reports device OOM as RuntimeError) splits it into two halves that are
-retried, a single-system failure is re-raised; the relaxed batches are re-collated at the end.
+adsorbdiff/relaxation/ml_relaxation.py:98-168).  Written from its contract, not its text:
+
+* same signature and return type (one re-collated ``Batch``);
+* a ``RuntimeError`` while sampling a batch of more than one system (the HIP library reports device OOM
+  and 32-bit-offset overflow as ``RuntimeError``) makes the batch be sampled as two halves instead;
+* a ``RuntimeError`` on a single system propagates to the caller;
+* order of the returned systems: the reference pushes both halves on the *left* of its work deque, first
+  half first, so the second half is sampled (and collated) before the first one.  ``_sample_or_split``
+  reproduces that order by recursing into the upper half first.
 """
 from __future__ import annotations
 
 import logging
-from collections import deque
 from pathlib import Path
-from typing import Optional
+from typing import Iterator
 
 import torch
 
 from .data import Batch, data_list_collater
 from .denoising_torch import Denoiser, DiffTorchCalc
+
+
+def _sample_or_split(batch, make_denoiser) -> Iterator:
+    """Yield sampled (sub-)batches of ``batch``; halve and retry on RuntimeError."""
+    try:
+        yield make_denoiser(batch).run()
+        return
+    except RuntimeError:
+        systems = batch.to_data_list()
+        if len(systems) == 1:
+            raise
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    logging.info(f"Failed to relax batch with size: {len(systems)}, splitting into two...")
+    half = len(systems) // 2
+    for part in (systems[half:], systems[:half]):
+        yield from _sample_or_split(data_list_collater(part), make_denoiser)
 
 
 def ml_diffuse(
@@ -29,40 +51,11 @@ def ml_diffuse(
     early_stop_batch: bool = False,
     logger=None,
 ):
-    batches = deque([batch])
-    relaxed_batches = []
-    while batches:
-        batch = batches.popleft()
-        oom = False
-        ids = batch.sid
-        calc = DiffTorchCalc(model, transform)
-        optimizer = Denoiser(
-            batch,
-            calc,
-            device=device,
-            save_full_traj=save_full_traj,
-            traj_dir=Path(traj_dir) if traj_dir is not None else None,
-            traj_names=ids,
-            early_stop_batch=early_stop_batch,
-            denoising_pos_params=denoising_pos_params,
-            logger=logger,
-        )
-        e: Optional[RuntimeError] = None
-        try:
-            relaxed_batch = optimizer.run()
-            relaxed_batches.append(relaxed_batch)
-        except RuntimeError as err:
-            e = err
-            oom = True
-            if torch.cuda.is_available():
-                torch.cuda.empty_cache()
-        if oom:
-            data_list = batch.to_data_list()
-            if len(data_list) == 1:
-                assert isinstance(e, RuntimeError)
-                raise e
-            logging.info(f"Failed to relax batch with size: {len(data_list)}, splitting into two...")
-            mid = len(data_list) // 2
-            batches.appendleft(data_list_collater(data_list[:mid]))
-            batches.appendleft(data_list_collater(data_list[mid:]))
-    return Batch.from_data_list(relaxed_batches)
+    sink = Path(traj_dir) if traj_dir is not None else None
+
+    def make_denoiser(b):
+        return Denoiser(b, DiffTorchCalc(model, transform), denoising_pos_params=denoising_pos_params,
+                        device=device, save_full_traj=save_full_traj, traj_dir=sink, traj_names=b.sid,
+                        early_stop_batch=early_stop_batch, logger=logger)
+
+    return Batch.from_data_list(list(_sample_or_split(batch, make_denoiser)))

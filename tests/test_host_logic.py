@@ -157,6 +157,8 @@ def test_ml_diffuse_splits_on_runtime_error(monkeypatch):
     b = make_batch(5, n_slab=16, n_ads=2, seed=9)
     out = R.ml_diffuse(b, model=object(), denoising_pos_params={}, traj_dir=None, save_full_traj=False, device="cpu")
     assert seen[0] == 5 and max(seen[1:]) <= 3 and sorted(out.sid) == sorted(b.sid)
+    # the reference pushes both halves on the left of its deque, first half first: the upper half is sampled first
+    assert seen == [5, 3, 2, 1, 2] and list(out.sid) == [b.sid[i] for i in (3, 4, 2, 0, 1)]
     assert torch.allclose(out.pos.sum(), b.pos.sum() + 3.0 * b.pos.shape[0])
 
     class AlwaysFail(FakeDenoiser):
