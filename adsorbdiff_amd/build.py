@@ -14,7 +14,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libadsorbdiff_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "graph.hip", "message.hip", "nodewise.hip", "stepper.hip", "peaks.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "graph.hip", "message.hip", "nodewise.hip", "stepper.hip", "peaks.hip", "collect.hip"]
 
 
 def _hipcc() -> str:
@@ -32,23 +32,49 @@ def needs_build() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    # No SLP vectorisation: with it hipcc (ROCm 7.2) packs adjacent f32 adds/mults of the message
+    # kernel's epilogue into v_pk_*_f32 next to the f16 MFMA loop and the kernel then returned
+    # run-to-run different sums in lanes 16-31 (bisected: deterministic and correct without).
+    # Packed f32 VALU math is also slower beside MFMAs (MI355X_MICROARCH.md, filler prices).
+    "-fno-slp-vectorize",
+]
+OBJ_DIR = CSRC / "build"  # git-ignored
+
+
+def _compile_one(args):
+    cc, src, obj = args
+    res = subprocess.run([cc, *FLAGS, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+    return src.name, res.returncode, res.stdout + res.stderr
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
+    """One object per translation unit (compiled in parallel, only when stale), then one link."""
     if not force and not needs_build():
         return LIB
-    cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        # No SLP vectorisation: with it hipcc (ROCm 7.2) packs adjacent f32 adds/mults of the message
-        # kernel's epilogue into v_pk_*_f32 next to the f16 MFMA loop and the kernel then returns
-        # run-to-run different sums in lanes 16-31 (scratch/ bisect: deterministic and correct without).
-        # Packed f32 VALU math is also slower beside MFMAs (MI355X_MICROARCH.md, filler prices).
-        "-fno-slp-vectorize",
-        "-o", str(LIB),
-    ] + [str(CSRC / s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+
+    cc = _hipcc()
+    OBJ_DIR.mkdir(exist_ok=True)
+    hdr_t = max((CSRC / "common.h").stat().st_mtime, (PKG.parent / "include" / "adsorbdiff_hip.h").stat().st_mtime,
+                Path(__file__).stat().st_mtime)
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = CSRC / s, OBJ_DIR / (s + ".o")
+        objs.append(obj)
+        if force or not obj.exists() or obj.stat().st_mtime < max(src.stat().st_mtime, hdr_t):
+            jobs.append((cc, src, obj))
     if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print("compiling:", [j[1].name for j in jobs])
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for name, rc, out in ex.map(_compile_one, jobs):
+            if rc != 0:
+                raise RuntimeError(f"hipcc failed on {name}:\n{out}")
+    res = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs],
+                         capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{res.stdout}\n{res.stderr}")
+        raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
     return LIB
 
 

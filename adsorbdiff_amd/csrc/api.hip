@@ -127,7 +127,8 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     }
     if (st == ADF_OK) st = dev_alloc(&h->rbf_bias_pack16, (size_t)L * (H / ADF_SLICE_CH) * 192);
     if (st == ADF_OK) st = dev_alloc(&h->rbf_scales, 16);
-    if (st == ADF_OK) st = dev_alloc(&h->flags, 4);
+    if (st == ADF_OK) st = dev_alloc(&h->flags, ADF_NFLAGS);
+    if (st == ADF_OK && hipMemset(h->flags, 0, sizeof(int32_t) * ADF_NFLAGS) != hipSuccess) st = ADF_EHIP;
     {   // fp16 hi/lo arena: per layer 9 H^2 + 2 (H*2H) ... computed exactly below
         const size_t HH = (size_t)H * H;
         const size_t per_layer = HH + 3 * HH + 2 * HH + 2 * HH + 3 * HH;                 // xp0 xp2 vp xv0 xv2
@@ -322,13 +323,19 @@ static int32_t check_batch(const adf_painn* h, const adf_batch* b) {
     return ADF_OK;
 }
 
+// The flags are sticky on the device: kernels only ever set them, so a condition raised at any step of a sampling
+// loop survives until it is read here (which clears them).
 static int32_t read_flags(adf_painn* h, hipStream_t s) {
-    int32_t f[4];
+    int32_t f[ADF_NFLAGS];
     ADF_HIP_CHECK(hipMemcpyAsync(f, h->flags, sizeof(f), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->flags, 0, sizeof(f), s));
     ADF_HIP_CHECK(hipStreamSynchronize(s));
+    if (f[4]) { adf_set_error("atomic number outside [1, %d] (rows of the embedding table)", h->hp.num_elements); return ADF_EINVAL; }
     if (f[0]) { adf_set_error("a centre atom has more than %d in-cutoff candidates", ADF_MAX_CAND); return ADF_EOVERFLOW; }
     if (f[2]) { adf_set_error("edge buffer overflow"); return ADF_EOVERFLOW; }
+    if (f[3]) { adf_set_error("an atom has more than %d incoming edges", ADF_MAX_INDEG); return ADF_EOVERFLOW; }
     if (f[1]) { adf_set_error("An image has no neighbors"); return ADF_ENONEIGHBOR; }
+    if (f[5]) { adf_set_error("non-finite activation in the forward (inf/nan input or weights)"); return ADF_EHIP; }
     return ADF_OK;
 }
 
@@ -337,6 +344,7 @@ extern "C" int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, co
     if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
     if (moving && (!mov_idx || !mov_off)) { adf_set_error("moving mask needs mov_idx and mov_off"); return ADF_EINVAL; }
     h->moving = moving; h->mov_idx = mov_idx; h->mov_off = mov_off;
+    ADF_HIP_CHECK(hipMemset(h->flags, 0, sizeof(int32_t) * ADF_NFLAGS));  // a new promise starts with clean flags
     h->cache_valid = false;
     h->rec0_valid = false;
     return ADF_OK;
@@ -660,7 +668,8 @@ extern "C" int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, con
                               const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
                               const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
                               const int32_t* out_idx, int32_t n_out, float* f1, float* f2, void* stream) {
-    if (num_steps <= 0 || !f1 || !f2 || !state) { adf_set_error("sample: bad argument"); return ADF_EINVAL; }
+    ADF_TRY(check_batch(h, b));
+    if (num_steps <= 0 || !f1 || !f2 || !state || !coefs_dev || !pos || !tags) { adf_set_error("sample: bad argument"); return ADF_EINVAL; }
     if ((z_tr_all == nullptr) != (z_rot_all == nullptr)) { adf_set_error("sample: need both noise tables or none"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const size_t zs = (size_t)b->num_systems * 3;

@@ -13,6 +13,8 @@
 #define ADF_SLICE_CH 64         // channels per message-kernel slice (x3 parts = 192 MFMA columns)
 #define ADF_MAX_CAND 1024       // in-cutoff candidates per centre held in LDS by the top-K kernel
 #define ADF_MAX_K 128
+#define ADF_NFLAGS 8
+#define ADF_MAX_INDEG 1024      // incoming edges per target the per-target sorter handles (graph.hip)
 
 void adf_set_error(const char* fmt, ...);
 
@@ -112,7 +114,10 @@ struct adf_painn {
     bool cache_valid;
     int32_t* e_src;      // [capE] source atom of every edge, grouped by target, sorted by distance
     float4* e_geom;      // [capE] (ux,uy,uz,d): unit vector target->source, distance
-    int32_t* flags;      // device int32[4]: {candidate overflow, empty image, edge overflow, -}
+    // device int32[8], STICKY (only adf_check_flags / adf_graph_build(num_edges) / adf_graph_set_moving clear them):
+    // {0 candidate overflow, 1 empty image, 2 edge overflow, 3 in-degree beyond the sorter, 4 atomic number out of
+    //  range, 5 non-finite or fp16-range-exceeding activation (gemm16.hip), 6-7 unused}
+    int32_t* flags;
     float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
     float* rec;          // [(N+1)][H/64][320] gather records of the message kernel (message.hip)
     // Layer-0 gather records depend on the atomic numbers only (x0 = emb(Z), vec0 = 0).  While a static-atom

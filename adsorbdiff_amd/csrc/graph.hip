@@ -309,15 +309,53 @@ __global__ void adf_fill_kernel(GraphParams p, const int32_t* nptr, int32_t* cur
 // the Gaussian basis, which shrinks the k-window it has to contract over; (2) the order no longer
 // depends on the atomic cursor above, so the segmented sums are run-to-run reproducible.
 #define SORT_MAX 256
+__device__ __forceinline__ bool edge_before(const float4& h, int sf, const float4& g, int sj) {
+    if (h.w != g.w) return h.w < g.w;
+    if (sf != sj) return sf < sj;
+    if (h.x != g.x) return h.x < g.x;
+    if (h.y != g.y) return h.y < g.y;
+    return h.z < g.z;
+}
+
 __global__ __launch_bounds__(256) void adf_sort_edges_kernel(const int32_t* nptr, int32_t* e_src, float4* e_geom,
-                                                              int N) {
+                                                              int N, int32_t* flags) {
     __shared__ float4 s_geo[4][SORT_MAX];
     __shared__ int32_t s_src[4][SORT_MAX];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + w;
     if (n >= N) return;
     const int e0 = nptr[n];
-    const int deg = min(nptr[n + 1] - e0, SORT_MAX);  // deg <= 2K <= 256
+    int deg = nptr[n + 1] - e0;
+    // In-degree = own kept entries (<= K) + every centre that lists this atom, so only sum(deg) <= 2NK is bounded:
+    // a hub atom can exceed 2K.  Up to SORT_MAX the segment is ranked out of LDS; up to ADF_MAX_INDEG each lane keeps
+    // its <= 16 records in registers and ranks them against the (still unmodified) global segment, then all lanes
+    // write; beyond that the message kernel's distance-ordered k-window would be wrong: flagged (ADF_EOVERFLOW).
+    if (deg > SORT_MAX) {
+        if (deg > ADF_MAX_INDEG) {
+            if (lane == 0) atomicExch(&flags[3], 1);
+            deg = ADF_MAX_INDEG;
+        }
+        float4 g[ADF_MAX_INDEG / 64]; int sj[ADF_MAX_INDEG / 64]; int rk[ADF_MAX_INDEG / 64];
+#pragma unroll
+        for (int u = 0; u < ADF_MAX_INDEG / 64; ++u) {
+            const int t = lane + 64 * u;
+            g[u] = t < deg ? e_geom[e0 + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            sj[u] = t < deg ? e_src[e0 + t] : 0;
+            rk[u] = 0;
+        }
+        for (int f = 0; f < deg; ++f) {
+            const float4 hh = e_geom[e0 + f];
+            const int sf = e_src[e0 + f];
+#pragma unroll
+            for (int u = 0; u < ADF_MAX_INDEG / 64; ++u) rk[u] += edge_before(hh, sf, g[u], sj[u]) ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < ADF_MAX_INDEG / 64; ++u)
+            if (lane + 64 * u < deg) { e_geom[e0 + rk[u]] = g[u]; e_src[e0 + rk[u]] = sj[u]; }
+        return;
+    }
     for (int t = lane; t < deg; t += 64) { s_geo[w][t] = e_geom[e0 + t]; s_src[w][t] = e_src[e0 + t]; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -328,14 +366,7 @@ __global__ __launch_bounds__(256) void adf_sort_edges_kernel(const int32_t* nptr
         for (int f = 0; f < deg; ++f) {
             const float4 h = s_geo[w][f];
             const int sf = s_src[w][f];
-            bool less = h.w < g.w;
-            if (h.w == g.w) {
-                if (sf != sj) less = sf < sj;
-                else if (h.x != g.x) less = h.x < g.x;
-                else if (h.y != g.y) less = h.y < g.y;
-                else less = h.z < g.z;
-            }
-            rank += less ? 1 : 0;
+            rank += edge_before(h, sf, g, sj) ? 1 : 0;
         }
         e_geom[e0 + rank] = g;
         e_src[e0 + rank] = sj;
@@ -355,7 +386,6 @@ int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
     ADF_HIP_CHECK(hipMemsetAsync(h->deg, 0, sizeof(int32_t) * (N + 1), s));
     ADF_HIP_CHECK(hipMemsetAsync(h->cursor, 0, sizeof(int32_t) * N, s));
     ADF_HIP_CHECK(hipMemsetAsync(h->img_cnt, 0, sizeof(int32_t) * B, s));
-    ADF_HIP_CHECK(hipMemsetAsync(h->flags, 0, sizeof(int32_t) * 4, s));
     // static-atom cache: valid for the same batch as long as only atoms flagged `moving` moved
     p.moving = h->moving; p.mov_idx = h->mov_idx; p.mov_off = h->mov_off;
     p.cache_d2 = h->cache_d2; p.cache_cid = h->cache_cid; p.cache_cnt = h->cache_cnt;
@@ -378,7 +408,8 @@ int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
                        h->flags);
     hipLaunchKernelGGL(adf_fill_kernel, dim3(nb), dim3(256), 0, s, p, h->nptr, h->cursor, h->e_src, h->e_geom,
                        (long long)h->capE);
-    hipLaunchKernelGGL(adf_sort_edges_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->nptr, h->e_src, h->e_geom, N);
+    hipLaunchKernelGGL(adf_sort_edges_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->nptr, h->e_src, h->e_geom, N,
+                       h->flags);
     ADF_HIP_CHECK(hipGetLastError());
     h->lastN = N; h->lastB = B;
     h->last_reps[0] = p.r0; h->last_reps[1] = p.r1; h->last_reps[2] = p.r2;

@@ -515,14 +515,12 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
                            h->rbf_bias_pack16 + l * per_layer_b, h->rbf_scales + l, H, R);
     }
     ADF_HIP_CHECK(hipGetLastError());
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per device (a function attribute is per device; set_weights is rare, so no caching)
 #define SET_LDS(F16_, VZ_)                                                                                    \
     ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<F16_, VZ_>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128, F16_)))
         SET_LDS(false, false); SET_LDS(false, true); SET_LDS(true, false); SET_LDS(true, true);
 #undef SET_LDS
-        attr_set = true;
     }
     return ADF_OK;
 }

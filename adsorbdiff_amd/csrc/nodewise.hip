@@ -14,14 +14,17 @@ __device__ __forceinline__ float ssilu_d(float x) {
 
 // x[n,:] = emb[Z[n]-1,:]   (gemnet_oc/layers/embedding_block.py:42).  vec = 0 (painn_denoising.py:426) is
 // not materialised: the first message layer runs in its vec-is-zero mode.
+// Z outside [1, num_elements] (torch's nn.Embedding raises IndexError there): flagged, row read clamped.
 __global__ void adf_embed_kernel(const float* __restrict__ emb, const int32_t* __restrict__ Z, float* __restrict__ x,
-                                 int N, int H) {
+                                 int N, int H, int num_elements, int32_t* flags) {
     const int h4 = H / 4;
     const long long total = (long long)N * h4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i / h4), c = (int)(i - (long long)n * h4);
-        const float4 v = reinterpret_cast<const float4*>(emb + (size_t)(Z[n] - 1) * H)[c];
+        int z = Z[n] - 1;
+        if (z < 0 || z >= num_elements) { if (c == 0) atomicExch(&flags[4], 1); z = min(max(z, 0), num_elements - 1); }
+        const float4 v = reinterpret_cast<const float4*>(emb + (size_t)z * H)[c];
         reinterpret_cast<float4*>(x + (size_t)n * H)[c] = v;
     }
 }
@@ -208,7 +211,8 @@ static inline unsigned ew_grid(long long total) {
 
 int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s) {
     const int H = h->hp.hidden_channels;
-    hipLaunchKernelGGL(adf_embed_kernel, dim3(ew_grid((long long)N * H / 4)), dim3(256), 0, s, h->emb, Z, x, N, H);
+    hipLaunchKernelGGL(adf_embed_kernel, dim3(ew_grid((long long)N * H / 4)), dim3(256), 0, s, h->emb, Z, x, N, H,
+                       h->hp.num_elements, h->flags);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

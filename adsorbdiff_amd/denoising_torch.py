@@ -23,6 +23,9 @@ Extensions (all optional, defaults reproduce the reference):
   * ``denoising_pos_params["scores_on_adsorbate_only"]`` (default False): the update only ever reads the
     model output on tag-2 atoms (reference :263-268, :460-467), so the last layer and the heads can be
     evaluated for those atoms alone (``adf_painn_forward_subset``).  Sampled positions are bit-identical.
+  * ``denoising_pos_params["placement_noise"]`` (default None): ``[B,3]`` uniforms for the initial placement instead
+    of ``torch.rand(B,3)`` from the CPU generator (:215) — a sharded run that indexes one global table by system id
+    samples exactly what the single-process run samples.
   * ``traj_dir=None`` is allowed (the reference crashes in ``write``); with a ``traj_dir`` the
     frames are kept on the device during the loop and written once at the end.
 """
@@ -170,7 +173,11 @@ class Denoiser:
             early = 10 if params.get("early_stop", True) else 0
 
             # initial placement: uniform noise from the CPU global generator (reference :215)
-            noise = torch.rand(B, 3)
+            noise = params.get("placement_noise")
+            if noise is None:
+                noise = torch.rand(B, 3)
+            else:  # extension: caller-supplied uniforms (sharded runs key them by global system id)
+                noise = torch.as_tensor(noise, dtype=torch.float32).reshape(B, 3).cpu()
             eng.init_placement(prep, pos, noise.to(dev))
             # from here on only the adsorbate (tag 2) moves: the graph builder may cache the slab-slab part and the
             # forward the layer-0 records (loop-invariant; results are bit-identical either way)

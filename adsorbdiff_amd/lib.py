@@ -19,6 +19,7 @@ EXPORTS = (
     "adf_check_flags",
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
+    "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
     "adf_last_error", "adf_version",
 )
 
@@ -99,6 +100,10 @@ def load():
         "adf_profile_enable": [vp, i32],
         "adf_profile_read": [vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64), vp],
         "adf_measure_peaks": [C.POINTER(C.c_float), vp],
+        "adf_comm_unique_id": [vp],
+        "adf_comm_create": [vp, i32, i32, C.POINTER(vp)],
+        "adf_comm_destroy": [vp],
+        "adf_allgather_sites": [vp, vp, i64, vp, vp],
         "adf_sample": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp],
     }
     for name, argtypes in sigs.items():

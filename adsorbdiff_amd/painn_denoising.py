@@ -274,22 +274,32 @@ class PaiNN(nn.Module):
         if self._engine is not None and self._engine.device != device:
             self._engine.close()
             self._engine = None
-        version = self._weights_version()
+        version = self._weights_version(device)
         if self._engine is None:
             self._engine = PaiNNEngine(self, device)
             self._engine_key = version
         elif self._engine_key != version:
-            # parameters were swapped or modified in place (EMA copy_to/restore, load_state_dict)
+            # parameters were swapped or modified in place (EMA copy_to/restore, load_state_dict, optimizer step)
             self._engine.bind_weights()
             self._engine_key = version
         return self._engine
 
-    def _weights_version(self):
-        # re-pack when any parameter tensor was swapped or modified in place
-        # (EMA store/copy_to/restore, load_state_dict)
-        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(
-            (b.data_ptr(), b._version) for b in self.buffers()
-        )
+    def _weights_version(self, device=None):
+        """Key of the packed weight images held by the engine.  (data_ptr, _version) catches swapped tensors and
+        autograd-visible in-place writes; the content fingerprint catches writes through ``param.data`` — what the
+        reference's EMA ``copy_to``/``restore`` do (modules/exponential_moving_average.py:113,147), which leave
+        ``_version`` untouched.  The fingerprint is the wrapping int64 sum of every tensor's bit pattern (two
+        kernels over 86 MB, one host read); engine() is called per forward(data) / per sampling run, never per step."""
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        flat = [t.detach().reshape(-1) for t in tensors
+                if t.is_cuda and t.dtype == torch.float32 and t.numel() > 0]
+        if not flat:
+            return key
+        with torch.no_grad():
+            bits = torch.cat(flat).view(torch.int32)
+            fp = int(bits.sum(dtype=torch.int64).item()) ^ int((bits[::7].sum(dtype=torch.int64) * 31).item())
+        return key + (fp,)
 
     def forward(self, data):
         """data: pos[N,3] f32, atomic_numbers[N], batch[N] i64, natoms[B] i64, cell[B,3,3] f32

@@ -8,13 +8,18 @@ OC20-Dense-shaped systems: initial placement, then `--num-steps` (50) reverse st
 cutoff), 1xMI355X").  Inputs are resident in HBM before the timed region starts.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus 8                      # starts its own 8 ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: systems are independent, so each rank samples its own shard (no data-path
-collective); the only exchange is one RCCL all_gather of the sampled adsorbate sites at the end
-of every pass (inside the timed region).  Default `--scaling weak`: every rank gets `--systems`
-systems; `--scaling strong` splits `--systems` over the ranks.
+Multi-GPU (BASELINE.json configs[2]: "the same 1000-system batch sharded 8 ways"): systems are independent, so
+every rank samples its shard with no data-path collective; the only exchange is one all_gather of the sampled
+adsorbate sites at the end of every pass (inside the timed region; RCCL over xGMI).  Default `--scaling strong`:
+the `--systems` systems are dealt to the ranks by atom count (`sampler.shard_batch`, the reference's
+balanced_partition, datasets/data_parallel.py:32-48) and the gathered sites come back in global system order;
+`--scaling weak` gives every rank `--systems` systems of its own.  When WORLD_SIZE is not set and --gpus N > 1,
+this process never touches the GPU: it starts N children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), relays rank 0's
+JSON line and exits non-zero if any child fails.
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   "roofline":     dominant kernel (fused message kernel, f32 MFMA bound), timed live with HIP
@@ -27,11 +32,11 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -49,51 +54,95 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--systems", type=int, default=1000, help="systems per rank (weak) or in total (strong)")
     ap.add_argument("--num-steps", type=int, default=50, help="reverse-diffusion steps per sample")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong")
+    ap.add_argument("--gather", choices=("torch", "rccl"), default="torch",
+                    help="exchange step: torch.distributed.all_gather (nccl backend = RCCL) or the library's own "
+                         "C-ABI adf_allgather_sites (RCCL communicator created by the library)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the adsorbate-only and exact-f32 extra passes")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="CPU baseline at SURVEY 8d's sizes (8 systems x 50 steps and 64 x 1 step; ~10 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                                                       "testing the N>1 path with several ranks on one GPU)")
-    ap.add_argument("--cpu-systems", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
 
 
-def cpu_baseline(model_sd, scale_factors, n_sys, n_steps, params):
-    """Time the CPU oracle on `n_sys` systems x `n_steps` reverse steps of the same workload."""
+def launch_ranks(args) -> int:
+    """Parent of an N-rank run.  Must not initialise the GPU (no torch.cuda call, no exec): it only starts one
+    child per rank and waits.  Rank 0's stdout (the JSON line) is relayed; any failing child fails the run."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def cpu_baseline(model_sd, scale_factors, params, full=False):
+    """Time the CPU oracle (kind "port": oracle/painn_oracle.py, checked equal to the imported reference by
+    oracle/make_golden.py) on bounded samples of the same workload: a throughput sample (many systems, 1 reverse
+    step) and a loop sample (few systems, consecutive steps).  SURVEY 8d's sizes (64 x 1 and 8 x 50) with --cpu-full."""
+    import torch
+
     from adsorbdiff_amd.synthetic import make_batch
     from oracle import painn_oracle as O
 
-    b = make_batch(n_sys, seed=1000)
-    torch.manual_seed(0)
-    noise = torch.rand(n_sys, 3)
-    pos = O.initial_placement(b.pos.clone(), b.cell, b.tags, b.batch, noise)
-    t0 = time.perf_counter()
-    for t in range(n_steps):
-        f1, f2 = O.painn_forward(model_sd, pos, b.atomic_numbers, b.cell, b.natoms, cutoff=10.0, max_neighbors=50,
-                                 scale_factors=scale_factors)
-        pos, _, _, _ = O.reverse_step(pos, b.cell, b.tags, b.batch, f1, f2, b.fixed, t, params)
-    dt = time.perf_counter() - t0
-    sys_steps_per_s = n_sys * n_steps / dt
+    def run(n_sys, n_steps):
+        b = make_batch(n_sys, seed=1000)
+        torch.manual_seed(0)
+        noise = torch.rand(n_sys, 3)
+        pos = O.initial_placement(b.pos.clone(), b.cell, b.tags, b.batch, noise)
+        t0 = time.perf_counter()
+        for t in range(n_steps):
+            f1, f2 = O.painn_forward(model_sd, pos, b.atomic_numbers, b.cell, b.natoms, cutoff=10.0, max_neighbors=50,
+                                     scale_factors=scale_factors)
+            pos, _, _, _ = O.reverse_step(pos, b.cell, b.tags, b.batch, f1, f2, b.fixed, t, params)
+        dt = time.perf_counter() - t0
+        return {"systems": n_sys, "reverse_steps": n_steps, "seconds": round(dt, 2),
+                "sites_sha256_16": sites_digest,  # equal for every --gpus N under --scaling strong (same systems, same noise)
+            "system_steps_per_s": n_sys * n_steps / dt}
+
+    wide = run(64, 1) if full else run(12, 1)
+    loop = run(8, params["num_steps"]) if full else run(2, 4)
+    best = max(wide["system_steps_per_s"], loop["system_steps_per_s"])
     return {
-        "value": sys_steps_per_s / params["num_steps"],
+        "value": best / params["num_steps"],
         "unit": "sites/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{n_sys} systems x {n_steps} of {params['num_steps']} reverse steps in {dt:.1f} s "
-                  f"({sys_steps_per_s:.3f} system-steps/s), linearly extrapolated to {params['num_steps']} steps",
+        "sample": "%d systems x 1 reverse step in %.1f s (%.3f system-steps/s) and %d systems x %d consecutive steps "
+                  "in %.1f s (%.3f system-steps/s); value = the better rate / %d steps per site, i.e. LINEARLY "
+                  "EXTRAPOLATED to the 1000-system x %d-step workload" % (
+                      wide["systems"], wide["seconds"], wide["system_steps_per_s"], loop["systems"],
+                      loop["reverse_steps"], loop["seconds"], loop["system_steps_per_s"], params["num_steps"],
+                      params["num_steps"]),
+        "samples": [wide, loop],
     }
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))  # before anything touches the GPU
+    import torch
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        args.gpus = world
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -112,7 +161,7 @@ def main():
 
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.painn_denoising import PaiNN
-    from adsorbdiff_amd.sampler import gather_sites
+    from adsorbdiff_amd.sampler import gather_sites, shard_batch
     from adsorbdiff_amd.scaling import PAINN_NB6_SCALE_FACTORS
     from adsorbdiff_amd.synthetic import make_batch
     from adsorbdiff_amd.trainer import DenoisingTrainer
@@ -127,24 +176,34 @@ def main():
 
     if args.scaling == "weak":
         n_local = args.systems
-        first = rank * args.systems
+        batch0 = make_batch(n_local, seed=1000 + rank, sid_offset=rank * args.systems).to(dev)
+        my_ids = [rank * args.systems + i for i in range(n_local)]
     else:
-        base, rem = divmod(args.systems, world)
-        n_local = base + (1 if rank < rem else 0)
-        first = rank * base + min(rank, rem)
+        # the SAME synthetic batch on every rank count (seed 1000), dealt by atom count like the reference does
+        full = make_batch(args.systems, seed=1000)
+        if world > 1:
+            batch0, my_ids = shard_batch(full, rank, world)
+        else:
+            batch0, my_ids = full, list(range(args.systems))
+        n_local = len(my_ids)
+        batch0 = batch0.to(dev)
     total_systems = args.systems * world if args.scaling == "weak" else args.systems
-    batch0 = make_batch(n_local, seed=1000 + rank, sid_offset=first).to(dev)
     params = dict(num_steps=args.num_steps, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55,
                   ode=True, early_stop=False)
     eng = model.engine(dev)
+    # initial-placement uniforms keyed by global system id: an N-rank strong-scaling run samples exactly the sites
+    # of the 1-rank run (the reference draws torch.rand(B,3) per process, denoising_torch.py:215)
+    torch.manual_seed(0)
+    placement = torch.rand(total_systems, 3)[torch.tensor(my_ids, dtype=torch.long)]
 
     def one_pass(extra=None):
         b = batch0.clone()
         torch.manual_seed(0)
-        den = Denoiser(b, DiffTorchCalc(trainer), dict(params, **(extra or {})), device=str(dev))
+        den = Denoiser(b, DiffTorchCalc(trainer), dict(params, placement_noise=placement, **(extra or {})),
+                       device=str(dev))
         out = den.run()
         assert den.steps_applied == args.num_steps, den.steps_applied
-        return gather_sites(out, world)
+        return gather_sites(out, world, via=args.gather, system_ids=my_ids)
 
     def fence():
         if world > 1:
@@ -170,8 +229,8 @@ def main():
 
     # Secondary measurement, N = 1 only, never `value`: the same pass with the model outputs evaluated on the
     # adsorbate atoms only (the stepper reads nothing else; sampled positions are bit-identical, checked here).
-    ads_only = None
-    if world == 1:
+    ads_only = exact_f32 = None
+    if world == 1 and not args.no_secondary:
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         sites_ads = one_pass({"scores_on_adsorbate_only": True})
@@ -182,6 +241,33 @@ def main():
                     "note": "opt-in denoising_pos_params['scores_on_adsorbate_only']: last layer's message targets, its "
                             "update and the heads evaluated for tag-2 atoms only (adf_painn_forward_subset); one pass, "
                             "not part of `value`"}
+        # Reference-width arithmetic: one pass with every matrix-core product in exact f32
+        # (v_mfma_f32_32x32x2_f32; ADF_GEMM=f32 is read when a handle is created, so a second model + engine).
+        if "ADF_GEMM" not in os.environ and "ADF_MSG" not in os.environ:
+            os.environ["ADF_GEMM"] = "f32"
+            try:
+                torch.manual_seed(0)
+                model32 = PaiNN(None, 50, 1, hidden_channels=512, num_layers=6, num_rbf=128, cutoff=10.0,
+                                max_neighbors=50, scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True).eval()
+                trainer32 = DenoisingTrainer(model32, device=dev)
+                b = batch0.clone()
+                torch.manual_seed(0)
+                den = Denoiser(b, DiffTorchCalc(trainer32), dict(params, placement_noise=placement), device=str(dev))
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                sites32 = gather_sites(den.run(), 1)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t1
+                dev_max = float((sites32 - sites).abs().max())
+                exact_f32 = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
+                             "max_abs_site_difference_vs_f16x3_angstrom": dev_max,
+                             "note": "ADF_GEMM=f32: exact-f32 MFMA (v_mfma_f32_32x32x2_f32) in every GEMM and in the "
+                                     "message kernel; one cold pass (includes the first-step full graph build and "
+                                     "weight packing), not part of `value`"}
+                model32.engine(dev).close()
+                del model32, trainer32, den
+            finally:
+                del os.environ["ADF_GEMM"]
 
     if rank == 0:
         assert sites.shape[0] == total_systems, (sites.shape, total_systems)
@@ -200,16 +286,21 @@ def main():
         dense_equiv = dense_flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
         gathered_bytes = E * 5 * H * 4.0  # per edge: the source's gather record (xa, xc, P0, P1, P2 per channel), from L2
         hbm_alg_bytes = counters.message_bytes_per_layer - E * 3 * H * 4.0 + N_atoms * 4 * H * 4.0  # fused: no rbfh
-        traffic = None
+        traffic = traffic_src = None
         pmc = ROOT / "profiles" / "message_kernel_pmc.json"
-        if pmc.exists():
+        if pmc.exists():  # PMC counters need their own rocprofv3 passes: this is the committed result, not this run's
             try:
                 traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+                traffic_src = "static: profiles/message_kernel_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / " \
+                              "WRITE_SIZE passes of this command, 2*FETCH+WRITE per full-size launch); not measured in this run"
             except Exception:
                 traffic = None
         gpu_ms = {k: round(v[0] / args.steps, 2) for k, v in prof.items() if isinstance(v, tuple)}
         measured = eng.measure_peaks()  # stream copy + register-resident MFMA loops, on this box, after the timed region
         peak_meas = measured["mfma_f16_tflops"] if f16 else measured["mfma_f32_tflops"]
+        import hashlib
+
+        sites_digest = hashlib.sha256(torch.nan_to_num(sites).cpu().numpy().tobytes()).hexdigest()[:16]
         out = {
             "metric": METRIC,
             "value": total_systems * args.steps / elapsed,
@@ -232,12 +323,15 @@ def main():
                 "atoms_per_system": 200,
                 "edges_per_system": round(E / max(n_local, 1), 1),
                 "weights": "reference initialisers, seed 0, shipped scale factors",
-                "parallelism": "systems sharded over %d GPU(s), one all_gather of sites per pass" % world,
+                "parallelism": "systems sharded over %d GPU(s) by atom count, no data-path collective, one all_gather "
+                               "of sites per pass (%s)" % (world, "adf_allgather_sites, RCCL" if args.gather == "rccl"
+                                                           else "torch.distributed %s" % args.backend),
                 "loop_invariant_reuse": "slab-slab top-K candidates and layer-0 gather records (functions of the static "
                                         "slab / atomic numbers only) are computed at the first of the 50 steps of each "
                                         "pass and reused; every pass starts cold; bit-identical to recomputing "
                                         "(denoising_pos_params['static_atom_cache']=False)",
             },
+            "sites_sha256_16": sites_digest,  # equal for every --gpus N under --scaling strong (same systems, same noise)
             "system_steps_per_s": total_systems * args.steps * args.num_steps / elapsed,
             "gpu_ms_per_pass": gpu_ms,
             "roofline": {
@@ -251,6 +345,7 @@ def main():
                 "measured_peak": peak_meas,
                 "frac_of_measured_peak": issued / peak_meas if peak_meas > 0 else None,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_ms": avg_s * 1e3,
                 "launches": msg_launches,
                 "flops_per_launch": issued_flops_per_launch,
@@ -272,9 +367,10 @@ def main():
             },
             "measured_peaks": measured,
             "scores_on_adsorbate_only": ads_only,
+            "exact_f32": exact_f32,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cpu_sd, scale_factors, args.cpu_systems, args.cpu_steps, params)
+            out["cpu_baseline"] = cpu_baseline(cpu_sd, scale_factors, params, full=args.cpu_full)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -245,6 +245,21 @@ int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, int64_t* mess
  * register-resident loop on every CU with non-zero operands.  Measurement aid of bench.py, not on the sampling path. */
 int32_t adf_measure_peaks(float* out_host3, void* stream);
 
+/* Multi-GPU exchange of the sharded sampler: systems are independent, every rank samples its shard
+ * with no data-path collective, and ONE all-gather of the sampled adsorbate sites ends a pass.  Replaces the reference's
+ * per-rank .npz + barrier + rank-0 merge (trainers/sde_denoising_trainer.py:862-909).  RCCL is loaded lazily (dlopen).
+ *   adf_comm_unique_id   rank 0 draws a 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band
+ *                        (adsorbdiff_amd/sampler.py broadcasts it through torch.distributed);
+ *   adf_comm_create      collective over all ranks: one communicator per rank on the current device;
+ *   adf_allgather_sites  out[r*bytes_per_rank ..] = rank r's `local`; device pointers, enqueued on `stream`;
+ *                        every rank passes the same (padded) bytes_per_rank. */
+#define ADF_COMM_ID_BYTES 128
+typedef struct adf_comm* adf_comm_t;
+int32_t adf_comm_unique_id(uint8_t* out128);
+int32_t adf_comm_create(const uint8_t* id128, int32_t rank, int32_t world, adf_comm_t* out);
+int32_t adf_comm_destroy(adf_comm_t comm);
+int32_t adf_allgather_sites(adf_comm_t comm, const void* local, int64_t bytes_per_rank, void* out, void* stream);
+
 const char* adf_last_error(void);
 const char* adf_version(void);
 

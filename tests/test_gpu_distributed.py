@@ -1,0 +1,116 @@
+"""N>1 path with the HIP sampler: two ranks share cuda:0 (gloo backend — RCCL refuses two ranks on one device), each
+samples its shard of the same batch, and the gathered sites must equal the single-process run bit for bit.
+Reference being replaced: sde_denoising_trainer.py:862-909 (per-rank npz + merge), datasets/data_parallel.py:32-48."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from adsorbdiff_amd.data import Batch
+from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+from adsorbdiff_amd.painn_denoising import PaiNN
+from adsorbdiff_amd.sampler import gather_sites, shard_batch
+from adsorbdiff_amd.synthetic import make_batch
+from adsorbdiff_amd.trainer import DenoisingTrainer
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo")
+torch.manual_seed(0)
+model = PaiNN(None, 50, 1, hidden_channels=128, num_layers=2, cutoff=6.0, max_neighbors=20, so3_denoising=True).eval()
+trainer = DenoisingTrainer(model, device="cuda:0")
+full = Batch.from_data_list(make_batch(4, n_slab=36, n_ads=3, seed=5).to_data_list()
+                            + make_batch(3, n_slab=64, n_ads=4, seed=6).to_data_list())
+B = len(full.natoms)
+if world > 1:
+    mine, ids = shard_batch(full, rank, world)
+else:
+    mine, ids = full, list(range(B))
+torch.manual_seed(0)
+noise = torch.rand(B, 3)[torch.tensor(ids)]
+params = dict(num_steps=4, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+              early_stop=False, placement_noise=noise)
+out = Denoiser(mine.to("cuda:0"), DiffTorchCalc(trainer), params, device="cuda:0").run()
+sites = gather_sites(out, world, system_ids=ids)
+if rank == 0:
+    torch.save({"sites": sites.cpu(), "ids": ids}, sys.argv[2])
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+"""
+
+
+def _run(world, out, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(ROOT), str(out)], env=env))
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0] * world, codes
+    return torch.load(out)
+
+
+def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
+    one = _run(1, tmp_path / "w1.pt", tmp_path)
+    two = _run(2, tmp_path / "w2.pt", tmp_path)
+    assert one["sites"].shape == (7, 4, 3) and sorted(two["ids"]) != list(range(7))
+    assert torch.equal(torch.nan_to_num(one["sites"]), torch.nan_to_num(two["sites"]))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 --backend gloo` on one GPU: n_gpus 2 in the JSON line, same sites as --gpus 1."""
+    def bench(n):
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--backend", "gloo", "--systems", "6",
+               "--num-steps", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return json.loads(res.stdout.strip().splitlines()[-1])
+
+    a, b = bench(1), bench(2)
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "strong"
+    assert b["config"]["systems_total"] == 6 and b["config"]["systems_per_gpu"] == 3
+    assert a["sites_sha256_16"] == b["sites_sha256_16"]
+
+
+def test_rccl_allgather_c_abi_single_rank():
+    """adf_comm_* / adf_allgather_sites through RCCL with a 1-rank communicator (all this box can host)."""
+    import ctypes as C
+
+    from adsorbdiff_amd import lib as L
+
+    lib = L.load()
+    buf = (C.c_uint8 * 128)()
+    L.check(lib.adf_comm_unique_id(buf))
+    comm = C.c_void_p()
+    L.check(lib.adf_comm_create(buf, 0, 1, C.byref(comm)))
+    x = torch.randn(5, 4, 3, device="cuda:0")
+    y = torch.empty(1, 5, 4, 3, device="cuda:0")
+    L.check(lib.adf_allgather_sites(comm, x.data_ptr(), x.numel() * 4, y.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(y[0], x)
+    L.check(lib.adf_comm_destroy(comm))

@@ -439,6 +439,99 @@ def test_weight_update_is_picked_up():
     assert rel_err(h1, f1) < 1e-6
 
 
+def test_ema_param_data_copy_is_picked_up():
+    """The reference's EMA writes through param.data.copy_ (modules/exponential_moving_average.py:113,147), which
+    bumps no autograd version counter: the engine key fingerprints the contents.  An engine that already packed the
+    raw weights must sample with the EMA weights inside the EMA scope and with the raw ones after restore()."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.exponential_moving_average import ExponentialMovingAverage
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("painn_small.npz")
+    m = small_model(fx)
+    b = batch_from_fixture(fx, device=DEV)
+    raw1, _ = m(b)                                   # engine created and packed with the raw weights
+    ema = ExponentialMovingAverage(m.parameters(), 0.5)
+    with torch.no_grad():
+        for s_ in ema.shadow_params:
+            s_.mul_(0.9)                             # shadow != raw
+    versions = [p._version for p in m.parameters()]
+    ema.store(); ema.copy_to()
+    assert [p._version for p in m.parameters()] == versions  # the hazard: nothing autograd-visible changed
+    in_scope, _ = m(b)
+    ref = small_model(fx)                            # a second model that simply holds the shadow weights
+    with torch.no_grad():
+        for p, s_ in zip([q for q in ref.parameters() if q.requires_grad], ema.shadow_params):
+            p.copy_(s_)
+    want, _ = ref(b)
+    assert rel_err(in_scope, raw1) > 1e-3 and torch.equal(in_scope, want)
+    ema.restore()
+    raw2, _ = m(b)
+    assert torch.equal(raw2, raw1)
+    # sampler: a trainer with an EMA samples with the shadow weights although the engine was bound to the raw ones
+    params = dict(num_steps=3, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+                  early_stop=False)
+    torch.manual_seed(3)
+    a = Denoiser(batch_from_fixture(fx, device=DEV), DiffTorchCalc(DenoisingTrainer(m, device=DEV, ema=ema)), params,
+                 device=DEV).run().pos.clone()
+    torch.manual_seed(3)
+    c = Denoiser(batch_from_fixture(fx, device=DEV), DiffTorchCalc(DenoisingTrainer(ref, device=DEV)), params,
+                 device=DEV).run().pos.clone()
+    assert torch.equal(a, c)
+    raw3, _ = m(b)
+    assert torch.equal(raw3, raw1)
+
+
+def test_bad_atomic_number_is_reported():
+    """Z outside the embedding table raises instead of reading out of bounds (torch's nn.Embedding: IndexError)."""
+    fx = load_npz("painn_small.npz")
+    m = small_model(fx)
+    b = batch_from_fixture(fx, device=DEV)
+    b.atomic_numbers = b.atomic_numbers.clone()
+    b.atomic_numbers[0] = 0
+    with pytest.raises(ValueError, match="atomic number"):
+        m(b)
+    b.atomic_numbers[0] = 200
+    with pytest.raises(ValueError, match="atomic number"):
+        m(b)
+    m(batch_from_fixture(fx, device=DEV))  # flags were cleared by the failed checks
+
+
+def test_hub_atom_with_many_incoming_edges():
+    """In-degree is not bounded by 2K (only sum(deg) <= 2NK): a hub listed by > 256 centres takes the register path
+    of the per-target sorter; the message layer must still match the oracle."""
+    import math
+
+    from oracle import painn_oracle as O
+
+    from adsorbdiff_amd.data import Batch
+
+    torch.manual_seed(11)
+    n, K, rc = 900, 120, 12.0
+    # log-uniform radii around a hub atom, isotropic directions: the hub is among the K nearest of many centres
+    # (272 incoming edges with this seed), the other atoms see 100-200
+    r = torch.exp(torch.rand(n - 1) * math.log(11.0 / 0.02)) * 0.02
+    pos = torch.zeros(n, 3)
+    pos[1:] = torch.nn.functional.normalize(torch.randn(n - 1, 3), dim=1) * r[:, None]
+    b = Batch()
+    b.pos = (pos + 50.0).float(); b.atomic_numbers = torch.randint(1, 80, (n,)).float()
+    b.tags = torch.ones(n, dtype=torch.long); b.fixed = torch.zeros(n, dtype=torch.long)
+    b.cell = (torch.eye(3) * 100.0).reshape(1, 3, 3); b.natoms = torch.tensor([n]); b.batch = torch.zeros(n, dtype=torch.long)
+    b.sid = ["hub"]
+    torch.manual_seed(0)
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=2, cutoff=rc, max_neighbors=K, so3_denoising=True).to(DEV).eval()
+    f1, f2 = m(b.to(DEV))
+    eng = m.engine()
+    eng.build_graph(b.to(DEV))
+    _, _, _, es, ed, _, _ = eng.export_graph()
+    indeg = torch.bincount(ed.long().cpu(), minlength=n)
+    assert int(indeg.max()) > 256, int(indeg.max())
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    o1, o2 = O.painn_forward(sd, b.pos.cpu(), b.atomic_numbers.cpu(), b.cell.cpu(), b.natoms.cpu(), cutoff=rc,
+                             max_neighbors=K, scale_factors=m.scale_factors())
+    assert rel_err(f1.cpu(), o1) < REL_TOL and rel_err(f2.cpu(), o2) < REL_TOL
+
+
 def test_calculator_single_structure_api():
     """AdsorbDiffCalculator.run_diffusion on one structure == Denoiser on the same system and seed."""
     from adsorbdiff_amd.calculator import AdsorbDiffCalculator, SimpleAtoms
