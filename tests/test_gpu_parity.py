@@ -527,8 +527,8 @@ def test_hub_atom_with_many_incoming_edges():
     indeg = torch.bincount(ed.long().cpu(), minlength=n)
     assert int(indeg.max()) > 256, int(indeg.max())
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
-    o1, o2 = O.painn_forward(sd, b.pos.cpu(), b.atomic_numbers.cpu(), b.cell.cpu(), b.natoms.cpu(), cutoff=rc,
-                             max_neighbors=K, scale_factors=m.scale_factors())
+    o1, o2 = O.painn_forward(sd, b.pos.cpu(), b.atomic_numbers.cpu(), b.cell.cpu(), b.natoms.cpu(), hidden_channels=128,
+                             num_layers=2, cutoff=rc, max_neighbors=K, scale_factors=m.scale_factors())
     assert rel_err(f1.cpu(), o1) < REL_TOL and rel_err(f2.cpu(), o2) < REL_TOL
 
 
