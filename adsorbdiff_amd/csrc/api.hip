@@ -143,6 +143,8 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         h->gemm_f32 = e && strcmp(e, "f32") == 0;
         const char* e2 = getenv("ADF_MSG");
         h->msg_f32 = e2 ? strcmp(e2, "f32") == 0 : h->gemm_f32;
+        const char* e3 = getenv("ADF_MSG_KERNEL");
+        h->msg_v1 = e3 && strcmp(e3, "v1") == 0;
     }
     if (st == ADF_OK) st = dev_alloc(&h->kcount, 1);
     if (st == ADF_OK && hipMemset(h->kcount, 0, sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;
@@ -154,7 +156,7 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
 static void free_workspaces(adf_painn* h) {
     void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
                     h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec,
-                    h->cache_d2, h->cache_cid, h->cache_cnt};
+                    h->cache_d2, h->cache_cid, h->cache_cnt, h->atab};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->nbr_cnt = h->nbr_src = h->nbr_shift = h->deg = h->nptr = h->cursor = h->img_cnt = h->e_src = nullptr;
@@ -162,6 +164,7 @@ static void free_workspaces(adf_painn* h) {
     h->e_geom = nullptr;
     h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = h->rec = nullptr;
     h->cache_d2 = nullptr; h->cache_cid = nullptr; h->cache_cnt = nullptr; h->cache_valid = false;
+    h->atab = nullptr; h->atab_valid = false;
     h->capN = h->capB = h->capE = 0;
 }
 
@@ -218,6 +221,7 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
             bw.un2_b = f(k++);
         }
     ADF_TRY(adf_pack_rbf(h, (hipStream_t)stream));
+    ADF_TRY(adf_message32_prepare());
     {   // split every GEMM weight into fp16 hi/lo (gemm16.hip)
         hipStream_t s = (hipStream_t)stream;
         const long long H = h->hp.hidden_channels, HH = H * H;
@@ -292,6 +296,10 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
     ALLOC(img_cnt, capB);
     ALLOC(e_src, capE);
     ALLOC(e_geom, capE);
+    if (!h->msg_f32 && !h->msg_v1) {
+        ALLOC(atab, capE * 96 + 64);
+        if (st == ADF_OK && hipMemsetAsync(h->atab, 0, 64, 0) != hipSuccess) st = ADF_EHIP;
+    }
     if (st == ADF_OK) {
         h->scan_tmp_bytes = adf_scan_temp_bytes(capN + 1);
         unsigned char* tmp = nullptr;
@@ -442,7 +450,9 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
         adf_prof_end(h, s);
     }
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
-    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec);
+    const int32_t st = (h->msg_f32 || h->msg_v1)
+        ? adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec)
+        : adf_message32_impl(h, l, N, x, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec);
     adf_prof_end(h, s);
     return st;
 }

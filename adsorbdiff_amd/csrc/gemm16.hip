@@ -46,7 +46,7 @@ __device__ __forceinline__ float ssilu16(float x) {
 //   linear layer for the SAME 32 channels (weights row-permuted at set_weights:
 //   column g*96 + part*32 + q  <->  original row part*H + 32g + q), so the consumer's elementwise
 //   work runs on the accumulators and the 3H-wide intermediate never goes to HBM:
-//     EPI 1  x_proj.2 -> gather records of the message kernel (xa, xc, P_i = vec_i * xb; message.hip)
+//     EPI 1  x_proj.2 -> gather records of the message kernel ((P0,P1,P2,xa) + xc, P_i = vec_i * xb; message.hip)
 //     EPI 2  xvec_proj.2 -> PaiNNUpdate gating + residuals + ScaleFactor (painn_denoising.py:614-623,449-451)
 //   MI=3, NJ=2 with EPI 3: vec_proj of PaiNNUpdate (painn_denoising.py:602-611).  The A rows of vec [N,3,H] are
 //   staged component-major (LDS row = component*32 + atom), so accumulator block i of a wave is component i of
@@ -375,22 +375,21 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                     const float4 p1 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 32 + 4 * c4);
                     const float4 p2 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 64 + 4 * c4);
                     if (n < M) {
-                        // half-record of (atom n, group g): [32 x (xa, xc, P0, P1)] then [32 x P2]
+                        // half-record of (atom n, group g): [32 x (P0, P1, P2, xa)] then [32 x xc]
                         float* rec = ep.rec + ((size_t)n * (H / 32) + g) * 160;
                         float4* ra_ = reinterpret_cast<float4*>(rec + 16 * c4);
                         if (!ep.vec_is_zero) {
-                            ra_[0] = make_float4(p0.x, p2.x, v0[it].x * p1.x, v1[it].x * p1.x);
-                            ra_[1] = make_float4(p0.y, p2.y, v0[it].y * p1.y, v1[it].y * p1.y);
-                            ra_[2] = make_float4(p0.z, p2.z, v0[it].z * p1.z, v1[it].z * p1.z);
-                            ra_[3] = make_float4(p0.w, p2.w, v0[it].w * p1.w, v1[it].w * p1.w);
-                            *reinterpret_cast<float4*>(rec + 128 + 4 * c4) =
-                                make_float4(v2[it].x * p1.x, v2[it].y * p1.y, v2[it].z * p1.z, v2[it].w * p1.w);
+                            ra_[0] = make_float4(v0[it].x * p1.x, v1[it].x * p1.x, v2[it].x * p1.x, p0.x);
+                            ra_[1] = make_float4(v0[it].y * p1.y, v1[it].y * p1.y, v2[it].y * p1.y, p0.y);
+                            ra_[2] = make_float4(v0[it].z * p1.z, v1[it].z * p1.z, v2[it].z * p1.z, p0.z);
+                            ra_[3] = make_float4(v0[it].w * p1.w, v1[it].w * p1.w, v2[it].w * p1.w, p0.w);
                         } else {
-                            ra_[0] = make_float4(p0.x, p2.x, 0.f, 0.f);
-                            ra_[1] = make_float4(p0.y, p2.y, 0.f, 0.f);
-                            ra_[2] = make_float4(p0.z, p2.z, 0.f, 0.f);
-                            ra_[3] = make_float4(p0.w, p2.w, 0.f, 0.f);
+                            ra_[0] = make_float4(0.f, 0.f, 0.f, p0.x);
+                            ra_[1] = make_float4(0.f, 0.f, 0.f, p0.y);
+                            ra_[2] = make_float4(0.f, 0.f, 0.f, p0.z);
+                            ra_[3] = make_float4(0.f, 0.f, 0.f, p0.w);
                         }
+                        *reinterpret_cast<float4*>(rec + 128 + 4 * c4) = p2;
                     }
                 }
             } else {

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const float inv_sqrt_h = out_scale / sqrtf((float)H);
     const float umax_scale = (float)(p.R - 1);
     const float coeff2 = p.coeff * 1.44269504088896341f;  // exp(c z) = exp2(c log2e z)
-    // one record row = H/32 half-records of 640 B: [32 x (xa, xc, P0, P1)] + [32 x P2] for 32 channels, read as one
+    // one record row = H/32 half-records of 640 B: [32 x (P0, P1, P2, xa)] + [32 x xc] for 32 channels, read as one
     // dwordx4 + one dword per lane (12-B-per-lane loads gather at 0.7x the rate of this split: measured 20 vs 28 TB/s).
     // Lane q owns channels c0+q (half-record 2*slice) and c0+32+q (half-record 2*slice+1).
     const unsigned int row_bytes = (unsigned int)p.nslices * 1280u;
@@ -252,28 +252,27 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 #define GATHER(r)                                                                               \
     const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
     const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
-    float4 ga0##r, ga1##r;                                     /* xa xc P0 P1 of channel j = 0, 1 */ \
-    float gz0##r = 0.f, gz1##r = 0.f;                          /* P2 */                               \
+    float4 ga0##r, ga1##r;                                     /* P0 P1 P2 xa of channel j = 0, 1 */ \
+    float gz0##r, gz1##r;                                      /* xc */                               \
+    gz0##r = *reinterpret_cast<const float*>(recP + o##r);                                      \
+    gz1##r = *reinterpret_cast<const float*>(recP + o##r + 640);                                \
     if (!VZ) {                                                                                  \
         ga0##r = *reinterpret_cast<const float4*>(recA + o##r);                                 \
         ga1##r = *reinterpret_cast<const float4*>(recA + o##r + 640);                           \
-        gz0##r = *reinterpret_cast<const float*>(recP + o##r);                                  \
-        gz1##r = *reinterpret_cast<const float*>(recP + o##r + 640);                            \
     } else {                                                                                    \
-        const float2 t0 = *reinterpret_cast<const float2*>(recA + o##r);                        \
-        const float2 t1 = *reinterpret_cast<const float2*>(recA + o##r + 640);                  \
-        ga0##r = make_float4(t0.x, t0.y, 0.f, 0.f); ga1##r = make_float4(t1.x, t1.y, 0.f, 0.f); \
+        ga0##r = make_float4(0.f, 0.f, 0.f, *reinterpret_cast<const float*>(recA + o##r + 12)); \
+        ga1##r = make_float4(0.f, 0.f, 0.f, *reinterpret_cast<const float*>(recA + o##r + 652)); \
     }
 #define CONSUME(r)                                                                              \
     {                                                                                           \
         const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
-        const float t3 = ga0##r.y * acc[4][r];                                                  \
-        sx0 += ga0##r.x * acc[0][r];                                                            \
-        if (!VZ) { sa0 += ga0##r.z * acc[2][r]; sb0 += ga0##r.w * acc[2][r]; sc0 += gz0##r * acc[2][r]; } \
+        const float t3 = gz0##r * acc[4][r];                                                    \
+        sx0 += ga0##r.w * acc[0][r];                                                            \
+        if (!VZ) { sa0 += ga0##r.x * acc[2][r]; sb0 += ga0##r.y * acc[2][r]; sc0 += ga0##r.z * acc[2][r]; } \
         ra0 += t3 * ux; rb0 += t3 * uy; rc0 += t3 * uz;                                         \
-        const float u3 = ga1##r.y * acc[5][r];                                                  \
-        sx1 += ga1##r.x * acc[1][r];                                                            \
-        if (!VZ) { sa1 += ga1##r.z * acc[3][r]; sb1 += ga1##r.w * acc[3][r]; sc1 += gz1##r * acc[3][r]; } \
+        const float u3 = gz1##r * acc[5][r];                                                    \
+        sx1 += ga1##r.w * acc[1][r];                                                            \
+        if (!VZ) { sa1 += ga1##r.x * acc[3][r]; sb1 += ga1##r.y * acc[3][r]; sc1 += ga1##r.z * acc[3][r]; } \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
             // rows 0-3: issued before the MFMA loop, they land while the matrix pipe is busy
@@ -454,7 +453,7 @@ __global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsi
 
 // Gather records of the message kernel (stand-alone producer, used by the exact-f32 mode; the f16x3
 // mode writes the same layout from the x_proj.2 GEMM epilogue, gemm16.hip EPI 1).  Per source atom n and
-// group g of 32 channels, 640 B:  [32 lanes][xa(c), xc(c), P0(c), P1(c)]  then  [32 lanes][P2(c)],
+// group g of 32 channels, 640 B:  [32 lanes][P0(c), P1(c), P2(c), xa(c)]  then  [32 lanes][xc(c)],
 // c = 32 g + lane, xa/xb/xc = the three H-wide parts of xh, P_i = vec_i * xb.  vec*xb is the only place
 // vec[src] and xb[src] enter the message (painn_denoising.py:549-552), so the per-edge gather shrinks
 // from 6 to 5 floats per channel and every piece a half-wave reads is one contiguous run of the source row.
@@ -473,11 +472,11 @@ __global__ void adf_pack_records_kernel(const float* __restrict__ xh, const floa
         float* out = rec + ((size_t)n * ng + g) * 160;
         if (!vec_is_zero) {
             const float* vr = vec + (size_t)n * 3 * H;
-            reinterpret_cast<float4*>(out)[qq] = make_float4(xa, xc, vr[c] * xb, vr[H + c] * xb);
-            out[128 + qq] = vr[2 * H + c] * xb;
+            reinterpret_cast<float4*>(out)[qq] = make_float4(vr[c] * xb, vr[H + c] * xb, vr[2 * H + c] * xb, xa);
         } else {
-            reinterpret_cast<float4*>(out)[qq] = make_float4(xa, xc, 0.f, 0.f);
+            reinterpret_cast<float4*>(out)[qq] = make_float4(0.f, 0.f, 0.f, xa);
         }
+        out[128 + qq] = xc;
     }
 }
 
