@@ -144,7 +144,7 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         const char* e2 = getenv("ADF_MSG");
         h->msg_f32 = e2 ? strcmp(e2, "f32") == 0 : h->gemm_f32;
         const char* e3 = getenv("ADF_MSG_KERNEL");
-        h->msg_v1 = e3 && strcmp(e3, "v1") == 0;
+        h->msg_v1 = !(e3 && strcmp(e3, "v2") == 0);  // v2 = message32.hip (experimental; measured slower: DESIGN.md 4)
     }
     if (st == ADF_OK) st = dev_alloc(&h->kcount, 1);
     if (st == ADF_OK && hipMemset(h->kcount, 0, sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;

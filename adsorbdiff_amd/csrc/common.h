@@ -123,7 +123,8 @@ struct adf_painn {
     // radial-basis MFMA operand per edge, fp16 hi/lo (message32.hip): 64 zero bytes, then [capE][96 B]
     unsigned char* atab;
     bool atab_valid;     // built for the handle's current graph
-    bool msg_v1;         // ADF_MSG_KERNEL=v1: first-generation f16 message kernel (message.hip)
+    bool rbf_uniform;    // Gaussian centres are k/(R-1): the message kernel may use its recurrence (ADF_MSG_RBF=direct: never)
+    bool msg_v1;         // default; ADF_MSG_KERNEL=v2 selects message32.hip (experimental)
     // Layer-0 gather records depend on the atomic numbers only (x0 = emb(Z), vec0 = 0).  While a static-atom
     // promise is in force (adf_graph_set_moving: same batch, only flagged atoms move) they are computed once.
     float* rec0;

@@ -35,6 +35,9 @@
 //                W·s = w_hi + w_lo in LDS as [col][k] halves, v_mfma_f32_32x32x16_f16 x 3 products,
 //                fp32 accumulate; the k-window is aligned to 8 and contracted 16 k at a time.
 //   F16 = false (ADF_GEMM=f32): exact f32 v_mfma_f32_32x32x2_f32, window contracted 2 k at a time.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,6 +66,7 @@ struct MsgParams {
     const float* mu;
     int N, H, R, G, nslices;
     float inv_cutoff, coeff, sarg, env_a, env_b, env_c;
+    float dmu2, dmusq, cstep;  // UNI: 2*dmu', dmu'^2, exp2(-2 dmu'^2) with dmu' = scaled spacing of the centres
     int env_pi;
     unsigned long long* kcount;  // optional: sum over 32-row blocks of the contracted k length (profiling)
 };
@@ -81,7 +85,9 @@ __device__ __forceinline__ float wave_max(float v) {
 #define MSG_WAVES_PER_SIMD 2
 // VZ = true: vec is identically zero on entry (first layer, painn_denoising.py:426) — its gathers,
 // the vec*b sums and the residual read are skipped.
-template <bool F16, bool VZ>
+// UNI: the Gaussian centres are equally spaced (GaussianSmearing's linspace, radial_basis.py:64-82; checked by the host):
+// the 8 basis values of a lane and k-step then follow from two exp2 by a multiplicative recurrence (see below).
+template <bool F16, bool VZ, bool UNI>
 __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_kernel(MsgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // carve: weight image | [192] bias | [128] mu | [8 waves][32][8] row meta | work counter
@@ -303,10 +309,37 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                 int k0 = klo;
                 do {  // at least one step: lets the accumulators live in place across the loop
                     // A fragment: lane (row q, half hi) holds k = k0 + 8*hi + j, j = 0..7
+                    half8 ah, al;
+                    if constexpr (UNI) {
+                        // a_j = E exp2(-(t - j d)^2), t = xs' - mu'_{k0+8hi}:  a_{j+1} = a_j r_j,  r_j = exp2(2 d (t - j d) - d^2),
+                        // r_{j+1} = r_j exp2(-2 d^2).  Two exp2 + 16 multiplications instead of 8 x (sub, mul, exp2, mul); the
+                        // products carry <= 14 roundings (1e-6 relative, the size of the f16x3 split error).  If a_0
+                        // underflows, every a_j of the group is below 2^-39 of the row's leading term (dropped like the
+                        // terms outside the k-window).  hi/lo split: packed round-to-zero conversions (lo absorbs the
+                        // truncation exactly) - 4 instructions per pair instead of 8.
+                        const float t0 = xsq - Mu[k0 + 8 * hi];
+                        float a = env256 * __builtin_amdgcn_exp2f(-(t0 * t0));
+                        // (clamped: far right of the group r would overflow while a_0 has long underflowed to 0: 0 * inf)
+                        float r = __builtin_amdgcn_exp2f(fminf(p.dmu2 * t0 - p.dmusq, 64.0f));
+                        float av[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            av[j] = a;
+                            a *= r;
+                            r *= p.cstep;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+                            const h2_t hh = __builtin_amdgcn_cvt_pkrtz(av[j], av[j + 1]);
+                            const h2_t ll = __builtin_amdgcn_cvt_pkrtz(av[j] - (float)hh[0], av[j + 1] - (float)hh[1]);
+                            ah[j] = (_Float16)hh[0]; ah[j + 1] = (_Float16)hh[1];
+                            al[j] = (_Float16)ll[0]; al[j + 1] = (_Float16)ll[1];
+                        }
+                    } else {
                     const float4 mu0 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi);
                     const float4 mu1 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi + 4);
                     const float mus[8] = {mu0.x, mu0.y, mu0.z, mu0.w, mu1.x, mu1.y, mu1.z, mu1.w};
-                    half8 ah, al;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float dm = xsq - mus[j];
@@ -316,6 +349,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                         const _Float16 h = (_Float16)a;
                         ah[j] = h;
                         al[j] = (_Float16)(a - (float)h);
+                    }
                     }
                     const _Float16* wh = Wh + (size_t)q * MSG_LDK + k0 + 8 * hi;
                     const _Float16* wl = Wlo + (size_t)q * MSG_LDK + k0 + 8 * hi;
@@ -498,6 +532,15 @@ static size_t msg_lds_bytes(int R, bool f16) {
 
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
+    {   // are the Gaussian centres the linspace(0, 1, R) of GaussianSmearing?  (a buffer, but a checkpoint may carry another)
+        float mu[128];
+        ADF_HIP_CHECK(hipMemcpyAsync(mu, h->rbf_offset, sizeof(float) * R, hipMemcpyDeviceToHost, s));
+        ADF_HIP_CHECK(hipStreamSynchronize(s));
+        bool uni = true;
+        for (int k = 0; k < R; ++k) uni = uni && fabsf(mu[k] - (float)k / (float)(R - 1)) <= 2e-7f;
+        const char* e = getenv("ADF_MSG_RBF");
+        h->rbf_uniform = uni && !(e && strcmp(e, "direct") == 0);
+    }
     const size_t per_layer = (size_t)(H / ADF_SLICE_CH) * R * MSG_COLS;
     const size_t per_layer_b = (size_t)(H / ADF_SLICE_CH) * MSG_COLS;
     for (int l = 0; l < h->hp.num_layers; ++l) {
@@ -515,10 +558,11 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
     }
     ADF_HIP_CHECK(hipGetLastError());
     {   // per device (a function attribute is per device; set_weights is rare, so no caching)
-#define SET_LDS(F16_, VZ_)                                                                                    \
-    ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<F16_, VZ_>),           \
+#define SET_LDS(F16_, VZ_, UNI_)                                                                              \
+    ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_kernel<F16_, VZ_, UNI_>),     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)msg_lds_bytes(128, F16_)))
-        SET_LDS(false, false); SET_LDS(false, true); SET_LDS(true, false); SET_LDS(true, true);
+        SET_LDS(false, false, false); SET_LDS(false, true, false); SET_LDS(true, false, false); SET_LDS(true, true, false);
+        SET_LDS(true, false, true); SET_LDS(true, true, true);
 #undef SET_LDS
     }
     return ADF_OK;
@@ -560,10 +604,15 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     if (workers < 1) workers = 1;
     if (workers > p.G) workers = p.G;
     dim3 grid((unsigned)(workers * p.nslices));
-#define LAUNCH_MSG(F16_, VZ_)                                                                              \
-    hipLaunchKernelGGL((adf_message_kernel<F16_, VZ_>), grid, dim3(MSG_THREADS), msg_lds_bytes(R, F16_), s, p)
-    if (f16) { if (vec_is_zero) LAUNCH_MSG(true, true); else LAUNCH_MSG(true, false); }
-    else { if (vec_is_zero) LAUNCH_MSG(false, true); else LAUNCH_MSG(false, false); }
+#define LAUNCH_MSG(F16_, VZ_, UNI_)                                                                        \
+    hipLaunchKernelGGL((adf_message_kernel<F16_, VZ_, UNI_>), grid, dim3(MSG_THREADS), msg_lds_bytes(R, F16_), s, p)
+    {   // scaled spacing of the (equally spaced) centres: mu_k = k / (R - 1)
+        const double d = sqrt(0.5 / (step * step) * 1.4426950408889634) * step;
+        p.dmu2 = (float)(2.0 * d); p.dmusq = (float)(d * d); p.cstep = (float)exp2(-2.0 * d * d);
+    }
+    if (f16 && h->rbf_uniform) { if (vec_is_zero) LAUNCH_MSG(true, true, true); else LAUNCH_MSG(true, false, true); }
+    else if (f16) { if (vec_is_zero) LAUNCH_MSG(true, true, false); else LAUNCH_MSG(true, false, false); }
+    else { if (vec_is_zero) LAUNCH_MSG(false, true, false); else LAUNCH_MSG(false, false, false); }
 #undef LAUNCH_MSG
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
