@@ -45,7 +45,7 @@ extern "C" int32_t adf_profile_enable(adf_painn_t h, int32_t on) {
     h->prof_on = on != 0;
     h->prof_used = 0;
     h->prof_cat->clear();
-    ADF_HIP_CHECK(hipMemset(h->kcount, 0, sizeof(unsigned long long)));
+    ADF_HIP_CHECK(hipMemset(h->kcount, 0, 8 * sizeof(unsigned long long)));
     return ADF_OK;
 }
 
@@ -53,10 +53,13 @@ extern "C" int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, in
     if (!h || !ms || !count) { adf_set_error("null argument"); return ADF_EINVAL; }
     ADF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     if (message_ksteps) {
-        unsigned long long k = 0;
-        ADF_HIP_CHECK(hipMemcpy(&k, h->kcount, sizeof(k), hipMemcpyDeviceToHost));
+        unsigned long long k[8];
+        ADF_HIP_CHECK(hipMemcpy(k, h->kcount, sizeof(k), hipMemcpyDeviceToHost));
         ADF_HIP_CHECK(hipMemset(h->kcount, 0, sizeof(k)));
-        *message_ksteps = (int64_t)k;
+        *message_ksteps = (int64_t)k[0];
+        if (k[1])  // development builds of message32.hip (-DM32_STAMP): wave cycles per segment of the block body
+            fprintf(stderr, "m32 stamps: S0 %llu  S1 %llu  finish %llu  S2 %llu  S3 %llu  S4 %llu  rotate %llu\n", k[1], k[2], k[3], k[4],
+                    k[5], k[6], k[7]);
     }
     for (int c = 0; c < ADF_PROF_NCAT; ++c) { ms[c] = 0.f; count[c] = 0; }
     const size_t pairs = h->prof_used / 2;
@@ -146,8 +149,8 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         const char* e3 = getenv("ADF_MSG_KERNEL");
         h->msg_v1 = !(e3 && strcmp(e3, "v2") == 0);  // v2 = message32.hip (experimental; measured slower: DESIGN.md 4)
     }
-    if (st == ADF_OK) st = dev_alloc(&h->kcount, 1);
-    if (st == ADF_OK && hipMemset(h->kcount, 0, sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;
+    if (st == ADF_OK) st = dev_alloc(&h->kcount, 8);
+    if (st == ADF_OK && hipMemset(h->kcount, 0, 8 * sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;
     if (st != ADF_OK) { adf_painn_destroy(h); return st; }
     *out = h;
     return ADF_OK;

@@ -20,6 +20,8 @@
 // Gather record of (source atom, 32 channels), 640 B: [32 x (P0, P1, P2, xa)] + [32 x xc], P_i = vec_i * xb
 // (gemm16.hip EPI 1).  Tile order b -> a -> c: tile b consumes quad.xyz, tile a quad.w (after which the quad of the
 // NEXT block's same row is requested into the same registers), tile c the xc dword (same rolling refill).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -124,6 +126,19 @@ __device__ __forceinline__ T ld32(const void* base, unsigned int off) {
 // gather of one record piece; with the ablation bit the register keeps its value (the asm keeps the address alive)
 #define M32_GATHER(dst, T, off)                                                    \
     if (M32_ABL & 2) { asm volatile("" ::"v"(off)); } else { dst = ld32<T>(recB, off); }
+// CSR bounds of a target by a SCALAR load.  hipcc proves the address uniform and wants the result in SGPRs; written
+// as a plain load it emits global_load + s_waitcnt vmcnt(0) + v_readfirstlane on the spot - a full drain of the
+// gather pipeline per target (measured: 1300 cycles per block).  The scalar load counts on lgkmcnt instead.  Load
+// and wait sit in ONE asm statement: the compiler does not know that an asm output arrives later and may copy or
+// spill the SGPR pair in between (seen: wild CSR bounds -> memory fault), so the ~200-cycle scalar-cache round trip
+// per target is paid in place.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i32x2 sload2(const int32_t* ptr) {
+    i32x2 v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ void st32(void* base, unsigned int off, T v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off) = v;
@@ -167,6 +182,9 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
             if (piece == 16 && hl == 0) { v[0] = b16[2 * scol]; v[1] = b16[2 * scol + 1]; }
             *reinterpret_cast<half8*>(Wh + (size_t)row * M32_LDK + piece * 8) = v;
         }
+        // meta buffers start zeroed: the first block's pipeline consumes a non-existent previous tile as 0 * (unit
+        // vector read from the still unwritten buffer) - leftover LDS bits may be NaN / inf
+        for (int i = tid; i < M32_WAVES * 256; i += M32_THREADS) Meta[i] = 0.f;
         if (tid == 0) *Ctr = 0;
     }
     __syncthreads();
@@ -185,6 +203,13 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
     const unsigned int laneX = (unsigned int)slice * 640u + 512u + (unsigned int)q * 4u;
     const _Float16* wbase = Wh + (size_t)q * M32_LDK + 8 * hi;  // + part*32*LDK + k0 ; lo image at + 96*LDK
     unsigned int ksteps = 0;
+#ifdef M32_STAMP  // development: wave cycles per segment of the block body, summed into p.kcount[1..7]
+    unsigned long long st_[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_[i] += n_ - st_t; st_t = n_; }
+#else
+#define STAMP(i)
+#endif
     half8 aone = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hi == 0) { aone[0] = (_Float16)256.0f; aone[1] = (_Float16)256.0f; }
 
@@ -204,16 +229,17 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
             const int g = xcd * p.Gx + gl;
             if (gl >= p.Gx || g >= p.G) return false;
             const int e = g * 32 + (t & 31);
-            if (e < p.items) { o_out = e; n_out = p.tlist ? p.tlist[e] : e; return true; }
+            if (e < p.items) { o_out = e; n_out = p.tlist ? __builtin_amdgcn_readfirstlane(p.tlist[e]) : e; return true; }
         }
     };
     // generator state: current target (edges gen_e .. gen_e1) and the one after it (bounds requested one target ahead)
     int gen_n = 0, gen_o = 0, gen_e = 0, gen_e1 = 0;
     bool gen_have = fetch_target(gen_n, gen_o);
-    if (gen_have) { gen_e = p.nptr[gen_n]; gen_e1 = p.nptr[gen_n + 1]; }
-    int nxt_n = 0, nxt_o = 0, nxt_e = 0, nxt_e1 = 0;
+    if (gen_have) { const i32x2 b_ = sload2(p.nptr + gen_n); gen_e = b_[0]; gen_e1 = b_[1]; }
+    int nxt_n = 0, nxt_o = 0;
+    i32x2 nxt_b = {0, 0};  // bounds of the next target
     bool nxt_have = gen_have && fetch_target(nxt_n, nxt_o);
-    if (nxt_have) { nxt_e = p.nptr[nxt_n]; nxt_e1 = p.nptr[nxt_n + 1]; }
+    if (nxt_have) nxt_b = sload2(p.nptr + nxt_n);
 
     struct Blk { int eb, nv, n, orow; bool last, valid; };
     auto gen_next = [&]() -> Blk {
@@ -222,10 +248,11 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
         b.nv = gen_have ? max(0, min(32, gen_e1 - gen_e)) : 0;
         b.last = gen_have && (gen_e + 32 >= gen_e1);
         if (b.last) {
-            gen_have = nxt_have; gen_n = nxt_n; gen_o = nxt_o; gen_e = nxt_e; gen_e1 = nxt_e1;
+            gen_have = nxt_have; gen_n = nxt_n; gen_o = nxt_o;
             if (gen_have) {
+                gen_e = nxt_b[0]; gen_e1 = nxt_b[1];
                 nxt_have = fetch_target(nxt_n, nxt_o);
-                if (nxt_have) { nxt_e = p.nptr[nxt_n]; nxt_e1 = p.nptr[nxt_n + 1]; }
+                if (nxt_have) nxt_b = sload2(p.nptr + nxt_n);
             }
         } else {
             gen_e += 32;
@@ -279,7 +306,9 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
     for (int r = 0; r < 16; ++r) { gq[r] = make_float4(0.f, 0.f, 0.f, 0.f); gx[r] = 0.f; }
     half8 Ah[M32_KSP], Al[M32_KSP];  // this block's fragments; refilled for the next block step by step in tile c
     float sx = 0.f, sa = 0.f, sb = 0.f, sc = 0.f, ra = 0.f, rb = 0.f, rc = 0.f;
-    float resP0 = 0.f, resP1 = 0.f, resN0 = 0.f, resN1 = 0.f;
+    // residual inputs of the target rows: (x | vec_y, vec_x | vec_z) by half-wave; N = requested for the current block,
+    // P = of the previous block (consumed when its target is finished)
+    float resPx = 0.f, resPy = 0.f, resPz = 0.f, resNx = 0.f, resNy = 0.f, resNz = 0.f;
 
     Blk bP; bP.valid = false; bP.last = false; bP.eb = bP.nv = bP.n = bP.orow = 0;
     Blk b0 = gen_next();
@@ -302,14 +331,16 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
         if (!VZ) gq[r] = ld32<float4>(recB, off + laneQ);
         else gq[r].w = ld32<float>(recB, off + laneQ + 12u);
     }
-    auto load_res = [&](const Blk& b, float& r0, float& r1) {
-        // wave-uniform row pointers + the lane's channel: scalar-base addressing, no per-lane 64-bit pointers
+    // Requested for EVERY block, branch-free and straight into the loop-carried registers: a conditional load (only
+    // for a target's last block) ends in a register copy of the fresh value at the loop edge, i.e. a vmcnt(0) drain
+    // of the whole gather pipeline per block.  rx: x (half-wave 1 reads a valid dummy), ry: vec_y, rz: vec_x | vec_z.
+    auto load_res = [&](const Blk& b, float& rx, float& ry, float& rz) {
         const unsigned int xo = ((unsigned int)b.n * H + c0 + q) * 4u;
         const unsigned int vo = ((unsigned int)b.n * 3u * H + c0 + q) * 4u;
-        if (hi == 0) { r0 = ld32<float>(p.x, xo); r1 = VZ ? 0.f : ld32<float>(p.vec, vo); }
-        else if (!VZ) { r0 = ld32<float>(p.vec, vo + H * 4u); r1 = ld32<float>(p.vec, vo + H * 8u); }
+        rx = ld32<float>(p.x, xo);
+        if (!VZ) { ry = ld32<float>(p.vec, vo + H * 4u); rz = ld32<float>(p.vec, vo + (unsigned int)hi * (H * 8u)); }
     };
-    if (b0.valid && b0.last) load_res(b0, resN0, resN1);
+    load_res(b0, resNx, resNy, resNz);
 
     // one accumulator tile: bias MFMA + 3 products per k-step of the window; `work(i)` is called between MFMAs
     // with i = 0..15 (consume / gather work of one accumulator row each), in program order
@@ -322,11 +353,11 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
         const unsigned int xo = ((unsigned int)b.orow * H + c0 + q) * 4u;
         const unsigned int vo = ((unsigned int)b.orow * 3u * H + c0 + q) * 4u;
         if (hi == 0) {
-            st32<float>(p.x_out, xo, __fmul_rn(__fadd_rn(resP0, fx), inv_sqrt2));
-            st32<float>(p.vec_out, vo, resP1 + fa);
+            st32<float>(p.x_out, xo, __fmul_rn(__fadd_rn(resPx, fx), inv_sqrt2));
+            st32<float>(p.vec_out, vo, resPz + fa);
         } else {
-            st32<float>(p.vec_out, vo + H * 4u, resP0 + fb);
-            st32<float>(p.vec_out, vo + H * 8u, resP1 + fc);
+            st32<float>(p.vec_out, vo + H * 4u, resPy + fb);
+            st32<float>(p.vec_out, vo + H * 8u, resPz + fc);
         }
         sx = sa = sb = sc = ra = rb = rc = 0.f;
     };
@@ -437,6 +468,7 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
     // cbuf = meta buffer of this block; pbuf = the other one (previous block's until it is rewritten for the next).
     auto body = [&](f32x16& TA, f32x16& TB, const int cbuf) __attribute__((always_inline)) {
         const int pbuf = cbuf ^ 1;
+        STAMP(6)
         // -- S0: look two blocks ahead; window and A fragments of the next block; residual rows
         const Blk b2 = gen_next();
         float4 geo2; int src2;
@@ -447,6 +479,7 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
         f32x4 UX[2], UY[2], UZ[2];
         u32x4 OC[2], OA[2];
         PRE_C(0)
+        STAMP(0)
         // -- S1: tile b of this block (not in the vec == 0 layer) while tile c of the previous block is consumed
         if (!VZ) {
             M32_TILE(TA, 1, Ah, Al, WORK_C, POST_NONE)
@@ -454,24 +487,29 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
             WORK_C(0) WORK_C(1) WORK_C(2) WORK_C(3) WORK_C(4) WORK_C(5) WORK_C(6) WORK_C(7)
             WORK_C(8) WORK_C(9) WORK_C(10) WORK_C(11) WORK_C(12) WORK_C(13) WORK_C(14) WORK_C(15)
         }
+        STAMP(1)
         if (bP.valid && bP.last) finish_target(bP);
+        STAMP(2)
         // -- S2: the previous block's meta is dead now: write the next block's into its buffer
         write_meta(pbuf, b1, geo1, src1);
         PRE_A(0)
+        STAMP(3)
         // -- S3: tile a while tile b is consumed
         if (!VZ) {
             M32_TILE(TB, 0, Ah, Al, WORK_B, POST_NONE)
         } else {
             M32_TILE(TB, 0, Ah, Al, WORK_NONE, POST_NONE)
         }
+        STAMP(4)
         // -- S4: tile c while tile a is consumed and the next block's quads are requested
         M32_TILE(TA, 2, Ah, Al, WORK_A, POST_A)
+        STAMP(5)
         // -- rotate
         bP = b0; b0 = b1; b1 = b2;
         geo1 = geo2; src1 = src2;
         kb0 = kb1; klo0 = klo1; ks0 = ks1;
-        resP0 = resN0; resP1 = resN1;
-        if (b0.valid && b0.last) load_res(b0, resN0, resN1);
+        resPx = resNx; resPy = resNy; resPz = resNz;
+        load_res(b0, resNx, resNy, resNz);
     };
 
     // resN of block 0 was loaded in the prologue; body() loads the residual rows of the block that becomes current
@@ -499,10 +537,16 @@ __global__ __launch_bounds__(M32_THREADS, 2) void adf_message32_kernel(Msg32Para
         }
     }
     if (p.kcount && lane == 0) atomicAdd(p.kcount, (unsigned long long)ksteps * 8ull);
+#ifdef M32_STAMP
+    if (p.kcount && lane == 0)
+        for (int i = 0; i < 7; ++i) atomicAdd(p.kcount + 1 + i, st_[i]);
+#endif
 }
 
 static size_t m32_lds_bytes() {
-    return (size_t)2 * M32_COLS * M32_LDK * 2 + sizeof(float4) * M32_WAVES * 2 * 32 + 16;
+    static long pad = -1;  // development: ADF_M32_PAD=<bytes> of extra LDS limits the workgroups per CU
+    if (pad < 0) { const char* e = getenv("ADF_M32_PAD"); pad = e ? atol(e) : 0; }
+    return (size_t)2 * M32_COLS * M32_LDK * 2 + sizeof(float4) * M32_WAVES * 2 * 32 + 16 + (size_t)pad;
 }
 
 int32_t adf_message32_prepare() {
