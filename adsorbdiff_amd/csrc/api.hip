@@ -346,7 +346,12 @@ static int32_t read_flags(adf_painn* h, hipStream_t s) {
     if (f[2]) { adf_set_error("edge buffer overflow"); return ADF_EOVERFLOW; }
     if (f[3]) { adf_set_error("an atom has more than %d incoming edges", ADF_MAX_INDEG); return ADF_EOVERFLOW; }
     if (f[1]) { adf_set_error("An image has no neighbors"); return ADF_ENONEIGHBOR; }
-    if (f[5]) { adf_set_error("non-finite activation in the forward (inf/nan input or weights)"); return ADF_EHIP; }
+    if (f[5]) {
+        adf_set_error("non-finite model output%s", h->gemm_f32 ? " (exact-f32 arithmetic: the inputs or weights are not finite)"
+                      : " in f16x3 arithmetic: an activation left the fp16 range or the inputs are not finite; "
+                        "adf_painn_set_arithmetic(h, 1) selects exact f32");
+        return ADF_ENUMERIC;
+    }
     return ADF_OK;
 }
 
@@ -628,6 +633,16 @@ extern "C" int32_t adf_linear_forward(const float* A, const float* W, const floa
     (void)hipStreamSynchronize(s);
     (void)hipFree(buf);
     return st;
+}
+
+// 0 = f16x3 split products on the f16 matrix cores (default), 1 = exact f32 MFMA everywhere (what ADF_GEMM=f32 selects
+// at creation).  Takes effect with the next forward; the weight images of both modes are kept by adf_painn_set_weights.
+extern "C" int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    h->gemm_f32 = exact_f32 != 0;
+    h->msg_f32 = exact_f32 != 0;
+    h->rec0_valid = false;
+    return ADF_OK;
 }
 
 extern "C" int32_t adf_check_flags(adf_painn_t h, void* stream) {

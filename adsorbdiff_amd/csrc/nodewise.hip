@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void adf_head_final_kernel(const float* __rest
                                                               const float* __restrict__ w_vec2,
                                                               const float* __restrict__ un2_w,
                                                               const float* __restrict__ un2_b, float* __restrict__ out,
-                                                              int N, int C) {
+                                                              int N, int C, int32_t* flags) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -199,6 +199,11 @@ __global__ __launch_bounds__(256) void adf_head_final_kernel(const float* __rest
         out[(size_t)n * 3 + 0] = g * t0;
         out[(size_t)n * 3 + 1] = g * t1;
         out[(size_t)n * 3 + 2] = g * t2;
+        // Non-finite output: inf / nan inputs or weights - or, in the f16x3 arithmetic, an activation beyond the fp16
+        // range (|a| > 65504 -> a_hi = inf), which always ends up here (LayerNorm and the residual streams spread
+        // it).  Reported by adf_check_flags as ADF_ENUMERIC; the host re-runs in exact f32 (engine.py).
+        const float s3 = g * t0 + g * t1 + g * t2;
+        if (!(fabsf(s3) <= 3.0e38f)) atomicExch(&flags[5], 1);
     }
 }
 
@@ -273,7 +278,7 @@ int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const fl
         ADF_TRY(adf_launch_gemm16(x1, H2, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s, cat1, H2));
     }
     hipLaunchKernelGGL(adf_head_final_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->y, v1, b1.vec2_w, b1.un2_w,
-                       b1.un2_b, out, N, H2);
+                       b1.un2_b, out, N, H2, h->flags);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

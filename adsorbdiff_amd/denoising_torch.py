@@ -184,74 +184,87 @@ class Denoiser:
             if params.get("static_atom_cache", True):
                 eng.set_moving_atoms(prep, prep.tags == 2)
 
-            f1 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
-            f2 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
-            out_idx = None
-            if params.get("scores_on_adsorbate_only", False):
-                out_idx = torch.nonzero(prep.tags == 2).reshape(-1).to(torch.int32).contiguous()
-            state = torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
-            frames = [] if self.traj_dir else None
-            check_every = 1 if B <= 8 else 5
-            z_tr = z_rot = None
-            if not ode:
-                z_tr = torch.empty(B, 3, dtype=torch.float32, device=dev)
-                z_rot = torch.empty(B, 3, dtype=torch.float32, device=dev)
-            # schedule table on the device: every step is then the same launch sequence and can be replayed
-            # from one captured hipGraph (`use_graph`, opt-in: measured no gain on MI355X at B=1 — the step is
-            # bound by the dependent chain of ~140 small kernels on the device, not by launch overhead)
-            coefs_dev = torch.tensor(
-                [[c.coef_tr, c.rot_pre, c.rot_dt, c.rot_g2, c.noise_tr, c.noise_rot] for c in coefs],
-                dtype=torch.float32, device=dev)
-            use_graph = bool(params.get("use_graph", False))
-            graph = None
+            pos0 = pos.clone()  # a run that leaves the f16x3 range is repeated in exact f32 from here
 
-            def one_step():
-                eng.forward_prepared(prep, pos, f1, f2, out_idx)
-                eng.sde_step_scheduled(prep, pos, f1, f2, coefs_dev, T, state, z_tr, z_rot, early_stop_count=early)
-
-            # Nothing to hand to the host between steps (no per-step frames, no host noise hook, no graph replay):
-            # the whole loop is one library call (adf_sample), polling the early-stop flag every `check_every` steps.
-            fused_loop = (not use_graph) and self.noise_fn is None and (frames is None or not self.save_full)
-            if fused_loop:
-                zt = zr = None
-                if not ode:  # device generator, drawn in the reference's order (:274-289): z_tr then z_rot, per step
-                    zt = torch.empty(T, B, 3, dtype=torch.float32, device=dev)
-                    zr = torch.empty(T, B, 3, dtype=torch.float32, device=dev)
-                    for t_idx in range(T):
-                        zt[t_idx].normal_()
-                        zr[t_idx].normal_()
-                eng.sample(prep, pos, f1, f2, coefs_dev, T, state, zt, zr, early_stop_count=early,
-                           poll_every=check_every if early else 0, out_idx=out_idx)
-            for t_idx in range(0 if fused_loop else T):  # per-step path
+            def attempt():
+                f1 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+                f2 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+                out_idx = None
+                if params.get("scores_on_adsorbate_only", False):
+                    out_idx = torch.nonzero(prep.tags == 2).reshape(-1).to(torch.int32).contiguous()
+                state = torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+                frames = [] if self.traj_dir else None
+                check_every = 1 if B <= 8 else 5
+                z_tr = z_rot = None
                 if not ode:
-                    if self.noise_fn is not None:
-                        a, b_ = self.noise_fn(t_idx, B)
-                        z_tr.copy_(a.to(dev, torch.float32))
-                        z_rot.copy_(b_.to(dev, torch.float32))
-                    else:  # device generator, like the reference (:274-289)
-                        z_tr.normal_()
-                        z_rot.normal_()
-                if graph is not None:
-                    graph.replay()
-                else:
-                    one_step()
-                    if use_graph and t_idx == 0 and T > 2:
-                        # step 0 ran eagerly (workspaces are now allocated); capture the identical step once
-                        torch.cuda.synchronize(dev)
-                        graph = torch.cuda.CUDAGraph()
-                        snapshot = (pos.clone(), state.clone())
-                        with torch.cuda.graph(graph):
-                            one_step()
-                        # the capture itself does not execute; restore nothing, but make sure state is intact
-                        assert torch.equal(state, snapshot[1])
-                if frames is not None and (self.save_full or t_idx == T - 1):
+                    z_tr = torch.empty(B, 3, dtype=torch.float32, device=dev)
+                    z_rot = torch.empty(B, 3, dtype=torch.float32, device=dev)
+                # schedule table on the device: every step is then the same launch sequence and can be replayed
+                # from one captured hipGraph (`use_graph`, opt-in: measured no gain on MI355X at B=1 — the step is
+                # bound by the dependent chain of ~140 small kernels on the device, not by launch overhead)
+                coefs_dev = torch.tensor(
+                    [[c.coef_tr, c.rot_pre, c.rot_dt, c.rot_g2, c.noise_tr, c.noise_rot] for c in coefs],
+                    dtype=torch.float32, device=dev)
+                use_graph = bool(params.get("use_graph", False))
+                graph = None
+
+                def one_step():
+                    eng.forward_prepared(prep, pos, f1, f2, out_idx)
+                    eng.sde_step_scheduled(prep, pos, f1, f2, coefs_dev, T, state, z_tr, z_rot, early_stop_count=early)
+
+                # Nothing to hand to the host between steps (no per-step frames, no host noise hook, no graph replay):
+                # the whole loop is one library call (adf_sample), polling the early-stop flag every `check_every` steps.
+                fused_loop = (not use_graph) and self.noise_fn is None and (frames is None or not self.save_full)
+                if fused_loop:
+                    zt = zr = None
+                    if not ode:  # device generator, drawn in the reference's order (:274-289): z_tr then z_rot, per step
+                        zt = torch.empty(T, B, 3, dtype=torch.float32, device=dev)
+                        zr = torch.empty(T, B, 3, dtype=torch.float32, device=dev)
+                        for t_idx in range(T):
+                            zt[t_idx].normal_()
+                            zr[t_idx].normal_()
+                    eng.sample(prep, pos, f1, f2, coefs_dev, T, state, zt, zr, early_stop_count=early,
+                               poll_every=check_every if early else 0, out_idx=out_idx)
+                for t_idx in range(0 if fused_loop else T):  # per-step path
+                    if not ode:
+                        if self.noise_fn is not None:
+                            a, b_ = self.noise_fn(t_idx, B)
+                            z_tr.copy_(a.to(dev, torch.float32))
+                            z_rot.copy_(b_.to(dev, torch.float32))
+                        else:  # device generator, like the reference (:274-289)
+                            z_tr.normal_()
+                            z_rot.normal_()
+                    if graph is not None:
+                        graph.replay()
+                    else:
+                        one_step()
+                        if use_graph and t_idx == 0 and T > 2:
+                            # step 0 ran eagerly (workspaces are now allocated); capture the identical step once
+                            torch.cuda.synchronize(dev)
+                            graph = torch.cuda.CUDAGraph()
+                            snapshot = (pos.clone(), state.clone())
+                            with torch.cuda.graph(graph):
+                                one_step()
+                            # the capture itself does not execute; restore nothing, but make sure state is intact
+                            assert torch.equal(state, snapshot[1])
+                    if frames is not None and (self.save_full or t_idx == T - 1):
+                        frames.append(pos.clone())
+                    if early and (t_idx % check_every == check_every - 1):
+                        if int(state[1].item()):
+                            break
+                if frames is not None and not frames:
                     frames.append(pos.clone())
-                if early and (t_idx % check_every == check_every - 1):
-                    if int(state[1].item()):
-                        break
-            if frames is not None and not frames:
-                frames.append(pos.clone())
-            eng.check_flags()
+                eng.check_flags()
+                return state, frames
+
+            frames = None
+            try:
+                state, frames = attempt()
+            except _lib.NumericRangeError:
+                if not eng.use_exact_f32():
+                    raise
+                pos.copy_(pos0)
+                state, frames = attempt()
             st = state.tolist()
             self.steps_applied = st[3]
             self.cvg_count = st[0]

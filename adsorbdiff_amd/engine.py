@@ -104,6 +104,9 @@ class PaiNNEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.adf_painn_create(C.byref(hp), C.byref(self.handle)))
         self._weights_keepalive: List[torch.Tensor] = []
+        import os
+
+        self.exact_f32 = os.environ.get("ADF_GEMM") == "f32"
         self._last_graph_N = 0
         self.bind_weights()
 
@@ -213,8 +216,27 @@ class PaiNNEngine:
         f1 = torch.empty(prep.num_atoms, 3, dtype=torch.float32, device=self.device)
         f2 = torch.empty_like(f1) if self.model.so3_denoising else None
         self.forward_prepared(prep, pos, f1, f2)
-        self.check_flags()  # ValueError on an image without neighbours, like the reference
+        try:
+            self.check_flags()  # ValueError on an image without neighbours, like the reference
+        except _lib.NumericRangeError:
+            if not self.use_exact_f32():  # already exact: the inputs / weights themselves are not finite
+                raise
+            self.forward_prepared(prep, pos, f1, f2)
+            self.check_flags()
         return f1, f2
+
+    def use_exact_f32(self) -> bool:
+        """Switch the handle to exact-f32 arithmetic (after a NumericRangeError in the default f16x3 mode: an
+        activation left the fp16 range).  Returns False if it already was exact."""
+        if self.exact_f32:
+            return False
+        import logging
+
+        logging.warning("adsorbdiff_amd: non-finite output in f16x3 arithmetic; re-running in exact f32 "
+                        "(this engine stays in exact f32)")
+        _lib.check(self.lib.adf_painn_set_arithmetic(self.handle, 1))
+        self.exact_f32 = True
+        return True
 
     def build_graph(self, data):
         """Graph only; returns the number of symmetrised edges."""

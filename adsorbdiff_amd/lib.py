@@ -12,11 +12,16 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-ADF_OK, ADF_EINVAL, ADF_EOOM, ADF_ENONEIGHBOR, ADF_EHIP, ADF_EOVERFLOW = 0, 1, 2, 3, 4, 5
+ADF_OK, ADF_EINVAL, ADF_EOOM, ADF_ENONEIGHBOR, ADF_EHIP, ADF_EOVERFLOW, ADF_ENUMERIC = 0, 1, 2, 3, 4, 5, 6
+
+
+class NumericRangeError(ArithmeticError):
+    """Non-finite model output (ADF_ENUMERIC).  Not a RuntimeError on purpose: ``ml_diffuse`` must not answer it by
+    splitting the batch; the engine answers it by re-running in exact f32."""
 
 EXPORTS = (
     "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_graph_set_moving",
-    "adf_check_flags",
+    "adf_check_flags", "adf_painn_set_arithmetic",
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
@@ -87,6 +92,7 @@ def load():
         "adf_graph_build": [vp, C.POINTER(BatchDesc), vp, C.POINTER(i64)],
         "adf_graph_set_moving": [vp, vp, vp, vp],
         "adf_check_flags": [vp, vp],
+        "adf_painn_set_arithmetic": [vp, i32],
         "adf_graph_export": [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.POINTER(i64), vp],
         "adf_painn_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp],
         "adf_painn_forward_subset": [vp, C.POINTER(BatchDesc), vp, i32, vp, vp, vp],
@@ -123,6 +129,8 @@ def check(status: int) -> None:
         raise ValueError(msg)
     if status == ADF_EOOM:
         raise RuntimeError(f"HIP out of memory: {msg}")
+    if status == ADF_ENUMERIC:
+        raise NumericRangeError(msg)
     if status == ADF_EINVAL:
         raise ValueError(f"adsorbdiff_hip: invalid argument: {msg}")
     raise RuntimeError(f"adsorbdiff_hip error {status}: {msg}")

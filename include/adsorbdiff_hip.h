@@ -36,6 +36,7 @@ extern "C" {
 #define ADF_ENONEIGHBOR 3 /* an image has no neighbours (painn_denoising.py:370)  */
 #define ADF_EHIP 4        /* HIP runtime error                                    */
 #define ADF_EOVERFLOW 5   /* candidate list of one centre exceeded its capacity   */
+#define ADF_ENUMERIC 6    /* non-finite model output (see adf_painn_set_arithmetic) */
 
 typedef struct adf_painn* adf_painn_t;
 
@@ -118,6 +119,12 @@ int32_t adf_graph_build(adf_painn_t h, const adf_batch* b, void* stream, int64_t
  * on the atomic numbers only (x0 = emb(Z), vec0 = 0), so the batch's atomic numbers and the weights must not change
  * either (adf_painn_set_weights invalidates).  Pass NULLs to switch the cache off (default).  Any call invalidates. */
 int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, const int32_t* mov_idx, const int32_t* mov_off);
+
+/* Arithmetic of the dense products: 0 = f16x3 (three fp16 matrix-core products per fp32 product, fp32 accumulate:
+ * 2^-22 relative per product for activations inside the fp16 range, |a| <= 65504; default), 1 = exact f32 MFMA (the
+ * reference's width, models/painn/README.md:12; ~2x slower).  A forward whose output is not finite reports
+ * ADF_ENUMERIC through adf_check_flags; the host mirror then re-runs the forward / the sampling run in exact f32. */
+int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32);
 
 /* Read the device-side error flags of the last graph build (candidate overflow,
  * empty image).  Synchronises the stream.  adf_painn_forward does not check

@@ -116,6 +116,72 @@ def test_linear_kernels_vs_fp64(mode, shape):
     assert rel_err(out, ref) < (1e-6 if mode == 0 else 3e-6)
 
 
+@pytest.mark.parametrize("scale,tol", [(1.0e3, 2e-6), (1.0, 2e-6), (1.0e-2, 4e-4), (1.0e-4, 4e-4)])
+def test_linear_f16x3_activation_range(scale, tol):
+    """Documented range of the f16x3 split (gemm16.hip): activations are split into fp16 hi/lo unscaled, so a product
+    keeps ~2^-22 relative precision for 0.125 <= |a| <= 65504; below 0.125 a_lo is an fp16 subnormal that the matrix
+    core flushes and that element carries 2^-11 (random signs: a K = 512 dot product then sits at ~1e-4 relative, the
+    bound asserted here); above 65504 a_hi overflows and the forward reports ADF_ENUMERIC (next test)."""
+    import ctypes as C
+
+    from adsorbdiff_amd import lib as L
+
+    lib = L.load()
+    torch.manual_seed(3)
+    M, N, K = 512, 256, 512
+    A = (torch.randn(M, K, device=DEV) * scale).contiguous()
+    W = (torch.randn(N, K, device=DEV) / K**0.5).contiguous()
+    Cm = torch.empty(M, N, device=DEV)
+    L.check(lib.adf_linear_forward(A.data_ptr(), W.data_ptr(), None, Cm.data_ptr(), M, N, K, 0, 1,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T
+    err = float((Cm.double() - ref).norm() / ref.norm())
+    assert err < tol, (scale, err)
+
+
+def test_out_of_range_activations_fall_back_to_exact_f32():
+    """LayerNorm gain x 1e5 with x_proj.0 weights x 1e-5: the same function in exact arithmetic, but the GEMM input
+    exceeds the fp16 range (|a| > 65504), so the f16x3 forward produces a non-finite output; adf_check_flags reports
+    ADF_ENUMERIC and the engine re-runs in exact f32 - the caller sees the oracle's answer.  The sampler does the
+    same for a whole run."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+    from oracle import painn_oracle as O
+
+    fx = load_npz("painn_small.npz")
+    def rescaled():
+        mm = small_model(fx)
+        with torch.no_grad():
+            mm.message_layers[1].x_layernorm.weight.mul_(1.0e5)
+            mm.message_layers[1].x_layernorm.bias.mul_(1.0e5)
+            mm.message_layers[1].x_proj[0].weight.mul_(1.0e-5)
+        return mm
+
+    m = rescaled()
+    b = batch_from_fixture(fx, device=DEV)
+    f1, f2 = m(b)
+    assert m.engine().exact_f32 and bool(torch.isfinite(f1).all()) and bool(torch.isfinite(f2).all())
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    bc = batch_from_fixture(fx)
+    o1, o2 = O.painn_forward(sd, bc.pos, bc.atomic_numbers, bc.cell, bc.natoms, hidden_channels=int(fx["hp_hidden_channels"]),
+                             num_layers=int(fx["hp_num_layers"]), cutoff=float(fx["hp_cutoff"]),
+                             max_neighbors=int(fx["hp_max_neighbors"]), scale_factors=m.scale_factors())
+    assert rel_err(f1.cpu(), o1) < REL_TOL and rel_err(f2.cpu(), o2) < REL_TOL
+    # a fresh engine (f16x3 again) inside the sampler: the run is repeated in exact f32 from the initial placement
+    m2 = rescaled()
+    params = dict(num_steps=2, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+                  early_stop=False)
+    torch.manual_seed(3)
+    out = Denoiser(batch_from_fixture(fx, device=DEV), DiffTorchCalc(DenoisingTrainer(m2, device=DEV)), params,
+                   device=DEV).run()
+    assert m2.engine().exact_f32 and bool(torch.isfinite(out.pos).all())
+    torch.manual_seed(3)
+    ref = Denoiser(batch_from_fixture(fx, device=DEV), DiffTorchCalc(DenoisingTrainer(m, device=DEV)), params,
+                   device=DEV).run()
+    assert torch.equal(out.pos, ref.pos)  # m's engine is in exact f32 already: same arithmetic, same run
+
+
 def test_painn_small_layers_and_output():
     fx = load_npz("painn_small.npz")
     m = small_model(fx)
