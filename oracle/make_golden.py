@@ -219,14 +219,48 @@ def main():
             self.pos_log.append(batch.pos.clone())
             return super().predict_denoising(batch, per_image, disable_tqdm)
 
+    import adsorbdiff.relaxation.diffusers.denoising_torch as ref_dt
+
     def run_ref(batch, params, seed, model):
+        """The real Denoiser.run with recording hooks around its own calls: per step the per-system scores
+        (_get_ads_output of the two heads, denoising_torch.py:263-268), the wrapped COM displacement (the argument of
+        the allclose early-stop test, :312-317) and the rotation vector (the argument of axis_angle_to_matrix, :327)."""
         tr = RecTrainer(model)
-        with tempfile.TemporaryDirectory() as td:
-            torch.manual_seed(seed)
-            den = RefDenoiser(batch, RefDiffTorchCalc(tr), denoising_pos_params=params, device="cpu",
-                              traj_dir=Path(td), traj_names=batch.sid)
-            out = den.run()
-        return out.pos.clone(), tr.pos_log
+        ads_calls, dcom_log, drot_log = [], [], []
+        orig_get, orig_aa, orig_allclose = RefDenoiser._get_ads_output, ref_dt.axis_angle_to_matrix, torch.allclose
+
+        def rec_get(self_, pred):
+            out = orig_get(self_, pred)
+            ads_calls.append(out.clone())
+            return out
+
+        def rec_aa(v):
+            drot_log.append(v.clone())
+            return orig_aa(v)
+
+        def rec_allclose(a, b_, **kw):
+            dcom_log.append(a.clone())
+            return orig_allclose(a, b_, **kw)
+
+        RefDenoiser._get_ads_output, ref_dt.axis_angle_to_matrix, torch.allclose = rec_get, rec_aa, rec_allclose
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                torch.manual_seed(seed)
+                den = RefDenoiser(batch, RefDiffTorchCalc(tr), denoising_pos_params=params, device="cpu",
+                                  traj_dir=Path(td), traj_names=batch.sid)
+                out = den.run()
+        finally:
+            RefDenoiser._get_ads_output, ref_dt.axis_angle_to_matrix, torch.allclose = orig_get, orig_aa, orig_allclose
+        nb = int(batch.batch.max()) + 1
+        steps = len(dcom_log)                       # every step reaches the allclose test
+        # one call for the initial placement (:220), then (translation score, rotation score, COM) per step
+        assert len(ads_calls) == 1 + 3 * steps, (len(ads_calls), steps)
+        ads_calls = ads_calls[1:]
+        rec = dict(score_tr=torch.stack(ads_calls[0::3]), score_rot=torch.stack(ads_calls[1::3]),
+                   com=torch.stack(ads_calls[2::3]), dcom=torch.stack(dcom_log))
+        applied = len(drot_log) // nb               # the step that breaks the loop rotates nothing
+        rec["drot"] = torch.stack(drot_log).reshape(applied, nb, 3) if applied else torch.zeros(0, nb, 3)
+        return out.pos.clone(), tr.pos_log, rec
 
     def run_oracle(batch, params, seed, sd, hp_, sf):
         torch.manual_seed(seed)
@@ -255,18 +289,29 @@ def main():
                 head.output_network[1].update_net[2].bias.mul_(gain).add_(bias)
         return {k: v.clone() for k, v in ref_s.state_dict().items()}
 
+    # ode3_fixed: one adsorbate atom per system carries fixed == 1 (DiffTorchCalc zeroes its positions_free row, :498).
+    # ode3_img: 13-atom systems in ~4.3 A cells -> 5 x 5 x 3 = 75 periodic images at rc = 6 A.
     for mode, ode, T, nb_, seed, gain, bias in (
         ("ode5", True, 5, 4, 123, 100.0, 0.2),
         ("sde3", False, 3, 3, 321, 100.0, 0.2),
         ("ode8", True, 8, 4, 99, 0.2, 0.0),
         ("ode_early", True, 40, 1, 7, 1e-2, 0.0),
+        ("ode3_fixed", True, 3, 3, 17, 1.0, 0.05),
+        ("ode3_img", True, 3, 3, 18, 1.0, 0.05),
     ):
         params = dict(num_steps=T, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=ode)
         sdx = set_gain(gain, bias)
         model = ref_s
-        bt = make_batch(nb_, n_slab=36, n_ads=4, seed=50 + nb_)
+        if mode == "ode3_img":
+            bt = make_batch(nb_, n_slab=9, n_ads=4, seed=60)
+            assert O.cell_repeats(bt.cell, 6.0)[:2] == [2, 2], O.cell_repeats(bt.cell, 6.0)
+        else:
+            bt = make_batch(nb_, n_slab=36, n_ads=4, seed=50 + nb_)
+        if mode == "ode3_fixed":
+            first_ads = torch.nonzero(bt.tags == 2).reshape(-1)[:: 4]
+            bt.fixed[first_ads] = 1
         pos_in = bt.pos.clone()
-        pos_r, log_r = run_ref(bt.clone(), params, seed, model)
+        pos_r, log_r, rec_r = run_ref(bt.clone(), params, seed, model)
         pos_o, rec_o = run_oracle(bt, params, seed, sdx, hp, [1.05, 0.9])
         err = (pos_r - pos_o).abs().max().item()
         step_err = [(log_r[i + 1] - rec_o[i]["pos"]).abs().max().item() for i in range(min(len(log_r) - 1, len(rec_o)))]
@@ -280,7 +325,17 @@ def main():
             assert 0.05 < max(r["dcom"].abs().max().item() for r in rec_o) < 1.5
         if mode == "ode_early":
             assert len(log_r) == 10 and len(rec_o) == 9, (len(log_r), len(rec_o))
+        # the oracle's per-step quantities against the reference's own
+        for t in range(min(len(rec_o), rec_r["dcom"].shape[0])):
+            for key, okey in (("score_tr", "s_tr"), ("score_rot", "s_rot"), ("dcom", "dcom"), ("drot", "drot")):
+                if t >= rec_r[key].shape[0]:
+                    continue
+                if okey in rec_o[t]:
+                    dv = (rec_o[t][okey] - rec_r[key][t]).abs().max().item()
+                    assert dv <= 2e-5 * max(1.0, rec_r[key][t].abs().max().item()) or chaotic, (mode, t, key, dv)
         fxs = dict(pos_in=pos_in, pos_final=pos_r, pos_log=torch.stack(log_r), num_steps=T, ode=int(ode), seed=seed,
+                   ref_score_tr=rec_r["score_tr"], ref_score_rot=rec_r["score_rot"], ref_dcom=rec_r["dcom"],
+                   ref_drot=rec_r["drot"], ref_com=rec_r["com"],
                    **{k: v for k, v in batch_inputs(bt).items() if k != "pos"})
         fxs.update({"sd::" + k: v for k, v in sdx.items() if k != "atom_radii"})
         np.savez_compressed(GOLD / f"stepper_{mode}.npz", **npify(fxs))

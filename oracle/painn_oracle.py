@@ -411,5 +411,9 @@ def reverse_sde_sampling_rot(
                 break
         pos = new_pos
         if record is not None:
-            record.append({"dcom": dcom.clone(), "drot": drot.clone(), "pos": pos.clone()})
+            B = cell.shape[0]
+            f2z = f2.clone()
+            f2z[fixed == 1] = 0
+            record.append({"dcom": dcom.clone(), "drot": drot.clone(), "pos": pos.clone(),
+                           "s_tr": ads_mean(f1, tags, batch, B), "s_rot": ads_mean(f2z, tags, batch, B)})
     return pos

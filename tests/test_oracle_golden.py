@@ -90,6 +90,39 @@ def test_stepper_oracle_each_step_vs_reference():
         np.testing.assert_allclose(new_pos.numpy(), want.numpy(), rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("name", ["ode8", "ode3_fixed", "ode3_img", "sde3"])
+def test_oracle_step_quantities_vs_reference_records(name):
+    """The reference's own per-step records (scores, wrapped COM displacement, rotation vector; hooks in
+    oracle/make_golden.py) against the oracle, teacher-forced on the recorded positions."""
+    hp = dict(hidden_channels=128, num_layers=2, num_rbf=128, cutoff=6.0, max_neighbors=20)
+    fx = load_npz(f"stepper_{name}.npz")
+    sd = state_dict_from_fixture(fx)
+    b = batch_from_fixture(fx, pos_key="pos_in")
+    B = len(b.natoms)
+    T = int(fx["num_steps"])
+    params = dict(num_steps=T, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=bool(int(fx["ode"])))
+    log = torch.from_numpy(fx["pos_log"])
+    torch.manual_seed(int(fx["seed"]))
+    torch.rand(B, 3)  # the placement draw precedes the step noises in the reference's stream
+    for t in range(min(T, 2)):
+        z_tr = z_rot = None
+        if not params["ode"]:
+            z_tr = torch.normal(mean=0, std=1, size=(B, 3))
+            z_rot = torch.normal(mean=0, std=1, size=(B, 3))
+        f1, f2 = O.painn_forward(sd, log[t], b.atomic_numbers, b.cell, b.natoms, scale_factors=[1.05, 0.9], **hp)
+        f2z = f2.clone()
+        f2z[b.fixed == 1] = 0
+        assert rel_err(O.ads_mean(f1, b.tags, b.batch, B), fx["ref_score_tr"][t]) < 1e-5
+        assert rel_err(O.ads_mean(f2z, b.tags, b.batch, B), fx["ref_score_rot"][t]) < 1e-5
+        _, dcom, drot, _ = O.reverse_step(log[t], b.cell, b.tags, b.batch, f1, f2, b.fixed, t, params, z_tr, z_rot)
+        assert rel_err(drot, fx["ref_drot"][t]) < 1e-5
+        np.testing.assert_allclose(dcom.numpy(), fx["ref_dcom"][t], rtol=0, atol=2e-5)
+    if name == "ode3_fixed":
+        assert int((b.fixed[b.tags == 2] == 1).sum()) == B
+    if name == "ode3_img":
+        assert O.cell_repeats(b.cell, 6.0)[:2] == [2, 2]
+
+
 def test_early_stop_rule():
     """Cumulative (not consecutive) count, break before applying the 10th converged step."""
     fx = load_npz("stepper_ode_early.npz")
