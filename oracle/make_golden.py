@@ -339,6 +339,108 @@ def main():
                    **{k: v for k, v in batch_inputs(bt).items() if k != "pos"})
         fxs.update({"sd::" + k: v for k, v in sdx.items() if k != "atom_radii"})
         np.savez_compressed(GOLD / f"stepper_{mode}.npz", **npify(fxs))
+    # ---------------------------------------------------------------- 6. training step
+    # The reference's own noising (tr_so3_schedule + pbc_correction), loss (_compute_loss) and IGSO(3) tables are
+    # executed from their source file (the functions only: importing the trainer module drags in the whole training
+    # stack), then autograd of the reference PaiNN gives the gradients the HIP backward is tested against.
+    import ast
+    import types as _types
+
+    from adsorbdiff.utils import rot_utils as ref_rot
+    import torch_scatter as _ts
+
+    ref_src = Path("/root/reference/adsorbdiff/trainers/sde_denoising_trainer.py").read_text()
+    tree = ast.parse(ref_src)
+    wanted = {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("pbc_correction", "tr_so3_schedule"):
+            wanted[node.name] = node
+        if isinstance(node, ast.ClassDef) and node.name == "DenoisingTrainer":
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == "_compute_loss":
+                    wanted[sub.name] = sub
+    assert set(wanted) == {"pbc_correction", "tr_so3_schedule", "_compute_loss"}, set(wanted)
+    ns = {"torch": torch, "np": np, "scatter": _ts.scatter, "rot_utils": ref_rot}
+    exec(compile(ast.Module(body=list(wanted.values()), type_ignores=[]), "<reference functions>", "exec"), ns)
+    ref_tr_so3_schedule, ref_compute_loss = ns["tr_so3_schedule"], ns["_compute_loss"]
+
+    # IGSO(3) tables: the oracle's own evaluation of the series against the reference's cached arrays (sub-sampled)
+    from oracle import train_oracle as TO
+
+    eps_rows = np.array([0, 37, 250, 499, 731, 999])
+    om_cols = np.arange(0, ref_rot.X_N, 97)
+    tab = TO.igso3_rows(eps_rows)
+    for key, ref_arr in (("cdf", ref_rot._cdf_vals), ("score", ref_rot._score_norms)):
+        a, r = tab[key], ref_arr[eps_rows]
+        assert np.allclose(a, r, rtol=1e-9, atol=1e-12), (key, np.abs(a - r).max())
+    assert np.allclose(tab["exp_score_norm"], ref_rot._exp_score_norms[eps_rows], rtol=1e-9)
+    np.savez_compressed(GOLD / "igso3_tables.npz", eps_rows=eps_rows, om_cols=om_cols,
+                        cdf=ref_rot._cdf_vals[eps_rows][:, om_cols], score=ref_rot._score_norms[eps_rows][:, om_cols],
+                        exp_score_norm=ref_rot._exp_score_norms, omegas=ref_rot._omegas_array[om_cols],
+                        min_eps=ref_rot.MIN_EPS, max_eps=ref_rot.MAX_EPS, n_eps=ref_rot.N_EPS, x_n=ref_rot.X_N)
+    print("[igso3] oracle series == reference tables on", len(eps_rows), "eps rows")
+
+    tparams = dict(ads_std_low=0.1, ads_std_high=10, free_std_low=0.0, free_std_high=0.0, rot_std_low=0.01,
+                   rot_std_high=1.55, num_steps=50)
+    ref_s.load_state_dict(base_sd)
+    sd_t = {k: v.clone() for k, v in ref_s.state_dict().items()}
+    bt = make_batch(4, n_slab=36, n_ads=4, seed=71)
+    bt.fixed = bt.fixed.clone()
+    pos_clean = bt.pos.clone()
+    torch.manual_seed(2024)
+    np.random.seed(2024)
+    nb = ref_tr_so3_schedule(bt.clone(), tparams)
+    # the oracle's noising, same random streams
+    torch.manual_seed(2024)
+    np.random.seed(2024)
+    ob = TO.tr_so3_schedule(pos_clean.clone(), bt.cell, bt.tags, bt.batch, bt.natoms, tparams, TO.Igso3(ref_rot))
+    for key in ("pos", "tr_sigma", "rot_sigma", "rot_score", "tr_score", "ads_center_noise_vec"):
+        dv = (getattr(nb, key) - ob[key]).abs().max().item()
+        assert dv <= 1e-6 * max(1.0, getattr(nb, key).abs().max().item()), (key, dv)
+    # forward + loss + autograd of the REFERENCE model (train mode is eval mode for PaiNN: no dropout / batch norm)
+    ref_s.train()
+    ref_s.zero_grad()
+    o1, o2 = ref_s(nb.clone())
+    fake_self = _types.SimpleNamespace(config={"optim": {}, "model_attributes": {"so3_denoising": True}}, device="cpu")
+    out = {"positions": o1, "positions_free": o2}
+    loss_r = ref_compute_loss(fake_self, out, nb)
+    loss_r.backward()
+    grads_r = {k: (p.grad.clone() if p.grad is not None else None) for k, p in ref_s.named_parameters()}
+    ref_s.eval()
+    # the oracle: same loss, autograd through its own forward
+    sd_req = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd_t.items()}
+    q1, q2 = O.painn_forward(sd_req, ob["pos"], bt.atomic_numbers, bt.cell, bt.natoms, scale_factors=[1.05, 0.9], **hp)
+    loss_o, terms_o = TO.score_matching_loss(q1, q2, bt.tags, bt.batch, ob, TO.Igso3(ref_rot))
+    loss_o.backward()
+    print(f"[train] loss ref={loss_r.item():.8f} oracle={loss_o.item():.8f}")
+    assert abs(loss_r.item() - loss_o.item()) <= 1e-6 * max(1.0, abs(loss_r.item()))
+    gn = {}
+    for k, g in grads_r.items():
+        go = sd_req[k].grad
+        if g is None:
+            assert go is None or float(go.abs().max()) == 0.0, k
+            gn[k] = 0.0
+            continue
+        gn[k] = float(g.norm())
+        assert float((g - go).norm()) <= 2e-5 * max(float(g.norm()), 1e-12), (k, float((g - go).norm()), float(g.norm()))
+    unused = sorted(k for k, v in gn.items() if v == 0.0)
+    print("[train] gradients of", len(gn), "parameters match; without gradient:", unused)
+    keep = ["message_layers.1.rbf_proj.weight", "message_layers.1.rbf_proj.bias", "message_layers.1.x_proj.2.weight",
+            "message_layers.1.x_proj.0.weight", "message_layers.1.x_layernorm.weight", "update_layers.1.vec_proj.weight",
+            "update_layers.1.xvec_proj.2.weight", "update_layers.0.vec_proj.weight", "message_layers.0.rbf_proj.weight",
+            "message_layers.0.x_proj.2.bias", "atom_emb.embeddings.weight",
+            "out_forces.output_network.0.vec1_proj.weight", "out_forces2.output_network.1.update_net.2.weight",
+            "out_forces.output_network.0.update_net.0.weight"]
+    fxt = dict(pos_clean=pos_clean, pos_noised=nb.pos, tr_sigma=nb.tr_sigma, rot_sigma=nb.rot_sigma, tr_score=nb.tr_score,
+               rot_score=nb.rot_score, ads_center_noise_vec=nb.ads_center_noise_vec, out1=o1.detach(), out2=o2.detach(),
+               loss=loss_r.detach(), loss_terms=torch.stack([t.detach() for t in terms_o]), seed=2024,
+               grad_names=np.array(sorted(gn)), grad_norms=np.array([gn[k] for k in sorted(gn)]),
+               **{k: v for k, v in batch_inputs(bt).items() if k != "pos"})
+    fxt.update({"grad::" + k: grads_r[k] for k in keep})
+    fxt.update({"sd::" + k: v for k, v in sd_t.items() if k != "atom_radii"})
+    for k, v in tparams.items():
+        fxt["tp_" + k] = v
+    np.savez_compressed(GOLD / "train_small.npz", **npify(fxt))
     print("all goldens written to", GOLD)
 
 
