@@ -25,6 +25,7 @@ EXPORTS = (
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
+    "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_bwd", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
     "adf_last_error", "adf_version",
 )
 
@@ -110,12 +111,37 @@ def load():
         "adf_comm_create": [vp, i32, i32, C.POINTER(vp)],
         "adf_comm_destroy": [vp],
         "adf_allgather_sites": [vp, vp, i64, vp, vp],
+        "adf_op_linear_fwd": [vp, i32, vp, vp, vp, i32, i64, i32, i32, vp],
+        "adf_op_linear_bwd": [vp, i32, vp, vp, i32, vp, i32, i32, vp, vp, i32, i64, i32, i32, vp, vp],
+        "adf_op_ssilu_fwd": [vp, vp, i64, vp],
+        "adf_op_ssilu_bwd": [vp, vp, vp, i64, vp],
+        "adf_op_layernorm_fwd": [vp, vp, vp, vp, vp, i32, i32, vp],
+        "adf_op_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
+        "adf_op_embed_fwd": [vp, vp, i32, vp, vp],
+        "adf_op_embed_bwd": [vp, vp, vp, i32, i32, vp],
+        "adf_op_rbf": [vp, vp, vp],
+        "adf_op_message_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp],
+        "adf_op_message_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+        "adf_op_vdot_fwd": [vp, vp, vp, i32, i64, i32, C.c_float, vp],
+        "adf_op_vdot_bwd": [vp, vp, i32, vp, vp, i32, vp, vp, i64, i32, vp],
+        "adf_op_update_out_fwd": [vp, vp, vp, vp, vp, C.c_float, vp, vp, i64, i32, vp],
+        "adf_op_update_out_bwd": [vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+        "adf_op_vnorm_fwd": [vp, vp, i32, i64, i32, vp],
+        "adf_op_vnorm_bwd": [vp, vp, i32, vp, i32, vp, i64, i32, vp],
+        "adf_op_gate_fwd": [vp, vp, vp, i32, vp, i64, i32, vp],
+        "adf_op_gate_bwd": [vp, vp, vp, i32, vp, vp, vp, i64, i32, vp],
+        "adf_op_copy_rows": [vp, i32, vp, i32, i64, i32, i32, vp],
+        "adf_op_score_loss": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
+        "adf_op_sqnorm_accumulate": [vp, i64, vp, vp],
+        "adf_op_adamw_step": [vp, vp, vp, vp, vp, i64, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float, vp],
         "adf_sample": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = i32
+    lib.adf_op_linear_bwd_scratch.argtypes = [i64, i32, i32]
+    lib.adf_op_linear_bwd_scratch.restype = i64
     _LIB = lib
     return lib
 

@@ -1,0 +1,73 @@
+"""Forward noising of a training batch — mirror of ``tr_so3_schedule`` / ``pbc_correction``
+(adsorbdiff/trainers/sde_denoising_trainer.py:45-135): per system a diffusion time t ~ U(0,1), a Gaussian in-plane
+displacement of the adsorbate's centre of mass (minimum-image wrapped), an IGSO(3) rotation about it and the +1 A lift;
+the batch gets ``tr_sigma, rot_sigma, tr_score, rot_score, ads_center_noise_vec`` attached and its adsorbate positions
+overwritten, exactly like the reference's in-place version.  Host-side data preparation (B rows of 3-vectors per
+batch); random streams are consumed in the reference's order (torch.rand, torch normal_, then numpy per system).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .so3_tables import Igso3Tables
+
+
+def axis_angle_to_matrix(v: torch.Tensor) -> torch.Tensor:
+    """[3] axis-angle -> [3,3] via the unit quaternion (adsorbdiff/utils/rot_utils.py:18-98, small-angle series below 1e-6)."""
+    ang = torch.linalg.norm(v)
+    half = 0.5 * ang
+    k = 0.5 - ang * ang / 48 if float(ang.abs()) < 1e-6 else torch.sin(half) / ang
+    qr, (qi, qj, qk) = torch.cos(half), v * k
+    two_s = 2.0 / (qr * qr + qi * qi + qj * qj + qk * qk)
+    return torch.stack([
+        1 - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+        two_s * (qi * qj + qk * qr), 1 - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
+        two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)]).reshape(3, 3)
+
+
+@torch.no_grad()
+def pbc_correction(noise_vec: torch.Tensor, cell: torch.Tensor) -> torch.Tensor:
+    """[B,3] vectors wrapped to the minimum image of their system's cell: fractional coordinates by an fp64 solve with
+    cell^T, into (-0.5, 0.5], back with the rows of cell."""
+    frac = torch.linalg.solve(cell.transpose(1, 2).double(), noise_vec.double().unsqueeze(-1)).squeeze(-1)
+    frac = frac % 1.0 % 1.0
+    frac = torch.where(frac > 0.5, frac - 1, frac)
+    return torch.einsum("bi,bij->bj", frac.float(), cell.float())
+
+
+@torch.no_grad()
+def tr_so3_schedule(batch, denoise_pos_params: dict, tables: Igso3Tables = None):
+    tables = tables or Igso3Tables.shared()
+    lo, hi = denoise_pos_params["ads_std_low"], denoise_pos_params["ads_std_high"]
+    rlo, rhi = denoise_pos_params["rot_std_low"], denoise_pos_params["rot_std_high"]
+    dev = batch.pos.device
+    B = int(batch.natoms.shape[0])
+    t = torch.rand(size=(B,), device=dev)
+    tr_sigma = lo ** (1 - t) * hi**t
+    rot_sigma = rlo ** (1 - t) * rhi**t
+    ads = batch.tags == 2
+    bidx = batch.batch[ads]
+    cnt = torch.zeros(B, device=dev).index_add_(0, bidx, torch.ones(bidx.shape[0], device=dev))
+    center = torch.zeros(B, 3, device=dev).index_add_(0, bidx, batch.pos[ads]) / cnt[:, None]
+    noise = torch.zeros(center.shape, device=dev).normal_() * tr_sigma[:, None]
+    noise = pbc_correction(noise, batch.cell.reshape(B, 3, 3))
+    noise[:, -1] = 0
+    rot_sigma_h = rot_sigma.cpu()
+    R, rot_score = [], []
+    for b in range(B):
+        eps = rot_sigma_h[b].item()
+        upd = tables.sample_vec(eps=eps)
+        R.append(axis_angle_to_matrix(torch.tensor(upd)).float())
+        rot_score.append(torch.from_numpy(tables.score_vec(vec=upd, eps=eps)).float())
+    R = torch.stack(R).to(dev)
+    rel = batch.pos[ads] - center[bidx]
+    new_ads = torch.einsum("nj,nij->ni", rel, R[bidx]) + noise[bidx] + center[bidx]
+    new_ads[:, -1] += 1  # the reference lifts the noised adsorbate by 1 A
+    batch.pos = batch.pos.clone()
+    batch.pos[ads] = new_ads
+    batch.tr_sigma, batch.rot_sigma = tr_sigma[:, None], rot_sigma[:, None]
+    batch.rot_score = torch.stack(rot_score).to(dev)
+    batch.ads_center_noise_vec = noise
+    batch.tr_score = -noise / tr_sigma[:, None] ** 2
+    return batch

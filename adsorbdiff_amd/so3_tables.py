@@ -1,0 +1,94 @@
+"""IGSO(3) tables of the rotation noise: sampling CDF, score magnitude and expected score norm on the reference's
+(eps, omega) grid — what ``adsorbdiff/utils/rot_utils.py:140-264`` precomputes at import time (~6 min of numpy there).
+
+Here the series  f(w) = sum_l (2l+1) exp(-l(l+1) eps^2) sin((l+1/2) w) / sin(w/2)  (L = 2000 terms, 1000 eps values x
+2000 angles) is evaluated in fp64 torch ops on the ROCm device when there is one (a few seconds), otherwise on the host,
+and cached as ``adsorbdiff_amd/_cache/igso3_v1.npz``.  Look-ups (``sample_vec``, ``score_vec``, ``score_norm``) follow the
+reference's nearest-row / linear-interpolation rules and consume numpy's global random stream in the same order.
+Pinned against the reference's own tables by tests/golden/igso3_tables.npz (oracle/make_golden.py section 6).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+MIN_EPS, MAX_EPS, N_EPS = 0.01, 2, 1000
+X_N = 2000
+L_TERMS = 2000
+_CACHE = Path(__file__).resolve().parent / "_cache" / "igso3_v1.npz"
+
+
+def compute_tables(device: Optional[torch.device] = None, rows=None) -> dict:
+    """cdf [n, X_N], score [n, X_N], exp_score_norm [n] for the listed eps rows (default: all N_EPS)."""
+    if device is None:
+        device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    f64 = torch.float64
+    rows = np.arange(N_EPS) if rows is None else np.asarray(rows).reshape(-1)
+    eps_all = 10 ** np.linspace(np.log10(MIN_EPS), np.log10(MAX_EPS), N_EPS)
+    om = torch.from_numpy(np.linspace(0, np.pi, X_N + 1)[1:]).to(device, f64)
+    l = torch.arange(L_TERMS, dtype=f64, device=device)[:, None]
+    arg = om[None, :] * (l + 0.5)
+    hi, dhi = torch.sin(arg), (l + 0.5) * torch.cos(arg)
+    lo, dlo = torch.sin(om / 2), 0.5 * torch.cos(om / 2)
+    ratio = hi / lo[None, :]
+    dratio = (lo[None, :] * dhi - hi * dlo[None, :]) / lo[None, :] ** 2
+    cdf = np.empty((len(rows), X_N))
+    score = np.empty((len(rows), X_N))
+    esn = np.empty(len(rows))
+    marg = (1 - torch.cos(om)) / np.pi
+    for i, r in enumerate(rows):
+        w = (2 * l + 1) * torch.exp(-l * (l + 1) * float(eps_all[int(r)]) ** 2)
+        expansion = (w * ratio).sum(0)
+        sc = (w * dratio).sum(0) / expansion
+        pdf = expansion * marg
+        cdf[i] = (pdf.cumsum(0) / X_N * np.pi).cpu().numpy()
+        score[i] = sc.cpu().numpy()
+        esn[i] = float(torch.sqrt((sc**2 * pdf).sum() / pdf.sum() / np.pi))
+    return {"omegas": om.cpu().numpy(), "cdf": cdf, "score": score, "exp_score_norm": esn, "rows": rows}
+
+
+class Igso3Tables:
+    _shared = None
+
+    def __init__(self, omegas, cdf, score, exp_score_norm) -> None:
+        self.omegas = np.asarray(omegas)
+        self.cdf = cdf                    # [N_EPS, X_N] or None (only needed by sample / sample_vec)
+        self.score = score                # [N_EPS, X_N] or None (only needed by score_vec)
+        self.exp_score_norm = np.asarray(exp_score_norm)
+
+    @classmethod
+    def shared(cls) -> "Igso3Tables":
+        """The full tables: loaded from the cache file, computed (and cached) on first use."""
+        if cls._shared is None:
+            if _CACHE.exists():
+                z = np.load(_CACHE)
+                cls._shared = cls(z["omegas"], z["cdf"], z["score"], z["exp_score_norm"])
+            else:
+                t = compute_tables()
+                _CACHE.parent.mkdir(exist_ok=True)
+                np.savez(_CACHE, omegas=t["omegas"], cdf=t["cdf"], score=t["score"], exp_score_norm=t["exp_score_norm"])
+                cls._shared = cls(t["omegas"], t["cdf"], t["score"], t["exp_score_norm"])
+        return cls._shared
+
+    @staticmethod
+    def eps_index(eps):
+        idx = (np.log10(eps) - np.log10(MIN_EPS)) / (np.log10(MAX_EPS) - np.log10(MIN_EPS)) * N_EPS
+        return np.clip(np.around(idx).astype(int), a_min=0, a_max=N_EPS - 1)
+
+    def sample(self, eps) -> float:
+        return float(np.interp(np.random.rand(), self.cdf[self.eps_index(eps)], self.omegas))
+
+    def sample_vec(self, eps) -> np.ndarray:
+        x = np.random.randn(3)
+        x /= np.linalg.norm(x)
+        return x * self.sample(eps)
+
+    def score_vec(self, eps, vec) -> np.ndarray:
+        om = np.linalg.norm(vec)
+        return np.interp(om, self.omegas, self.score[self.eps_index(eps)]) * vec / om
+
+    def score_norm(self, eps: torch.Tensor) -> torch.Tensor:
+        return torch.from_numpy(self.exp_score_norm[self.eps_index(eps.detach().cpu().numpy())]).float()

@@ -1,0 +1,361 @@
+"""Score-matching training step of the PaiNN denoiser on the device (BASELINE config 5).
+
+Replaces, for this model, what the reference's trainer does per step
+(adsorbdiff/trainers/sde_denoising_trainer.py:370-537, 675-728; base_trainer.py:787-820):
+
+    tr_so3_schedule (noising)  ->  model forward  ->  _compute_loss  ->  loss.backward()
+    ->  clip_grad_norm_  ->  AdamW.step  ->  EMA.update           (+ DDP gradient all-reduce)
+
+Every arithmetic operation of forward, loss, backward and optimizer runs in hand-written HIP kernels behind the C ABI
+(csrc/train.hip, csrc/gemm.hip, csrc/graph.hip); this module only sequences the calls and owns the buffers (PyTorch as
+allocator / stream / collective plumbing).  There is no autograd graph: `PaiNNTrainStep.loss_and_grad` writes the
+gradients straight into ``param.grad`` of the mirror module, so ``torch.nn.parallel``-style code, checkpoints and the
+reference's parameter naming keep working.
+
+Status (round 2): correctness-first - exact f32, materialised radial projection, unfused elementwise kernels.  Pinned
+against the reference's own autograd (tests/golden/train_small.npz: loss + gradients, oracle/make_golden.py section 6).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .so3_tables import Igso3Tables
+
+
+class _Ops:
+    """Thin typed wrappers over the adf_op_* entry points (device pointers in, status out)."""
+
+    def __init__(self, device) -> None:
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        self._scratch = torch.empty(0, device=self.dev)
+
+    def s(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def scratch(self, n: int) -> torch.Tensor:
+        if self._scratch.numel() < n:
+            self._scratch = torch.empty(int(n * 1.25) + 1024, device=self.dev)
+        return self._scratch
+
+    def new(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, dtype=torch.float32, device=self.dev)
+
+    def linear(self, A, W, b, M, N, K, lda=None, out=None, ldc=None):
+        if out is None:
+            out = self.new(M, N)
+        _lib.check(self.lib.adf_op_linear_fwd(A.data_ptr(), lda or K, W.data_ptr(), b.data_ptr() if b is not None else None,
+                                              out.data_ptr(), ldc or N, M, N, K, self.s()))
+        return out
+
+    def linear_bwd(self, A, W, dC, M, N, K, dW, db, want_dA=True, dA=None, lda=None, ldc=None, ldda=None, acc_dA=False):
+        if want_dA and dA is None:
+            dA = self.new(M, K)
+        sc = self.scratch(int(self.lib.adf_op_linear_bwd_scratch(M, N, K)))
+        _lib.check(self.lib.adf_op_linear_bwd(
+            A.data_ptr() if A is not None else None, lda or K, W.data_ptr(), dC.data_ptr(), ldc or N,
+            dA.data_ptr() if want_dA else None, ldda or K, 1 if acc_dA else 0,
+            dW.data_ptr() if dW is not None else None, db.data_ptr() if db is not None else None, 1, M, N, K,
+            sc.data_ptr(), self.s()))
+        return dA
+
+
+class PaiNNTrainStep:
+    """loss + gradients of the score-matching objective for a mirror ``PaiNN`` module on a ROCm device."""
+
+    def __init__(self, model, device="cuda:0", igso3: Optional[Igso3Tables] = None) -> None:
+        self.model = model
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("PaiNNTrainStep needs a ROCm device (the HIP path has no CPU fallback)")
+        if not model.so3_denoising:
+            raise NotImplementedError("the training step is written for so3_denoising=True (two heads)")
+        self.ops = _Ops(self.dev)
+        self.lib = self.ops.lib
+        self.igso3 = igso3 or Igso3Tables.shared()
+
+    # ------------------------------------------------------------------ helpers
+    def _params(self) -> Dict[str, torch.nn.Parameter]:
+        return dict(self.model.named_parameters())
+
+    def zero_grad(self) -> None:
+        for p in self.model.parameters():
+            if p.requires_grad:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                else:
+                    p.grad.zero_()
+
+    # ------------------------------------------------------------------ the step
+    def loss_and_grad(self, batch, targets: dict) -> torch.Tensor:
+        """``batch``: noised batch on the device (pos, atomic_numbers, tags, batch, natoms, cell); ``targets``: tr_sigma
+        [B,1], rot_sigma [B,1], tr_score [B,3], rot_score [B,3] (what tr_so3_schedule attaches to the batch).
+        Accumulates into ``param.grad`` (call zero_grad first, like optimizer.zero_grad) and returns the device tensor
+        (loss, translation term, rotation term)."""
+        m, ops, lib = self.model, self.ops, self.lib
+        P = self._params()
+        H, L, R = m.hidden_channels, m.num_layers, m.num_rbf
+        eng = m.engine(self.dev)
+        h = eng.handle
+        E = eng.build_graph(batch)
+        prep = eng.prepare(batch)
+        N, B = prep.num_atoms, prep.num_systems
+        if prep.tags is None:
+            raise ValueError("batch.tags is required (tag 2 marks the adsorbate)")
+        s = ops.s
+        G = {k: p.grad for k, p in P.items() if p.requires_grad}
+        for k, g in G.items():
+            if g is None:
+                raise RuntimeError("call zero_grad() before loss_and_grad()")
+        scales = m.scale_factors()
+
+        # ---------------- forward with saved activations
+        x = ops.new(N, H)
+        _lib.check(lib.adf_op_embed_fwd(h, prep.atomic_numbers.data_ptr(), N, x.data_ptr(), s()))
+        eng.check_flags()
+        rbf = ops.new(E, R)
+        _lib.check(lib.adf_op_rbf(h, rbf.data_ptr(), s()))
+        vec = None
+        saved: List[dict] = []
+        for l in range(L):
+            mp, up = f"message_layers.{l}.", f"update_layers.{l}."
+            a = {"x": x, "vec": vec}
+            a["y"], a["stats"] = ops.new(N, H), ops.new(N, 2)
+            _lib.check(lib.adf_op_layernorm_fwd(x.data_ptr(), P[mp + "x_layernorm.weight"].data_ptr(),
+                                                P[mp + "x_layernorm.bias"].data_ptr(), a["y"].data_ptr(),
+                                                a["stats"].data_ptr(), N, H, s()))
+            a["h0"] = ops.linear(a["y"], P[mp + "x_proj.0.weight"], P[mp + "x_proj.0.bias"], N, H, H)
+            a["c"] = ops.new(N, H)
+            _lib.check(lib.adf_op_ssilu_fwd(a["h0"].data_ptr(), a["c"].data_ptr(), N * H, s()))
+            a["xh"] = ops.linear(a["c"], P[mp + "x_proj.2.weight"], P[mp + "x_proj.2.bias"], N, 3 * H, H)
+            a["rbfh"] = ops.linear(rbf, P[mp + "rbf_proj.weight"], P[mp + "rbf_proj.bias"], E, 3 * H, R)
+            a["x1"], a["vec1"] = ops.new(N, H), ops.new(N, 3, H)
+            _lib.check(lib.adf_op_message_fwd(h, a["xh"].data_ptr(), vec.data_ptr() if vec is not None else None,
+                                              a["rbfh"].data_ptr(), x.data_ptr(), a["x1"].data_ptr(), a["vec1"].data_ptr(),
+                                              1 if vec is None else 0, s()))
+            a["vv"] = ops.linear(a["vec1"], P[up + "vec_proj.weight"], None, 3 * N, 2 * H, H)
+            a["cat"], a["dot"] = ops.new(N, 2 * H), ops.new(N, H)
+            _lib.check(lib.adf_op_copy_rows(a["x1"].data_ptr(), H, a["cat"].data_ptr(), 2 * H, N, H, 0, s()))
+            _lib.check(lib.adf_op_vdot_fwd(a["vv"].data_ptr(), a["dot"].data_ptr(), a["cat"].data_ptr() + 4 * H, 2 * H, N, H,
+                                           C.c_float(1e-8), s()))
+            a["u0"] = ops.linear(a["cat"], P[up + "xvec_proj.0.weight"], P[up + "xvec_proj.0.bias"], N, H, 2 * H)
+            a["ua"] = ops.new(N, H)
+            _lib.check(lib.adf_op_ssilu_fwd(a["u0"].data_ptr(), a["ua"].data_ptr(), N * H, s()))
+            a["a"] = ops.linear(a["ua"], P[up + "xvec_proj.2.weight"], P[up + "xvec_proj.2.bias"], N, 3 * H, H)
+            x2, vec2 = ops.new(N, H), ops.new(N, 3, H)
+            _lib.check(lib.adf_op_update_out_fwd(a["x1"].data_ptr(), a["vec1"].data_ptr(), a["a"].data_ptr(),
+                                                 a["dot"].data_ptr(), a["vv"].data_ptr(), C.c_float(scales[l]),
+                                                 x2.data_ptr(), vec2.data_ptr(), N, H, s()))
+            saved.append(a)
+            x, vec = x2, vec2
+
+        heads = []
+        outs = []
+        for hname in ("out_forces", "out_forces2"):
+            hs = {}
+            xin, vin, Cin = x, vec, H
+            for blk, Cout in ((0, H // 2), (1, 1)):
+                q = f"{hname}.output_network.{blk}."
+                b = {"xin": xin, "vin": vin, "Cin": Cin, "Cout": Cout}
+                b["t1"] = ops.linear(vin, P[q + "vec1_proj.weight"], None, 3 * N, Cin, Cin)
+                b["cat"] = ops.new(N, 2 * Cin)
+                _lib.check(lib.adf_op_copy_rows(xin.data_ptr(), Cin, b["cat"].data_ptr(), 2 * Cin, N, Cin, 0, s()))
+                _lib.check(lib.adf_op_vnorm_fwd(b["t1"].data_ptr(), b["cat"].data_ptr() + 4 * Cin, 2 * Cin, N, Cin, s()))
+                b["t2"] = ops.linear(vin, P[q + "vec2_proj.weight"], None, 3 * N, Cout, Cin)
+                b["g0"] = ops.linear(b["cat"], P[q + "update_net.0.weight"], P[q + "update_net.0.bias"], N, Cin, 2 * Cin)
+                b["ga"] = ops.new(N, Cin)
+                _lib.check(lib.adf_op_ssilu_fwd(b["g0"].data_ptr(), b["ga"].data_ptr(), N * Cin, s()))
+                b["o"] = ops.linear(b["ga"], P[q + "update_net.2.weight"], P[q + "update_net.2.bias"], N, 2 * Cout, Cin)
+                b["xs"], b["vout"] = ops.new(N, Cout), ops.new(N, 3, Cout)
+                _lib.check(lib.adf_op_gate_fwd(b["o"].data_ptr(), b["t2"].data_ptr(), b["xs"].data_ptr(), Cout,
+                                               b["vout"].data_ptr(), N, Cout, s()))
+                hs[blk] = b
+                xin, vin, Cin = b["xs"], b["vout"], Cout
+            heads.append(hs)
+            outs.append(vin.reshape(N, 3))
+        f1, f2 = outs
+
+        # ---------------- loss and its gradient with respect to the two heads' outputs
+        t = {k: targets[k].to(self.dev, torch.float32).contiguous() for k in ("tr_sigma", "rot_sigma", "tr_score", "rot_score")}
+        rot_norm = self.igso3.score_norm(t["rot_sigma"].reshape(-1).cpu()).to(self.dev).contiguous()
+        loss = ops.new(3)
+        df1, df2 = ops.new(N, 3), ops.new(N, 3)
+        _lib.check(lib.adf_op_score_loss(f1.data_ptr(), f2.data_ptr(), prep.tags.data_ptr(), prep.atom_offset.data_ptr(),
+                                         t["tr_sigma"].data_ptr(), t["rot_sigma"].data_ptr(), t["tr_score"].data_ptr(),
+                                         t["rot_score"].data_ptr(), rot_norm.data_ptr(), loss.data_ptr(), df1.data_ptr(),
+                                         df2.data_ptr(), B, ops.scratch(2 * B + 16).data_ptr(), s()))
+
+        # ---------------- backward: heads
+        dx = torch.zeros(N, H, device=self.dev)
+        dvec = torch.zeros(N, 3, H, device=self.dev)
+        for hname, hs, dout in (("out_forces", heads[0], df1), ("out_forces2", heads[1], df2)):
+            dxs, dv = None, dout.reshape(N, 3, 1)
+            for blk in (1, 0):
+                b = hs[blk]
+                q = f"{hname}.output_network.{blk}."
+                Cin, Cout = b["Cin"], b["Cout"]
+                d_o, dt2 = ops.new(N, 2 * Cout), ops.new(N, 3, Cout)
+                _lib.check(lib.adf_op_gate_bwd(b["o"].data_ptr(), b["t2"].data_ptr(), dxs.data_ptr() if dxs is not None else None,
+                                               Cout, dv.data_ptr(), d_o.data_ptr(), dt2.data_ptr(), N, Cout, s()))
+                dga = ops.linear_bwd(b["ga"], P[q + "update_net.2.weight"], d_o, N, 2 * Cout, Cin,
+                                     G[q + "update_net.2.weight"], G[q + "update_net.2.bias"])
+                dg0 = ops.new(N, Cin)
+                _lib.check(lib.adf_op_ssilu_bwd(b["g0"].data_ptr(), dga.data_ptr(), dg0.data_ptr(), N * Cin, s()))
+                dcat = ops.linear_bwd(b["cat"], P[q + "update_net.0.weight"], dg0, N, Cin, 2 * Cin,
+                                      G[q + "update_net.0.weight"], G[q + "update_net.0.bias"])
+                dt1 = ops.new(N, 3, Cin)
+                _lib.check(lib.adf_op_vnorm_bwd(b["t1"].data_ptr(), b["cat"].data_ptr() + 4 * Cin, 2 * Cin,
+                                                dcat.data_ptr() + 4 * Cin, 2 * Cin, dt1.data_ptr(), N, Cin, s()))
+                # gradient of this block's inputs: x from the left half of dcat, v from the two projections
+                if blk == 1:
+                    dxs_in, dv_in = ops.new(N, Cin), ops.new(N, 3, Cin)
+                    tgt_x, ldx, tgt_v, acc = dxs_in, Cin, dv_in, False
+                else:
+                    tgt_x, ldx, tgt_v, acc = dx, H, dvec, True
+                _lib.check(lib.adf_op_copy_rows(dcat.data_ptr(), 2 * Cin, tgt_x.data_ptr(), ldx, N, Cin, 1 if acc else 0, s()))
+                ops.linear_bwd(b["vin"], P[q + "vec1_proj.weight"], dt1, 3 * N, Cin, Cin, G[q + "vec1_proj.weight"], None,
+                               dA=tgt_v, acc_dA=acc)
+                ops.linear_bwd(b["vin"], P[q + "vec2_proj.weight"], dt2, 3 * N, Cout, Cin, G[q + "vec2_proj.weight"], None,
+                               dA=tgt_v, acc_dA=True)
+                if blk == 1:
+                    dxs, dv = dxs_in, dv_in
+
+        # ---------------- backward: layers, last to first
+        for l in range(L - 1, -1, -1):
+            a = saved[l]
+            mp, up = f"message_layers.{l}.", f"update_layers.{l}."
+            # update block
+            da, ddot, dv1 = ops.new(N, 3 * H), ops.new(N, H), ops.new(N, 3, H)
+            dx1, dvec1 = ops.new(N, H), ops.new(N, 3, H)
+            _lib.check(lib.adf_op_update_out_bwd(a["a"].data_ptr(), a["dot"].data_ptr(), a["vv"].data_ptr(),
+                                                 C.c_float(scales[l]), dx.data_ptr(), dvec.data_ptr(), da.data_ptr(),
+                                                 ddot.data_ptr(), dv1.data_ptr(), dx1.data_ptr(), dvec1.data_ptr(), N, H, s()))
+            dua = ops.linear_bwd(a["ua"], P[up + "xvec_proj.2.weight"], da, N, 3 * H, H, G[up + "xvec_proj.2.weight"],
+                                 G[up + "xvec_proj.2.bias"])
+            du0 = ops.new(N, H)
+            _lib.check(lib.adf_op_ssilu_bwd(a["u0"].data_ptr(), dua.data_ptr(), du0.data_ptr(), N * H, s()))
+            dcat = ops.linear_bwd(a["cat"], P[up + "xvec_proj.0.weight"], du0, N, H, 2 * H, G[up + "xvec_proj.0.weight"],
+                                  G[up + "xvec_proj.0.bias"])
+            _lib.check(lib.adf_op_copy_rows(dcat.data_ptr(), 2 * H, dx1.data_ptr(), H, N, H, 1, s()))
+            dvv = ops.new(N, 3, 2 * H)
+            _lib.check(lib.adf_op_vdot_bwd(a["vv"].data_ptr(), a["cat"].data_ptr() + 4 * H, 2 * H, ddot.data_ptr(),
+                                           dcat.data_ptr() + 4 * H, 2 * H, dv1.data_ptr(), dvv.data_ptr(), N, H, s()))
+            ops.linear_bwd(a["vec1"], P[up + "vec_proj.weight"], dvv, 3 * N, 2 * H, H, G[up + "vec_proj.weight"], None,
+                           dA=dvec1, acc_dA=True)
+            # message block
+            first = a["vec"] is None
+            dxh, drbfh = ops.new(N, 3 * H), ops.new(E, 3 * H)
+            dvec_in = None if first else ops.new(N, 3, H)
+            dx_in = ops.new(N, H)
+            _lib.check(lib.adf_op_message_bwd(h, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
+                                              a["rbfh"].data_ptr(), dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(),
+                                              drbfh.data_ptr(), dvec_in.data_ptr() if not first else None, dx_in.data_ptr(),
+                                              1 if first else 0, s()))
+            ops.linear_bwd(rbf, P[mp + "rbf_proj.weight"], drbfh, E, 3 * H, R, G[mp + "rbf_proj.weight"],
+                           G[mp + "rbf_proj.bias"], want_dA=False)
+            dc = ops.linear_bwd(a["c"], P[mp + "x_proj.2.weight"], dxh, N, 3 * H, H, G[mp + "x_proj.2.weight"],
+                                G[mp + "x_proj.2.bias"])
+            dh0 = ops.new(N, H)
+            _lib.check(lib.adf_op_ssilu_bwd(a["h0"].data_ptr(), dc.data_ptr(), dh0.data_ptr(), N * H, s()))
+            dy = ops.linear_bwd(a["y"], P[mp + "x_proj.0.weight"], dh0, N, H, H, G[mp + "x_proj.0.weight"],
+                                G[mp + "x_proj.0.bias"])
+            dlw, dlb = ops.new(H), ops.new(H)
+            _lib.check(lib.adf_op_layernorm_bwd(a["x"].data_ptr(), P[mp + "x_layernorm.weight"].data_ptr(),
+                                                a["stats"].data_ptr(), dy.data_ptr(), dx_in.data_ptr(), dlw.data_ptr(),
+                                                dlb.data_ptr(), N, H, ops.scratch(64 * 2 * H + 16).data_ptr(), s()))
+            _lib.check(lib.adf_op_copy_rows(dlw.data_ptr(), H, G[mp + "x_layernorm.weight"].data_ptr(), H, 1, H, 1, s()))
+            _lib.check(lib.adf_op_copy_rows(dlb.data_ptr(), H, G[mp + "x_layernorm.bias"].data_ptr(), H, 1, H, 1, s()))
+            dx, dvec = dx_in, dvec_in
+        _lib.check(lib.adf_op_embed_bwd(dx.data_ptr(), prep.atomic_numbers.data_ptr(),
+                                        G["atom_emb.embeddings.weight"].data_ptr(), N, H, s()))
+        self.last_outputs = (f1, f2)
+        return loss
+
+
+class FusedAdamW:
+    """AdamW + global-norm clipping + EMA, one HIP launch per parameter tensor (csrc/train.hip: tr_adamw_kernel).
+    Same update as torch.optim.AdamW(lr, betas, eps, weight_decay) preceded by clip_grad_norm_(max_norm) and followed
+    by ExponentialMovingAverage.update (base_trainer.py:787-820); parameters named by ``no_decay`` get weight_decay 0
+    (base_trainer.py:571-600, model.no_weight_decay())."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm: Optional[float] = None,
+                 ema=None) -> None:
+        self.lib = _lib.load()
+        self.model = model
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.ema = ema
+        self.step_count = 0
+        no_decay = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
+        self.entries = []
+        for name, p in model.named_parameters():
+            if p.requires_grad:
+                self.entries.append((name, p, torch.zeros_like(p), torch.zeros_like(p), name in no_decay))
+        self.sqnorm = None
+
+    def step(self) -> torch.Tensor:
+        """Applies the update from ``param.grad``; returns the (pre-clip) global gradient norm as a device tensor."""
+        self.step_count += 1
+        dev = self.entries[0][1].device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if self.sqnorm is None:
+            self.sqnorm = torch.zeros(1, device=dev)
+        self.sqnorm.zero_()
+        for _, p, _, _, _ in self.entries:
+            if p.grad is not None:
+                _lib.check(self.lib.adf_op_sqnorm_accumulate(p.grad.data_ptr(), p.numel(), self.sqnorm.data_ptr(), stream))
+        shadows = self.ema.shadow_params if self.ema is not None else None
+        decay = 0.0
+        if self.ema is not None:
+            decay = self.ema.decay
+            if self.ema.num_updates is not None:
+                self.ema.num_updates += 1
+                decay = min(decay, (1 + self.ema.num_updates) / (10 + self.ema.num_updates))
+        i = 0
+        for _, p, m_, v_, nodecay in self.entries:
+            if p.grad is None:
+                i += 1
+                continue
+            _lib.check(self.lib.adf_op_adamw_step(
+                p.data_ptr(), p.grad.data_ptr(), m_.data_ptr(), v_.data_ptr(),
+                shadows[i].data_ptr() if shadows is not None else None, p.numel(), self.sqnorm.data_ptr(),
+                C.c_float(self.max_grad_norm or 0.0), C.c_float(self.lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]),
+                C.c_float(self.eps), C.c_float(0.0 if nodecay else self.weight_decay), self.step_count, C.c_float(decay),
+                stream))
+            i += 1
+        return self.sqnorm.sqrt()
+
+
+def allreduce_gradients(model, world_size: int, bucket_mb: float = 64.0) -> None:
+    """DDP step: average ``param.grad`` over the ranks in flat buckets (RCCL all-reduce over xGMI under backend nccl).
+    Parameters without a gradient on any rank (out_energy.*: the reference runs DDP with find_unused_parameters=True,
+    base_trainer.py:442-447) are skipped consistently: their .grad stays zero everywhere."""
+    if world_size <= 1:
+        return
+    import torch.distributed as dist
+
+    grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
+    bucket, size, limit = [], 0, int(bucket_mb * 2**20 / 4)
+    def flush():
+        if not bucket:
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world_size)
+        o = 0
+        for g in bucket:
+            g.copy_(flat[o : o + g.numel()].view_as(g))
+            o += g.numel()
+    for g in grads:
+        bucket.append(g)
+        size += g.numel()
+        if size >= limit:
+            flush()
+            bucket, size = [], 0
+    flush()

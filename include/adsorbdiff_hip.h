@@ -267,6 +267,57 @@ int32_t adf_comm_create(const uint8_t* id128, int32_t rank, int32_t world, adf_c
 int32_t adf_comm_destroy(adf_comm_t comm);
 int32_t adf_allgather_sites(adf_comm_t comm, const void* local, int64_t bytes_per_rank, void* out, void* stream);
 
+/* ---- Training step (score matching; SURVEY.md 8f-1, BASELINE config 5).  Device ops that adsorbdiff_amd/train_step.py
+ * strings together into forward-with-saved-activations, loss and backward of the PaiNN denoiser; they replace
+ * torch.autograd through models/painn/painn_denoising.py + DenoisingTrainer._compute_loss
+ * (trainers/sde_denoising_trainer.py:675-728) and torch.optim.AdamW + clip_grad_norm_ + the EMA update
+ * (trainers/base_trainer.py:787-820).  Exact f32.  All pointers are device pointers; ld* are row strides in floats;
+ * "acc" flags select accumulate-into instead of overwrite.  The graph ops use the handle's current graph. */
+int32_t adf_op_linear_fwd(const float* A, int32_t lda, const float* W, const float* bias, float* C, int32_t ldc, int64_t M,
+                          int32_t N, int32_t K, void* stream);
+int64_t adf_op_linear_bwd_scratch(int64_t M, int32_t N, int32_t K); /* floats of scratch adf_op_linear_bwd needs */
+int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W, const float* dC, int32_t ldc, float* dA, int32_t ldda,
+                          int32_t acc_dA, float* dW, float* db, int32_t acc_dW, int64_t M, int32_t N, int32_t K,
+                          float* scratch, void* stream);
+int32_t adf_op_ssilu_fwd(const float* h, float* y, int64_t n, void* stream);
+int32_t adf_op_ssilu_bwd(const float* h, const float* dy, float* dh, int64_t n, void* stream);
+int32_t adf_op_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int32_t N, int32_t H,
+                             void* stream);
+int32_t adf_op_layernorm_bwd(const float* x, const float* w, const float* stats, const float* dy, float* dx, float* dw,
+                             float* db, int32_t N, int32_t H, float* scratch, void* stream);
+int32_t adf_op_embed_fwd(adf_painn_t h, const int32_t* Z, int32_t N, float* x, void* stream);
+int32_t adf_op_embed_bwd(const float* dx, const int32_t* Z, float* demb, int32_t N, int32_t H, void* stream);
+int32_t adf_op_rbf(adf_painn_t h, float* rbf, void* stream);
+int32_t adf_op_message_fwd(adf_painn_t h, const float* xh, const float* vec, const float* rbfh, const float* x, float* x1,
+                           float* vec1, int32_t vec_is_zero, void* stream);
+int32_t adf_op_message_bwd(adf_painn_t h, const float* xh, const float* vec, const float* rbfh, const float* gx1,
+                           const float* gv1, float* dxh, float* drbfh, float* dvec, float* dx, int32_t vec_is_zero,
+                           void* stream);
+int32_t adf_op_vdot_fwd(const float* vv, float* dot, float* nrm, int32_t ldn, int64_t N, int32_t C, float eps, void* stream);
+int32_t adf_op_vdot_bwd(const float* vv, const float* nrm, int32_t ldn, const float* ddot, const float* dnrm, int32_t lddn,
+                        const float* dv1, float* dvv, int64_t N, int32_t C, void* stream);
+int32_t adf_op_update_out_fwd(const float* x1, const float* vec1, const float* a, const float* dot, const float* vv, float s,
+                              float* x2, float* vec2, int64_t N, int32_t H, void* stream);
+int32_t adf_op_update_out_bwd(const float* a, const float* dot, const float* vv, float s, const float* dx2,
+                              const float* dvec2, float* da, float* ddot, float* dv1, float* dx1, float* dvec1, int64_t N,
+                              int32_t H, void* stream);
+int32_t adf_op_vnorm_fwd(const float* t1, float* nrm, int32_t ldn, int64_t N, int32_t C, void* stream);
+int32_t adf_op_vnorm_bwd(const float* t1, const float* nrm, int32_t ldn, const float* dnrm, int32_t lddn, float* dt1,
+                         int64_t N, int32_t C, void* stream);
+int32_t adf_op_gate_fwd(const float* o, const float* t2, float* xs, int32_t ldx, float* vout, int64_t N, int32_t C,
+                        void* stream);
+int32_t adf_op_gate_bwd(const float* o, const float* t2, const float* dxs, int32_t lddx, const float* dvout, float* d_o,
+                        float* dt2, int64_t N, int32_t C, void* stream);
+int32_t adf_op_copy_rows(const float* src, int32_t lds_, float* dst, int32_t ldd, int64_t M, int32_t C, int32_t accumulate,
+                         void* stream);
+int32_t adf_op_score_loss(const float* f1, const float* f2, const int32_t* tags, const int32_t* atom_offset,
+                          const float* tr_sigma, const float* rot_sigma, const float* tr_score, const float* rot_score,
+                          const float* rot_norm, float* loss, float* df1, float* df2, int32_t B, float* scratch, void* stream);
+int32_t adf_op_sqnorm_accumulate(const float* g, int64_t n, float* out, void* stream);
+int32_t adf_op_adamw_step(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* sqnorm,
+                          float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                          float ema_decay, void* stream);
+
 const char* adf_last_error(void);
 const char* adf_version(void);
 

@@ -1,0 +1,103 @@
+"""Training step on the GPU against the REFERENCE's autograd: tests/golden/train_small.npz holds a
+batch noised by the reference's tr_so3_schedule, the reference model's loss (_compute_loss) and the gradients
+torch.autograd gave for its parameters (oracle/make_golden.py section 6).  Tolerance 1e-4 relative (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from adsorbdiff_amd.painn_denoising import PaiNN
+from adsorbdiff_amd.so3_tables import Igso3Tables
+from adsorbdiff_amd.train_step import FusedAdamW, PaiNNTrainStep
+from tests.helpers import batch_from_fixture, load_npz, rel_err, state_dict_from_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup():
+    fx = load_npz("train_small.npz")
+    tb = load_npz("igso3_tables.npz")
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=2, num_rbf=128, cutoff=6.0, max_neighbors=20,
+              scale_file={"upd_out_scalar_scale_0": 1.05, "upd_out_scalar_scale_1": 0.9}, so3_denoising=True)
+    missing, unexpected = m.load_state_dict(state_dict_from_fixture(fx), strict=False)
+    assert set(missing) <= {"atom_radii"} and not unexpected
+    m = m.to(DEV)
+    b = batch_from_fixture(fx, pos_key="pos_noised", device=DEV)
+    targets = {k: torch.from_numpy(fx[k]) for k in ("tr_sigma", "rot_sigma", "tr_score", "rot_score")}
+    tables = Igso3Tables(tb["omegas"], None, None, tb["exp_score_norm"])
+    return fx, m, b, targets, tables
+
+
+def test_loss_and_gradients_vs_reference_autograd():
+    fx, m, b, targets, tables = _setup()
+    step = PaiNNTrainStep(m, DEV, igso3=tables)
+    step.zero_grad()
+    loss = step.loss_and_grad(b, targets).cpu()
+    # forward outputs and the loss
+    assert rel_err(step.last_outputs[0].cpu(), fx["out1"]) < 1e-5 and rel_err(step.last_outputs[1].cpu(), fx["out2"]) < 1e-5
+    assert abs(float(loss[0]) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    np.testing.assert_allclose(loss[1:].numpy(), fx["loss_terms"], rtol=1e-5)
+    # every parameter's gradient norm, and the full gradient of the stored ones
+    P = dict(m.named_parameters())
+    for name, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        name = str(name)
+        p = P[name]
+        if not p.requires_grad:
+            continue
+        got = float(p.grad.norm())
+        if gn == 0.0:
+            assert got == 0.0, name  # out_energy.*: no path to the loss (DDP find_unused_parameters in the reference)
+        else:
+            assert abs(got - gn) < 1e-4 * gn, (name, got, gn)
+    for key in fx:
+        if key.startswith("grad::"):
+            name = key[6:]
+            assert rel_err(P[name].grad.cpu(), fx[key]) < 1e-4, (name, rel_err(P[name].grad.cpu(), fx[key]))
+
+
+def test_gradients_are_reproducible_and_accumulate():
+    fx, m, b, targets, tables = _setup()
+    step = PaiNNTrainStep(m, DEV, igso3=tables)
+    step.zero_grad()
+    step.loss_and_grad(b, targets)
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}
+    step.zero_grad()
+    step.loss_and_grad(b, targets)
+    for k, p in m.named_parameters():
+        if p.requires_grad and k != "atom_emb.embeddings.weight":  # the embedding gradient uses float atomics
+            assert torch.equal(p.grad, g1[k]), k
+    step.loss_and_grad(b, targets)  # no zero_grad: gradients add up
+    k = "message_layers.1.rbf_proj.weight"
+    assert rel_err(dict(m.named_parameters())[k].grad, 2 * g1[k]) < 1e-6
+
+
+def test_fused_adamw_matches_torch_adamw_clip_ema():
+    """AdamW + clip_grad_norm_ + EMA in one kernel per tensor == torch.optim.AdamW, torch clip and the EMA mirror."""
+    from adsorbdiff_amd.exponential_moving_average import ExponentialMovingAverage
+
+    fx, m, b, targets, tables = _setup()
+    step = PaiNNTrainStep(m, DEV, igso3=tables)
+    ref = PaiNN(None, 50, 1, hidden_channels=128, num_layers=2, num_rbf=128, cutoff=6.0, max_neighbors=20,
+                scale_file={"upd_out_scalar_scale_0": 1.05, "upd_out_scalar_scale_1": 0.9}, so3_denoising=True).to(DEV)
+    ref.load_state_dict(m.state_dict())
+    no_decay = set(ref.no_weight_decay())
+    groups = [{"params": [p for n, p in ref.named_parameters() if p.requires_grad and n in no_decay], "weight_decay": 0.0},
+              {"params": [p for n, p in ref.named_parameters() if p.requires_grad and n not in no_decay], "weight_decay": 0.01}]
+    topt = torch.optim.AdamW(groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    ema_ref = ExponentialMovingAverage(ref.parameters(), 0.99)
+    ema = ExponentialMovingAverage(m.parameters(), 0.99)
+    opt = FusedAdamW(m, lr=1e-3, weight_decay=0.01, max_grad_norm=0.05, ema=ema)
+    for it in range(3):
+        step.zero_grad()
+        step.loss_and_grad(b, targets)
+        for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            q.grad = p.grad.clone() if p.requires_grad else None
+        gn_ref = torch.nn.utils.clip_grad_norm_([q for q in ref.parameters() if q.grad is not None], max_norm=0.05)
+        topt.step()
+        ema_ref.update()
+        gn = opt.step()
+        assert abs(float(gn) - float(gn_ref)) < 1e-5 * float(gn_ref)
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.detach(), q.detach()) < 2e-6, n
+    for s1, s2 in zip(ema.shadow_params, ema_ref.shadow_params):
+        assert rel_err(s1, s2) < 2e-6

@@ -127,3 +127,45 @@ def test_early_stop_rule():
     """Cumulative (not consecutive) count, break before applying the 10th converged step."""
     fx = load_npz("stepper_ode_early.npz")
     assert fx["pos_log"].shape[0] == 10  # the reference made exactly 10 model calls out of 40
+
+
+def test_igso3_tables_product_vs_reference_rows():
+    """adsorbdiff_amd/so3_tables.py (torch, fp64) against sub-sampled rows of the reference's own cached tables."""
+    from adsorbdiff_amd.so3_tables import Igso3Tables, compute_tables
+
+    z = load_npz("igso3_tables.npz")
+    t = compute_tables(torch.device("cpu"), rows=z["eps_rows"][[0, 2, 5]])
+    cols = z["om_cols"]
+    np.testing.assert_allclose(t["cdf"][:, cols], z["cdf"][[0, 2, 5]], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(t["exp_score_norm"], z["exp_score_norm"][z["eps_rows"][[0, 2, 5]]], rtol=1e-8)
+    # the score table is a ratio of two series that both vanish where the density does: compare where an angle can occur
+    pdf = np.diff(np.concatenate([np.zeros((3, 1)), t["cdf"]], 1), axis=1)[:, cols]
+    live = pdf > 1e-9 * pdf.max(axis=1, keepdims=True)
+    np.testing.assert_allclose(t["score"][:, cols][live], z["score"][[0, 2, 5]][live], rtol=1e-7)
+    tab = Igso3Tables(z["omegas"], None, None, z["exp_score_norm"])
+    eps = torch.tensor([0.01, 0.3, 1.55])
+    assert tab.score_norm(eps).shape == (3,) and float(tab.score_norm(eps)[0]) > float(tab.score_norm(eps)[2])
+
+
+def test_noising_mirror_vs_reference_fixture():
+    """adsorbdiff_amd/noising.py::tr_so3_schedule under the reference's seeds reproduces the reference's noised batch
+    (tests/golden/train_small.npz), given tables - here the oracle's rows for the four sigmas involved."""
+    from adsorbdiff_amd.noising import tr_so3_schedule
+    from adsorbdiff_amd.so3_tables import Igso3Tables
+    from oracle import train_oracle as TO
+
+    fx = load_npz("train_small.npz")
+    b = batch_from_fixture(fx, pos_key="pos_clean")
+    params = dict(ads_std_low=float(fx["tp_ads_std_low"]), ads_std_high=float(fx["tp_ads_std_high"]),
+                  rot_std_low=float(fx["tp_rot_std_low"]), rot_std_high=float(fx["tp_rot_std_high"]))
+    rows = np.unique(Igso3Tables.eps_index(fx["rot_sigma"].reshape(-1)))
+    sub = TO.igso3_rows(rows)
+    cdf = np.zeros((1000, 2000)); score = np.zeros((1000, 2000)); esn = np.zeros(1000)
+    cdf[rows], score[rows], esn[rows] = sub["cdf"], sub["score"], sub["exp_score_norm"]
+    tables = Igso3Tables(sub["omegas"], cdf, score, esn)
+    torch.manual_seed(int(fx["seed"]))
+    np.random.seed(int(fx["seed"]))
+    nb = tr_so3_schedule(b, params, tables)
+    for key, fkey in (("pos", "pos_noised"), ("tr_sigma", "tr_sigma"), ("rot_sigma", "rot_sigma"), ("tr_score", "tr_score"),
+                      ("rot_score", "rot_score"), ("ads_center_noise_vec", "ads_center_noise_vec")):
+        np.testing.assert_allclose(getattr(nb, key).numpy(), fx[fkey], rtol=2e-5, atol=2e-5, err_msg=key)
