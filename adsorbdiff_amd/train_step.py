@@ -346,7 +346,12 @@ def allreduce_gradients(model, world_size: int, bucket_mb: float = 64.0) -> None
         if not bucket:
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if dist.get_backend() == "gloo" and flat.is_cuda:  # test configuration: several ranks on one GPU
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world_size)
         o = 0
         for g in bucket:

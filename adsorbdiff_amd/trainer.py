@@ -4,8 +4,10 @@ denoising_torch.py:38,491-500): ``predict_denoising(batch, per_image=False)``,
 ``_unwrapped_model``, ``ema``, ``scaler``, ``device``, ``config["model_attributes"]`` and
 ``run_relaxations`` (the ``run-relaxations`` task entry, tasks/task.py:90-100).
 
-Training (``train/validate/_compute_loss``), datasets, logging and checkpoint *writing* are out
-of scope; ``load_checkpoint`` reads the reference's checkpoint layout
+``train_step`` is the per-batch body of the reference's training loop (sde_denoising_trainer.py:410-441 +
+base_trainer.py:787-820): noising, forward, loss, backward, gradient all-reduce, clipping, AdamW, EMA — all device
+arithmetic in HIP kernels (adsorbdiff_amd/train_step.py).  Datasets, LR schedules, logging, evaluation and checkpoint
+*writing* stay out of scope; ``load_checkpoint`` reads the reference's checkpoint layout
 (base_trainer.py:456-533) so trained weights can be sampled with.
 """
 from __future__ import annotations
@@ -77,6 +79,45 @@ class DenoisingTrainer:
             if self.ema:
                 self.ema.restore()
         return predictions
+
+    # ---------------------------------------------------------------- training
+    def setup_training(self, denoising_pos_params: dict, lr: float = 1e-3, weight_decay: float = 0.001,
+                       clip_grad_norm: float = 100.0, ema_decay: float = 0.999, tables=None) -> None:
+        """Optimizer / EMA / noising parameters; defaults = configs/denoising/painn_so3.yml:56-83 (AdamW, weight decay
+        1e-3 except no_weight_decay() names, clip 100, EMA 0.999)."""
+        from .exponential_moving_average import ExponentialMovingAverage
+        from .train_step import FusedAdamW, PaiNNTrainStep
+
+        self.denoising_pos_params = dict(denoising_pos_params)
+        self.train_engine = PaiNNTrainStep(self._unwrapped_model, self.device, igso3=tables)
+        if ema_decay:
+            self.ema = ExponentialMovingAverage(self._unwrapped_model.parameters(), ema_decay)
+        self.optimizer = FusedAdamW(self._unwrapped_model, lr=lr, weight_decay=weight_decay, max_grad_norm=clip_grad_norm,
+                                    ema=self.ema)
+        self.step = 0
+
+    def train_step(self, batch, noised: bool = False) -> dict:
+        """One optimisation step on ``batch`` (clean positions unless ``noised``).  Multi-GPU: one process per GPU, each
+        with its own batch; gradients are averaged with a bucketed all-reduce (RCCL over xGMI under backend nccl)."""
+        import torch.distributed as dist
+
+        from .noising import tr_so3_schedule
+        from .train_step import allreduce_gradients
+
+        self.model.train()
+        batch = batch.to(self.device)
+        if hasattr(batch, "pos_relaxed"):
+            batch.pos = batch.pos_relaxed
+        if not noised:
+            batch = tr_so3_schedule(batch, self.denoising_pos_params, self.train_engine.igso3)
+        targets = {k: getattr(batch, k) for k in ("tr_sigma", "rot_sigma", "tr_score", "rot_score")}
+        self.train_engine.zero_grad()
+        loss = self.train_engine.loss_and_grad(batch, targets)
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        allreduce_gradients(self._unwrapped_model, world)
+        grad_norm = self.optimizer.step()
+        self.step += 1
+        return {"loss": loss, "grad_norm": grad_norm}
 
     # ---------------------------------------------------------------- checkpoint ingest
     def load_checkpoint(self, checkpoint_path: str) -> None:

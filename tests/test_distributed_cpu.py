@@ -59,3 +59,33 @@ def test_two_rank_shard_and_gather(tmp_path):
         want.append(pad)
     want = torch.cat(want)
     assert torch.equal(torch.nan_to_num(r0["sites"]), torch.nan_to_num(want))
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adsorbdiff_amd.train_step import allreduce_gradients
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    for p in net[2].parameters():
+        p.grad = None                      # a parameter no rank has a gradient for (the reference's unused heads)
+    for i, p in enumerate(list(net[0].parameters()) + list(net[1].parameters())):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    allreduce_gradients(net, world, bucket_mb=1e-4)  # tiny buckets: several all-reduces
+    torch.save([None if p.grad is None else p.grad.clone() for p in net.parameters()], os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    """DDP step of the training path: bucketed average over ranks, parameters without a gradient are skipped."""
+    world = 2
+    mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        if i >= 4:
+            assert a is None and b is None
+        else:
+            assert torch.equal(a, b) and torch.allclose(a, torch.full_like(a, 1.5 * (i + 1)))

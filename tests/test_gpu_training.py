@@ -101,3 +101,62 @@ def test_fused_adamw_matches_torch_adamw_clip_ema():
         assert rel_err(p.detach(), q.detach()) < 2e-6, n
     for s1, s2 in zip(ema.shadow_params, ema_ref.shadow_params):
         assert rel_err(s1, s2) < 2e-6
+
+
+WORKER = r"""
+import os, sys, torch, numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from adsorbdiff_amd.data import Batch
+from adsorbdiff_amd.painn_denoising import PaiNN
+from adsorbdiff_amd.so3_tables import Igso3Tables
+from adsorbdiff_amd.trainer import DenoisingTrainer
+from tests.helpers import batch_from_fixture, load_npz, state_dict_from_fixture
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+fx, tb = load_npz("train_small.npz"), load_npz("igso3_tables.npz")
+m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=2, num_rbf=128, cutoff=6.0, max_neighbors=20,
+          scale_file={"upd_out_scalar_scale_0": 1.05, "upd_out_scalar_scale_1": 0.9}, so3_denoising=True)
+m.load_state_dict(state_dict_from_fixture(fx), strict=False)
+tr = DenoisingTrainer(m, device="cuda:0")
+tr.setup_training(dict(ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55), lr=0.0, weight_decay=0.0,
+                  clip_grad_norm=0.0, ema_decay=0.0, tables=Igso3Tables(tb["omegas"], None, None, tb["exp_score_norm"]))
+full = batch_from_fixture(fx, pos_key="pos_noised")
+data = full.to_data_list()
+mine = Batch.from_data_list(data[2 * rank : 2 * rank + 2])          # two of the four systems per rank
+for k in ("tr_sigma", "rot_sigma", "tr_score", "rot_score"):
+    setattr(mine, k, torch.from_numpy(fx[k])[2 * rank : 2 * rank + 2])
+out = tr.train_step(mine, noised=True)                              # lr = 0: only the averaged gradients matter
+if rank == 0:
+    torch.save({k: p.grad.cpu() for k, p in m.named_parameters() if p.requires_grad}, sys.argv[2])
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_training_step_equals_full_batch(tmp_path):
+    """DDP semantics: two ranks (sharing cuda:0, gloo) with half of the fixture batch each; after the bucketed
+    all-reduce every rank holds the gradient of the full-batch loss = the reference's autograd gradients."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(root), str(tmp_path / "g.pt")], env=env))
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    got = torch.load(tmp_path / "g.pt")
+    fx = load_npz("train_small.npz")
+    for key in fx:
+        if key.startswith("grad::"):
+            assert rel_err(got[key[6:]], fx[key]) < 1e-4, key
