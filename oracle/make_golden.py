@@ -441,6 +441,60 @@ def main():
     for k, v in tparams.items():
         fxt["tp_" + k] = v
     np.savez_compressed(GOLD / "train_small.npz", **npify(fxt))
+    # ---------------------------------------------------------------- 7. EquiformerV2 denoiser
+    # Groundwork only: the reference model runs on CPU under an e3nn STAND-IN (oracle/refshim/e3nn_standin.py:
+    # parity UNPINNED for the S2-grid normalisation, see its docstring), checked for consistency with the vendored
+    # Wigner-D; small seeded models (L=4/M=2 as in configs/denoising/eqv2_conditional.yml and L=6/M=2 as in
+    # BASELINE.json) give the first fixtures.  Findings recorded with them: (a) atom_radii are in pm and are
+    # subtracted from Angstrom distances (equiformer_v2_denoising.py:209-213), so the Gaussian distance basis is
+    # identically 0 on every edge; (b) elements without a tabulated radius (Z = 36, 54, 85...) give NaN outputs;
+    # (c) the random edge gauge (edge_rot_mat.py:21) changes the outputs by < 1e-6 relative.
+    from oracle.refshim import e3nn_standin as E3
+
+    E3.install(sys.modules)
+    from adsorbdiff.models.equiformer_v2.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos as RefEqV2
+    from adsorbdiff.models.equiformer_v2.wigner import wigner_D as ref_wigner_D
+
+    chk = E3.self_check(ref_wigner_D)
+    print("[eqv2] e3nn stand-in self-check:", chk)
+    assert chk["equivariance_max_abs"] < 1e-12 and all(v < 1e-5 for k, v in chk.items() if k.startswith("roundtrip"))
+    be = make_batch(2, n_slab=16, n_ads=3, seed=3)
+    for lmax_, mmax_ in ((4, 2), (6, 2)):
+        torch.manual_seed(0)
+        eq = RefEqV2(None, None, None, max_neighbors=20, max_radius=6.0, max_num_elements=90, num_layers=2,
+                     sphere_channels=8, attn_hidden_channels=8, num_heads=2, attn_alpha_channels=4, attn_value_channels=4,
+                     ffn_hidden_channels=16, norm_type="layer_norm_sh", lmax_list=[lmax_], mmax_list=[mmax_],
+                     grid_resolution=18, edge_channels=8, num_distance_basis=16, attn_activation="silu",
+                     ffn_activation="silu", use_s2_act_attn=False, use_attn_renorm=True, use_gate_act=False,
+                     use_grid_mlp=True, use_sep_s2_act=True, alpha_drop=0.0, drop_path_rate=0.0, proj_drop=0.0,
+                     weight_init="uniform", FOR_denoising=True).eval()
+        bad = set(torch.nonzero(torch.isnan(eq.atom_radii)).flatten().tolist())
+        safe = torch.tensor([z for z in range(20, 80) if z not in bad])
+        bq = be.clone()
+        gz = torch.Generator().manual_seed(5)
+        zz = bq.atomic_numbers.clone()
+        zz[bq.tags < 2] = safe[torch.randint(0, len(safe), (int((bq.tags < 2).sum()),), generator=gz)].float()
+        bq.atomic_numbers = zz
+        outs = []
+        for gauge_seed in (1, 2):
+            torch.manual_seed(gauge_seed)
+            with torch.no_grad():
+                outs.append(eq(bq.clone()))
+        f1e, f2e = outs[0]
+        gauge = float((outs[0][0] - outs[1][0]).abs().max() / f1e.abs().max())
+        assert bool(torch.isfinite(f1e).all()) and gauge < 1e-5, gauge
+        grid = eq.SO3_grid[lmax_][mmax_]
+        fxe = dict(f1=f1e, f2=f2e, gauge_dependence=gauge, lmax=lmax_, mmax=mmax_, to_grid_mat=grid.to_grid_mat,
+                   from_grid_mat=grid.from_grid_mat, nan_radius_elements=np.array(sorted(bad)), **batch_inputs(bq))
+        pnames = {k for k, _ in eq.named_parameters()}
+        fxe.update({"sd::" + k: v for k, v in eq.state_dict().items() if k in pnames and k != "atom_radii"})  # parameters only
+        fxe["hp"] = np.array("num_layers=2 sphere_channels=8 attn_hidden_channels=8 num_heads=2 attn_alpha_channels=4 "
+                             "attn_value_channels=4 ffn_hidden_channels=16 norm_type=layer_norm_sh grid_resolution=18 "
+                             "edge_channels=8 num_distance_basis=16 max_num_elements=90 max_radius=6.0 max_neighbors=20 "
+                             "attn_activation=silu ffn_activation=silu use_grid_mlp=True use_sep_s2_act=True FOR_denoising=True")
+        np.savez_compressed(GOLD / f"eqv2_l{lmax_}m{mmax_}.npz", **npify(fxe))
+        print(f"[eqv2] L={lmax_} M={mmax_}: params={sum(p.numel() for p in eq.parameters())} |f1|max={f1e.abs().max():.4f} "
+              f"gauge dependence={gauge:.2e}")
     print("all goldens written to", GOLD)
 
 

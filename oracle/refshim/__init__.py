@@ -118,6 +118,21 @@ def install():
     tg_dd.BaseData = Data
     tg_utils = types.ModuleType("torch_geometric.utils")
     tg_utils.remove_self_loops = None
+
+    def _segment_softmax(src, index, ptr=None, num_nodes=None, dim=0):
+        """torch_geometric.utils.softmax: softmax of src over the entries that share an index (EqV2 attention over the
+        incoming edges of a node, transformer_block.py:340).  Documented PyG semantics: subtract the group max, exp,
+        divide by the group sum (+1e-16)."""
+        assert dim == 0
+        n = int(index.max()) + 1 if num_nodes is None else num_nodes
+        idx = index.reshape(-1, *([1] * (src.dim() - 1))).expand_as(src)
+        mx = torch.full((n,) + tuple(src.shape[1:]), float("-inf"), dtype=src.dtype, device=src.device)
+        mx = mx.scatter_reduce(0, idx, src, reduce="amax", include_self=True)
+        ex = (src - mx.gather(0, idx)).exp()
+        den = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device).scatter_add_(0, idx, ex)
+        return ex / (den.gather(0, idx) + 1e-16)
+
+    tg_utils.softmax = _segment_softmax
     tg.nn, tg.data, tg.utils = tg_nn, tg_data, tg_utils
     for name, mod in (
         ("torch_geometric", tg),

@@ -169,3 +169,32 @@ def test_noising_mirror_vs_reference_fixture():
     for key, fkey in (("pos", "pos_noised"), ("tr_sigma", "tr_sigma"), ("rot_sigma", "rot_sigma"), ("tr_score", "tr_score"),
                       ("rot_score", "rot_score"), ("ads_center_noise_vec", "ads_center_noise_vec")):
         np.testing.assert_allclose(getattr(nb, key).numpy(), fx[fkey], rtol=2e-5, atol=2e-5, err_msg=key)
+
+
+@pytest.mark.parametrize("name,lmax", [("eqv2_l4m2.npz", 4), ("eqv2_l6m2.npz", 6)])
+def test_eqv2_groundwork_fixture(name, lmax):
+    """EquiformerV2 groundwork: fixtures from the reference model on CPU under the e3nn stand-in
+    (S2-grid normalisation: parity UNPINNED, oracle/refshim/e3nn_standin.py).  Checks what is checkable without the
+    reference: shapes, finiteness, and that the stored grid matrices are the stand-in's own derivation with the
+    reference's m-truncation rescale (so3.py:572-613)."""
+    import math
+
+    from oracle.refshim import e3nn_standin as E
+
+    fx = load_npz(name)
+    N = fx["pos"].shape[0]
+    assert fx["f1"].shape == (N, 3) and fx["f2"].shape == (N, 3) and np.isfinite(fx["f1"]).all() and np.isfinite(fx["f2"]).all()
+    assert float(fx["gauge_dependence"]) < 1e-5 and int(fx["lmax"]) == lmax and int(fx["mmax"]) == 2
+    assert not set(fx["atomic_numbers"].astype(int).tolist()) & set(fx["nan_radius_elements"].tolist())
+    to, fr = E.ToS2Grid(lmax, (18, 18), normalization="component"), E.FromS2Grid((18, 18), lmax, normalization="component")
+    tg = torch.einsum("mbi,am->bai", to.shb, to.sha)
+    fg = torch.einsum("am,mbi->bai", fr.sha, fr.shb)
+    keep = []
+    for l in range(lmax + 1):
+        if l > 2:  # coefficients with |m| > mmax are dropped, the rest of the degree is rescaled
+            s = math.sqrt((2 * l + 1) / (2 * 2 + 1))
+            tg[:, :, l * l : (l + 1) ** 2] *= s
+            fg[:, :, l * l : (l + 1) ** 2] *= s
+        keep += [l * l + l + m for m in range(-min(l, 2), min(l, 2) + 1)]
+    np.testing.assert_allclose(tg[:, :, keep].numpy(), fx["to_grid_mat"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fg[:, :, keep].numpy(), fx["from_grid_mat"], rtol=1e-5, atol=1e-6)
