@@ -216,3 +216,37 @@ int32_t adf_stepper_step(adf_painn* h, const adf_batch* b, float* pos, const int
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
+
+// Hand-off rule of the reference's final-frame -> LMDB converter (scripts/create_lmdbs/pred_traj_to_lmdb.py:81-90): if the
+// lowest adsorbate atom (tag 2) is less than `min_gap` above the highest surface atom (tag 1), the whole adsorbate is
+// lifted by |diff| + min_gap.  One wave per system, in place; lifted[b] (optional) = applied shift.
+__global__ __launch_bounds__(64) void adf_lift_kernel(float* pos, const int32_t* tags, const int32_t* atom_offset,
+                                                       float min_gap, float* lifted) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int a0 = atom_offset[b], a1 = atom_offset[b + 1];
+    float zs = -3.0e38f, za = 3.0e38f;
+    for (int a = a0 + lane; a < a1; a += 64) {
+        const float z = pos[3 * a + 2];
+        if (tags[a] == 1) zs = fmaxf(zs, z);
+        if (tags[a] == 2) za = fminf(za, z);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { zs = fmaxf(zs, __shfl_xor(zs, o)); za = fminf(za, __shfl_xor(za, o)); }
+    float shift = 0.f;
+    if (zs > -1.0e38f && za < 1.0e38f) {
+        const float diff = za - zs;
+        if (diff < min_gap) shift = fabsf(diff) + min_gap;
+    }
+    if (shift != 0.f)
+        for (int a = a0 + lane; a < a1; a += 64)
+            if (tags[a] == 2) pos[3 * a + 2] = pos[3 * a + 2] + shift;
+    if (lifted && lane == 0) lifted[b] = shift;
+}
+
+extern "C" int32_t adf_lift_adsorbates(float* pos, const int32_t* tags, const int32_t* atom_offset, int32_t B, float min_gap,
+                                       float* lifted, void* stream) {
+    if (!pos || !tags || !atom_offset || B <= 0) { adf_set_error("lift_adsorbates: bad argument"); return ADF_EINVAL; }
+    hipLaunchKernelGGL(adf_lift_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pos, tags, atom_offset, min_gap, lifted);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}

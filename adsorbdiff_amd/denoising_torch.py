@@ -285,9 +285,10 @@ class Denoiser:
 
     # ------------------------------------------------------------------ trajectory sink
     def _write_trajectories(self, batch, frames) -> None:
-        """One file per system, written once after the loop as ``<name>.traj_tmp`` then renamed to
-        ``.traj`` (reference :66-82).  ASE trajectories when ``ase`` is importable, otherwise an
-        ``.npz`` with the same content (positions per frame, numbers, cell, tags, fixed)."""
+        """One file per system, written once after the loop under a temporary name and then renamed (the reference's
+        ``.traj_tmp`` -> ``.traj`` protocol, :66-82).  With ``ase`` importable: genuine ASE trajectories ``<name>.traj``;
+        without it the same content (positions per frame, numbers, cell, tags, fixed) goes to ``<name>.npz`` - a file
+        named ``.traj`` always is one."""
         traj_dir = Path(self.traj_dir)
         traj_dir.mkdir(exist_ok=True, parents=True)
         stack = torch.stack(frames).cpu().numpy()  # [F,N,3]
@@ -308,7 +309,7 @@ class Denoiser:
         start = 0
         for b, (n, name) in enumerate(zip(natoms, self.traj_names)):
             sl = slice(start, start + n)
-            tmp = traj_dir / f"{name}.traj_tmp"
+            tmp = traj_dir / (f"{name}.traj_tmp" if have_ase else f"{name}.npz_tmp")
             if have_ase:  # pragma: no cover
                 with Trajectory(tmp, mode="w") as traj:
                     for f in range(stack.shape[0]):
@@ -318,7 +319,7 @@ class Denoiser:
             else:
                 with open(tmp, "wb") as fh:
                     np.savez(fh, positions=stack[:, sl], numbers=Z[sl], tags=tags[sl], fixed=fixed[sl], cell=cell[b])
-            tmp.rename(tmp.with_suffix(".traj"))
+            tmp.rename(tmp.with_suffix(".traj" if have_ase else ".npz"))
             start += n
 
     def _get_ads_output(self, pred):

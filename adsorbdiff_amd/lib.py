@@ -24,7 +24,7 @@ EXPORTS = (
     "adf_check_flags", "adf_painn_set_arithmetic",
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
-    "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
+    "adf_lift_adsorbates", "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
     "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_bwd", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
     "adf_last_error", "adf_version",
 )
@@ -107,6 +107,7 @@ def load():
         "adf_profile_enable": [vp, i32],
         "adf_profile_read": [vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64), vp],
         "adf_measure_peaks": [C.POINTER(C.c_float), vp],
+        "adf_lift_adsorbates": [vp, vp, vp, i32, C.c_float, vp, vp],
         "adf_comm_unique_id": [vp],
         "adf_comm_create": [vp, i32, i32, C.POINTER(vp)],
         "adf_comm_destroy": [vp],

@@ -25,11 +25,11 @@ from .scaling import ensure_fitted
 
 def check_traj_files(batch, traj_dir) -> bool:
     """Resume rule of the sampler: a batch is skipped iff every <traj_dir>/<sid>.traj exists
-    (reference: utils/utils.py:968-973)."""
+    (reference: utils/utils.py:968-973); the ase-less sink <sid>.npz counts as well."""
     if traj_dir is None:
         return False
     traj_dir = Path(traj_dir)
-    return all((traj_dir / f"{sid}.traj").exists() for sid in batch.sid)
+    return all((traj_dir / f"{sid}.traj").exists() or (traj_dir / f"{sid}.npz").exists() for sid in batch.sid)
 
 
 class DenoisingTrainer:

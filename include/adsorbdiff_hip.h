@@ -252,6 +252,11 @@ int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, int64_t* mess
  * register-resident loop on every CU with non-zero operands.  Measurement aid of bench.py, not on the sampling path. */
 int32_t adf_measure_peaks(float* out_host3, void* stream);
 
+/* Hand-off to the relaxation stage: the lift rule of scripts/create_lmdbs/pred_traj_to_lmdb.py:81-90 applied to the
+ * sampled final frames on the device (in place).  lifted: optional [B] output = shift applied per system. */
+int32_t adf_lift_adsorbates(float* pos, const int32_t* tags, const int32_t* atom_offset, int32_t B, float min_gap,
+                            float* lifted, void* stream);
+
 /* Multi-GPU exchange of the sharded sampler: systems are independent, every rank samples its shard
  * with no data-path collective, and ONE all-gather of the sampled adsorbate sites ends a pass.  Replaces the reference's
  * per-rank .npz + barrier + rank-0 merge (trainers/sde_denoising_trainer.py:862-909).  RCCL is loaded lazily (dlopen).

@@ -401,10 +401,44 @@ def test_denoiser_end_to_end_vs_reference_fixture(tmp_path):
     # well-conditioned fixture (|dcom| <= 0.3 A per step): whole trajectory comparable
     np.testing.assert_allclose(out.pos.cpu().numpy(), fx["pos_final"], rtol=0, atol=1e-4)
     files = sorted(p.name for p in tmp_path.iterdir())
-    assert files == sorted(f"{s}.traj" for s in out.sid)  # written as .traj_tmp, renamed at the end
+    # written under a temporary name, renamed at the end; without the ase package the sink is <sid>.npz
+    assert files == sorted(f"{s}.npz" for s in out.sid)
     z = np.load(tmp_path / files[0])
     assert z["positions"].shape[0] == 8
     assert float(out.y.abs().sum()) == 0.0 and out.force.shape == out.pos.shape  # reference side effects
+
+
+def test_lift_rule_and_final_frame_records(tmp_path):
+    """Hand-off: the 0.1 A lift rule of pred_traj_to_lmdb.py:81-90 on the device vs a restatement in
+    numpy, and the per-system records of the final frames."""
+    from adsorbdiff_amd.handoff import lift_adsorbates, write_final_frames
+
+    b = make_batch(5, n_slab=36, n_ads=4, seed=77)
+    ads = b.tags == 2
+    # systems 0..4: adsorbate far above / 0.05 A above / exactly 0.1 A above / below the surface / deep inside
+    for k, dz in enumerate((2.0, 0.05, 0.1, -0.3, -4.0)):
+        m = (b.batch == k)
+        top = float(b.pos[m & (b.tags == 1), 2].max())
+        zmin = float(b.pos[m & ads, 2].min())
+        b.pos[m & ads, 2] += top + dz - zmin
+    want = b.pos.clone().numpy()
+    shifts = []
+    for k in range(5):
+        m = (b.batch == k).numpy()
+        a, s1 = m & ads.numpy(), m & (b.tags == 1).numpy()
+        diff = want[a, 2].min() - want[s1, 2].max()
+        sh = abs(diff) + 0.1 if diff < 0.1 else 0.0
+        want[a, 2] += np.float32(sh)
+        shifts.append(sh)
+    g = b.clone().to(DEV)
+    lifted = lift_adsorbates(g)
+    np.testing.assert_allclose(lifted.cpu().numpy(), np.array(shifts, np.float32), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(g.pos.cpu().numpy(), want, rtol=0, atol=2e-6)
+    assert shifts[0] == 0.0 and shifts[1] > 0 and shifts[3] > 0.39
+    out = write_final_frames(g, tmp_path / "final_frames.lmdb", apply_lift=False)
+    z = np.load(out, allow_pickle=False)
+    assert int(z["length"]) == 5 and z["3/pos"].shape == (40, 3) and str(z["4/sid"]) == b.sid[4]
+    np.testing.assert_allclose(z["1/pos"], want[40:80], atol=2e-6)
 
 
 def test_graph_replay_matches_eager():
@@ -446,7 +480,7 @@ def test_ml_diffuse_and_trainer_entry(tmp_path):
     res = tr.run_relaxations([b])
     assert len(res) == 1
     np.testing.assert_allclose(res[0].pos.cpu().numpy(), fx["pos_final"], rtol=0, atol=1e-4)
-    assert tr.run_relaxations([batch_from_fixture(fx, pos_key="pos_in")]) == []  # all .traj present -> skipped
+    assert tr.run_relaxations([batch_from_fixture(fx, pos_key="pos_in")]) == []  # every <sid>.traj / .npz present -> skipped
 
 
 def test_full_size_properties():
