@@ -199,3 +199,49 @@ def test_atoms_conversions_roundtrip():
     assert d.cell.shape == (1, 3, 3) and d.pbc.tolist() == [[True, True, True]] and int(d.natoms) == 18
     back = batch_to_atoms(Batch.from_data_list([d]))[0]
     assert np.allclose(back.get_positions(), b.pos.numpy()) and list(back.get_tags()) == b.tags.tolist()
+
+
+def test_balanced_batch_sampler_is_collective_free_and_balanced():
+    """Every rank derives all ranks' index streams locally (DistributedSampler is a pure function of seed / epoch /
+    rank): the per-step batches are disjoint, cover the step's global batch and are balanced by atom count."""
+    from torch.utils.data import DistributedSampler
+
+    from adsorbdiff_amd.data_parallel import BalancedBatchSampler, distributed_indices
+
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(20, 220, size=203)
+    # the index stream is torch's DistributedSampler's
+    for rank in range(4):
+        ds = DistributedSampler(list(range(203)), num_replicas=4, rank=rank, shuffle=True, seed=3)
+        ds.set_epoch(2)
+        assert list(ds) == distributed_indices(203, 4, rank, True, 3, 2)
+    samplers = [BalancedBatchSampler(sizes, batch_size=8, num_replicas=4, rank=r, shuffle=True, seed=3) for r in range(4)]
+    for s in samplers:
+        s.set_epoch(2)
+    streams = [list(s) for s in samplers]
+    assert len({len(st) for st in streams}) == 1 and len(streams[0]) == len(samplers[0])
+    plain = [[distributed_indices(203, 4, r, True, 3, 2)[i : i + 8] for i in range(0, 51, 8)] for r in range(4)]
+    for step in range(len(streams[0])):
+        got = sorted(i for r in range(4) for i in streams[r][step])
+        assert got == sorted(i for r in range(4) for i in plain[r][step])          # same global batch, re-dealt
+        loads = [int(sizes[streams[r][step]].sum()) for r in range(4)]
+        naive = [int(sizes[plain[r][step]].sum()) for r in range(4)]
+        assert max(loads) - min(loads) <= max(sizes) and max(loads) <= max(naive)
+    single = BalancedBatchSampler(sizes, 8, 1, 0, shuffle=False)
+    assert list(single)[0] == list(range(8))
+
+
+def test_record_dataset_roundtrip(tmp_path):
+    from adsorbdiff_amd.data_parallel import OCPCollater, RecordDataset
+
+    b = make_batch(3, n_slab=16, n_ads=2, seed=4)
+    recs = {}
+    for i, d in enumerate(b.to_data_list()):
+        for k, v in (("pos", d.pos.numpy()), ("cell", d.cell.numpy()), ("atomic_numbers", d.atomic_numbers.numpy()),
+                     ("natoms", int(d.natoms)), ("tags", d.tags.numpy()), ("fixed", d.fixed.numpy()), ("sid", str(d.sid)), ("fid", 0)):
+            recs[f"{i}/{k}"] = v
+    np.savez(tmp_path / "r.npz", length=3, **recs)
+    ds = RecordDataset(tmp_path / "r.npz")
+    assert len(ds) == 3 and ds.natoms.tolist() == [18, 18, 18]
+    back = OCPCollater()([ds[i] for i in range(3)])
+    assert torch.equal(back.pos, b.pos) and torch.equal(back.tags, b.tags) and back.sid == b.sid
