@@ -120,6 +120,10 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         return ADF_EHIP;
     }
     h->num_cus = prop.multiProcessorCount;
+    {   // incremental layers: on unless ADF_INCREMENTAL=0 (adf_painn_set_incremental overrides)
+        const char* e = getenv("ADF_INCREMENTAL");
+        h->inc_on = !(e && e[0] == '0');
+    }
     const int H = hp->hidden_channels, R = hp->num_rbf, L = hp->num_layers;
     int32_t st = dev_alloc(&h->rbf_pack, (size_t)L * (H / ADF_SLICE_CH) * R * 192);
     if (st == ADF_OK) st = dev_alloc(&h->rbf_bias_pack, (size_t)L * (H / ADF_SLICE_CH) * 192);
@@ -156,12 +160,29 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     return ADF_OK;
 }
 
+static void inc_free(adf_painn* h) {
+    for (int l = 0; l <= ADF_MAX_LAYERS; ++l) {
+        if (h->incX[l]) (void)hipFree(h->incX[l]);
+        if (h->incV[l]) (void)hipFree(h->incV[l]);
+        if (l < ADF_MAX_LAYERS && h->incR[l]) (void)hipFree(h->incR[l]);
+        h->incX[l] = h->incV[l] = nullptr;
+        if (l < ADF_MAX_LAYERS) h->incR[l] = nullptr;
+    }
+    void* ptrs[] = {h->inc_c0, h->inc_chg, h->inc_pend, h->inc_need, h->inc_tf, h->inc_list, h->inc_cnt, h->inc_tmp};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    h->inc_c0 = h->inc_chg = h->inc_pend = h->inc_need = h->inc_tf = nullptr;
+    h->inc_list = h->inc_cnt = nullptr; h->inc_tmp = nullptr; h->inc_tmp_bytes = 0;
+    h->inc_capN = 0; h->inc_valid = false;
+}
+
 static void free_workspaces(adf_painn* h) {
     void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
                     h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec,
-                    h->cache_d2, h->cache_cid, h->cache_cnt, h->atab};
+                    h->cache_d2, h->cache_cid, h->cache_cnt, h->atab, h->prev_nptr, h->prev_src, h->prev_geom};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    h->prev_nptr = h->prev_src = nullptr; h->prev_geom = nullptr; h->inc_valid = false;
     h->nbr_cnt = h->nbr_src = h->nbr_shift = h->deg = h->nptr = h->cursor = h->img_cnt = h->e_src = nullptr;
     h->scan_tmp = nullptr; h->scan_tmp_bytes = 0;
     h->e_geom = nullptr;
@@ -177,6 +198,8 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->rbf_pack) (void)hipFree(h->rbf_pack);
     if (h->rbf_bias_pack) (void)hipFree(h->rbf_bias_pack);
     if (h->rec0) (void)hipFree(h->rec0);
+    inc_free(h);
+    if (h->inc_cnt_host) (void)hipHostFree(h->inc_cnt_host);
     if (h->sub_x) (void)hipFree(h->sub_x);
     if (h->sub_vec) (void)hipFree(h->sub_vec);
     if (h->sub_f) (void)hipFree(h->sub_f);
@@ -270,6 +293,7 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
     }
     h->weights_set = true;
     h->rec0_valid = false;
+    h->inc_valid = false;
     return ADF_OK;
 }
 
@@ -299,6 +323,11 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
     ALLOC(img_cnt, capB);
     ALLOC(e_src, capE);
     ALLOC(e_geom, capE);
+    if (h->inc_on) {  // previous build's CSR (incremental layers); swapped with the live one per build
+        ALLOC(prev_nptr, capN + 1);
+        ALLOC(prev_src, capE);
+        ALLOC(prev_geom, capE);
+    }
     if (!h->msg_f32 && !h->msg_v1) {
         ALLOC(atab, capE * 96 + 64);
         if (st == ADF_OK && hipMemsetAsync(h->atab, 0, 64, 0) != hipSuccess) st = ADF_EHIP;
@@ -363,6 +392,7 @@ extern "C" int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, co
     ADF_HIP_CHECK(hipMemset(h->flags, 0, sizeof(int32_t) * ADF_NFLAGS));  // a new promise starts with clean flags
     h->cache_valid = false;
     h->rec0_valid = false;
+    h->inc_valid = false;
     return ADF_OK;
 }
 
@@ -435,28 +465,36 @@ static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
     return ADF_OK;
 }
 
+// Gather records of layer l for the n rows (x, vec): xh = x_proj(LayerNorm(x)) (painn_denoising.py:531), packed with
+// vec for the message kernel.  row_map != null: row r of (x, vec) is atom row_map[r] of the record table.
+static int32_t make_records(adf_painn* h, int l, int n, const float* x, const float* vec, bool vec_is_zero, float* rec,
+                            const int32_t* row_map, hipStream_t s) {
+    const int H = h->hp.hidden_channels;
+    const adf_layer_weights& w = h->layer[l];
+    if (n <= 0) return ADF_OK;
+    adf_prof_begin(h, ADF_PROF_NODE, s);
+    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s));
+    ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, n, H, H, 1, s));
+    if (h->gemm_f32) {
+        if (row_map) { adf_set_error("internal: mapped records need the f16x3 path"); return ADF_EINVAL; }
+        ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, n, 3 * H, H, 0, s));
+        ADF_TRY(adf_pack_records(h, n, h->xh, vec, vec_is_zero, s, rec));
+    } else {  // x_proj.2 with the gather records written from the accumulators (xh never materialised)
+        adf_epi ep = {};
+        ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
+        ep.row_map = row_map;
+        ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, n, H, H, 1, &ep, s));
+    }
+    adf_prof_end(h, s);
+    return ADF_OK;
+}
+
 // tlist != null: only the listed targets are evaluated and x_out / vec_out are compact [n_targets, ...] rows
 // rec != null: gather records go to / come from this buffer instead of h->rec; records_ready: they are already there
 static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const float* vec, float* x_out,
                              float* vec_out, bool vec_is_zero, hipStream_t s, const int32_t* tlist = nullptr,
                              int n_targets = 0, float* rec = nullptr, bool records_ready = false) {
-    const int H = h->hp.hidden_channels;
-    const adf_layer_weights& w = h->layer[l];
-    if (!records_ready) {
-        // xh = x_proj(LayerNorm(x))   (painn_denoising.py:531)
-        adf_prof_begin(h, ADF_PROF_NODE, s);
-        ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, N, H, s));
-        ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, N, H, H, 1, s));
-        if (h->gemm_f32) {
-            ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, N, 3 * H, H, 0, s));
-            ADF_TRY(adf_pack_records(h, N, h->xh, vec, vec_is_zero, s, rec));
-        } else {  // x_proj.2 with the gather records written from the accumulators (xh never materialised)
-            adf_epi ep = {};
-            ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
-            ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, N, H, H, 1, &ep, s));
-        }
-        adf_prof_end(h, s);
-    }
+    if (!records_ready) ADF_TRY(make_records(h, l, N, x, vec, vec_is_zero, rec, nullptr, s));
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
     const int32_t st = (h->msg_f32 || h->msg_v1)
         ? adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec)
@@ -533,6 +571,135 @@ extern "C" int32_t adf_painn_forward_subset(adf_painn_t h, const adf_batch* b, c
     return forward_impl(h, b, out_idx, n_out, f1, f2, stream);
 }
 
+// Incremental layers usable for this forward?  Allocates the kept state on first use (an allocation failure switches
+// the feature off: the plain path needs none of it) and swaps the CSR buffers so that the coming graph build leaves the
+// previous build's CSR in prev_*.
+static bool inc_prepare(adf_painn* h, int N) {
+    const int L = h->hp.num_layers, H = h->hp.hidden_channels;
+    if (!h->inc_on || !h->moving || h->gemm_f32 || h->msg_f32 || !h->msg_v1 || L > ADF_MAX_LAYERS || !h->prev_nptr)
+        return false;
+    if (N > h->inc_capN) {
+        (void)hipDeviceSynchronize();
+        inc_free(h);
+        const size_t cap = (size_t)N;
+        int32_t st = ADF_OK;
+        for (int l = 0; l <= L && st == ADF_OK; ++l) {
+            st = dev_alloc(&h->incX[l], cap * H);
+            if (st == ADF_OK && l >= 1) st = dev_alloc(&h->incV[l], cap * 3 * H);
+            if (st == ADF_OK && l < L) st = dev_alloc(&h->incR[l], (cap + 1) * 5 * H);
+        }
+        if (st == ADF_OK) st = dev_alloc(&h->inc_c0, cap);
+        if (st == ADF_OK) st = dev_alloc(&h->inc_chg, 2 * cap);
+        if (st == ADF_OK) st = dev_alloc(&h->inc_pend, cap * L);
+        if (st == ADF_OK) st = dev_alloc(&h->inc_need, cap * L);
+        if (st == ADF_OK) st = dev_alloc(&h->inc_tf, cap * L);
+        if (st == ADF_OK) st = dev_alloc(&h->inc_list, cap * L);
+        if (st == ADF_OK) st = dev_alloc(&h->inc_cnt, (size_t)2 * ADF_MAX_LAYERS);
+        if (st == ADF_OK) {
+            h->inc_tmp_bytes = adf_inc_temp_bytes((int64_t)cap);
+            unsigned char* tmp = nullptr;
+            st = dev_alloc(&tmp, h->inc_tmp_bytes + 16);
+            h->inc_tmp = tmp;
+        }
+        if (st == ADF_OK && !h->inc_cnt_host &&
+            hipHostMalloc(reinterpret_cast<void**>(&h->inc_cnt_host), sizeof(int32_t) * 2 * ADF_MAX_LAYERS) != hipSuccess)
+            st = ADF_EOOM;
+        if (st != ADF_OK) {
+            (void)hipGetLastError();
+            inc_free(h);
+            h->inc_on = false;
+            fprintf(stderr, "adsorbdiff_hip: no memory for incremental layers (%d atoms), continuing without\n", N);
+            return false;
+        }
+        h->inc_capN = (int64_t)cap;
+    }
+    if (h->inc_N != N || h->inc_layers != L || h->build_serial != h->inc_serial) h->inc_valid = false;
+    h->inc_N = N; h->inc_layers = L;
+    int32_t* tn = h->nptr; h->nptr = h->prev_nptr; h->prev_nptr = tn;
+    int32_t* ts = h->e_src; h->e_src = h->prev_src; h->prev_src = ts;
+    float4* tg = h->e_geom; h->e_geom = h->prev_geom; h->prev_geom = tg;
+    return true;
+}
+
+__global__ void adf_scatter_rows3_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int n,
+                                         float* __restrict__ dst);
+
+// One forward on the kept per-layer state.  The graph of this step is built; prev_* hold the previous build's CSR.
+static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const int32_t* out_idx, int32_t n_out,
+                                   float* f1, float* f2, hipStream_t s) {
+    const int L = h->hp.num_layers, H = h->hp.hidden_channels;
+    const size_t cap = (size_t)h->inc_capN, row = (size_t)5 * H;
+    const bool first = !h->inc_valid;
+    if (out_idx && n_out == 0) return ADF_OK;
+    adf_prof_begin(h, ADF_PROF_GRAPH, s);
+    if (first) {
+        ADF_TRY(adf_nodewise_embed(h, Z, N, h->incX[0], s));
+        for (int l = 0; l < L; ++l) ADF_HIP_CHECK(hipMemsetAsync(h->incR[l] + (size_t)N * row, 0, sizeof(float) * row, s));
+        ADF_HIP_CHECK(hipMemsetAsync(h->inc_pend, 0, cap * L, s));
+    } else {
+        ADF_TRY(adf_inc_compare(h, N, s));
+    }
+    ADF_HIP_CHECK(hipMemsetAsync(h->inc_cnt, 0, sizeof(int32_t) * 2 * ADF_MAX_LAYERS, s));
+    if (out_idx) ADF_TRY(adf_inc_need_from_list(h, N, L, out_idx, n_out, s));
+    for (int l = 0; l < L; ++l) ADF_TRY(adf_inc_plan_layer(h, l, N, first, out_idx != nullptr, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_cnt_host, h->inc_cnt, sizeof(int32_t) * 2 * L, hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    adf_prof_end(h, s);
+    h->inc_valid = true;
+    if (first) ADF_TRY(make_records(h, 0, N, h->incX[0], nullptr, true, h->incR[0], nullptr, s));
+    for (int l = 0; l < L; ++l) {
+        const int n = h->inc_cnt_host[l];
+        h->inc_rows += (unsigned long long)n; h->inc_rows_full += (unsigned long long)N;
+        h->inc_edges += (unsigned long long)h->inc_cnt_host[L + l];
+        if (n == 0) continue;
+        ++h->inc_launches;
+        const float* vin = l == 0 ? h->vecA : h->incV[l];  // layer 0: vec is zero, the pointer is not read
+        if (n == N) {  // every row: straight into the next layer's tables
+            ADF_TRY(message_layer(h, l, N, h->incX[l], vin, h->incX[l + 1], h->incV[l + 1], l == 0, s, nullptr, 0,
+                                  h->incR[l], true));
+            ADF_TRY(update_layer(h, l, N, h->incX[l + 1], h->incV[l + 1], s));
+            if (l + 1 < L)
+                ADF_TRY(make_records(h, l + 1, N, h->incX[l + 1], h->incV[l + 1], false, h->incR[l + 1], nullptr, s));
+            continue;
+        }
+        const int32_t* list = h->inc_list + cap * l;
+        ADF_TRY(message_layer(h, l, N, h->incX[l], vin, h->x, h->vecB, l == 0, s, list, n, h->incR[l], true));
+        ADF_TRY(update_layer(h, l, n, h->x, h->vecB, s));
+        adf_prof_begin(h, ADF_PROF_NODE, s);
+        ADF_TRY(adf_inc_scatter_rows(h->x, list, n, H, h->incX[l + 1], s));
+        ADF_TRY(adf_inc_scatter_rows(h->vecB, list, n, 3 * H, h->incV[l + 1], s));
+        adf_prof_end(h, s);
+        if (l + 1 < L) ADF_TRY(make_records(h, l + 1, n, h->x, h->vecB, false, h->incR[l + 1], list, s));
+    }
+    adf_prof_begin(h, ADF_PROF_HEADS, s);
+    if (!out_idx) {
+        ADF_TRY(adf_head_forward(h, 0, N, h->incX[L], h->incV[L], f1, s));
+        if (h->hp.num_heads == 2) ADF_TRY(adf_head_forward(h, 1, N, h->incX[L], h->incV[L], f2, s));
+    } else {
+        if (n_out > h->capS) {
+            const int64_t c = (int64_t)n_out + n_out / 4 + 64;
+            if (h->sub_x) (void)hipFree(h->sub_x);
+            if (h->sub_vec) (void)hipFree(h->sub_vec);
+            if (h->sub_f) (void)hipFree(h->sub_f);
+            h->sub_x = h->sub_vec = h->sub_f = nullptr; h->capS = 0;
+            ADF_TRY(dev_alloc(&h->sub_x, (size_t)c * H));
+            ADF_TRY(dev_alloc(&h->sub_vec, (size_t)c * 3 * H));
+            ADF_TRY(dev_alloc(&h->sub_f, (size_t)c * 3));
+            h->capS = c;
+        }
+        ADF_TRY(adf_inc_gather_rows(h->incX[L], out_idx, n_out, H, h->sub_x, s));
+        ADF_TRY(adf_inc_gather_rows(h->incV[L], out_idx, n_out, 3 * H, h->sub_vec, s));
+        for (int hd = 0; hd < h->hp.num_heads; ++hd) {
+            ADF_TRY(adf_head_forward(h, hd, n_out, h->sub_x, h->sub_vec, h->sub_f, s));
+            hipLaunchKernelGGL(adf_scatter_rows3_kernel, dim3((3 * n_out + 255) / 256), dim3(256), 0, s, h->sub_f, out_idx,
+                               n_out, hd == 0 ? f1 : f2);
+        }
+        ADF_HIP_CHECK(hipGetLastError());
+    }
+    adf_prof_end(h, s);
+    return ADF_OK;
+}
+
 static int32_t forward_impl(adf_painn_t h, const adf_batch* b, const int32_t* out_idx, int32_t n_out, float* f1,
                             float* f2, void* stream) {
     ADF_TRY(check_batch(h, b));
@@ -541,9 +708,14 @@ static int32_t forward_impl(adf_painn_t h, const adf_batch* b, const int32_t* ou
     hipStream_t s = (hipStream_t)stream;
     const int N = b->num_atoms;
     ADF_TRY(ensure_capacity(h, N, b->num_systems));
+    const bool inc = inc_prepare(h, N);
     adf_prof_begin(h, ADF_PROF_GRAPH, s);
     ADF_TRY(adf_graph_build_impl(h, b, s));
     adf_prof_end(h, s);
+    if (inc) {
+        h->inc_serial = h->build_serial;
+        return forward_incremental(h, N, b->atomic_numbers, out_idx, n_out, f1, f2, s);
+    }
     ADF_TRY(zero_pad_rows(h, N, s));
     ADF_TRY(adf_nodewise_embed(h, b->atomic_numbers, N, h->x, s));  // vec = 0 is implicit in layer 0
     float* vin = h->vecA;
@@ -642,6 +814,28 @@ extern "C" int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32) {
     h->gemm_f32 = exact_f32 != 0;
     h->msg_f32 = exact_f32 != 0;
     h->rec0_valid = false;
+    h->inc_valid = false;
+    return ADF_OK;
+}
+
+// Incremental layers (see incremental.hip): 1 = keep per-layer node state across the forwards of a static-atom promise
+// and recompute only rows whose inputs changed (default; bit-identical outputs), 0 = every forward computes every row.
+// Resets the row counters reported by adf_get_counters.
+extern "C" int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    if ((on != 0) != h->inc_on) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        h->inc_on = on != 0;
+        if (!h->inc_on) inc_free(h);
+        if (h->inc_on && h->capN > 0 && !h->prev_nptr) {  // workspaces exist without the previous-CSR buffers
+            int32_t st = dev_alloc(&h->prev_nptr, (size_t)h->capN + 1);
+            if (st == ADF_OK) st = dev_alloc(&h->prev_src, (size_t)h->capE);
+            if (st == ADF_OK) st = dev_alloc(&h->prev_geom, (size_t)h->capE);
+            if (st != ADF_OK) { h->inc_on = false; return st; }
+        }
+    }
+    h->inc_valid = false;
+    h->inc_rows = h->inc_rows_full = h->inc_edges = h->inc_launches = 0;
     return ADF_OK;
 }
 
@@ -733,5 +927,7 @@ extern "C" int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stre
     const int64_t head = 2 * (3 * N * H * H + 3 * N * H * H / 2 + N * 2 * H * H + N * H * H + 3 * N * (H / 2) * (H / 2) +
                               N * H * H / 2);
     out->dense_flops = L * (30 * H * H * N + 2 * R * 3 * H * E) + h->hp.num_heads * head;
+    out->inc_rows = (int64_t)h->inc_rows; out->inc_rows_full = (int64_t)h->inc_rows_full;
+    out->inc_msg_launches = (int64_t)h->inc_launches; out->inc_msg_edges = (int64_t)h->inc_edges;
     return ADF_OK;
 }

@@ -14,7 +14,8 @@
 #define ADF_MAX_CAND 1024       // in-cutoff candidates per centre held in LDS by the top-K kernel
 #define ADF_MAX_K 128
 #define ADF_NFLAGS 8
-#define ADF_MAX_INDEG 1024      // incoming edges per target the per-target sorter handles (graph.hip)
+#define ADF_MAX_INDEG 1024
+#define ADF_MAX_LAYERS 16      // incoming edges per target the per-target sorter handles (graph.hip)
 
 void adf_set_error(const char* fmt, ...);
 
@@ -57,6 +58,7 @@ struct adf_epi {
     int vec_is_zero;      // EPI 1
     const float* A2;      // any EPI: second source of the A operand for columns [K1, K) (same row stride), K1 % 32 == 0
     int K1;               // 0 = single source
+    const int32_t* row_map;  // EPI 1: record row of tile row n is row_map[n] (compact rows of an incremental layer); null = n
 };
 struct adf_layer_weights {
     const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
@@ -130,6 +132,25 @@ struct adf_painn {
     float* rec0;
     int64_t rec0_cap, rec0_N;
     bool rec0_valid;
+    // ---- incremental layers (api.hip forward_incremental, incremental.hip): per-layer node state kept across the
+    // forwards of one static-atom promise; a forward recomputes only rows whose inputs changed since they were computed
+    bool inc_on;                       // adf_painn_set_incremental / ADF_INCREMENTAL (default on)
+    bool inc_valid;                    // the kept state belongs to the current batch, weights and arithmetic
+    int64_t inc_capN, inc_N;
+    int inc_layers;
+    float* incX[ADF_MAX_LAYERS + 1];   // x entering layer l (l = L: entering the heads)   [capN, H]
+    float* incV[ADF_MAX_LAYERS + 1];   // vec likewise, l >= 1 (vec entering layer 0 is zero)  [capN, 3, H]
+    float* incR[ADF_MAX_LAYERS];       // gather records of layer l  [(capN+1), H/32, 160]
+    int32_t *prev_nptr, *prev_src;     // CSR of the previous build (swapped with nptr / e_src / e_geom per build)
+    float4* prev_geom;
+    unsigned char *inc_c0, *inc_chg;   // [capN] in-edges changed; [2][capN] layer input changed (ping-pong)
+    unsigned char *inc_pend, *inc_need, *inc_tf;  // [L][capN] row has unapplied changes / is needed / is recomputed now
+    int32_t* inc_list;                 // [L][capN] compacted recompute lists (ascending)
+    int32_t* inc_cnt;                  // device [2L]: list lengths, then in-edges of the listed rows
+    int32_t* inc_cnt_host;             // pinned copy
+    void* inc_tmp; size_t inc_tmp_bytes;  // hipcub select workspace
+    unsigned long long inc_rows, inc_rows_full, inc_edges, inc_launches;  // totals since adf_painn_set_incremental
+    unsigned long long build_serial, inc_serial;  // graph builds made / the build the kept state belongs to
     float *sub_x, *sub_vec, *sub_f;  // compact rows of adf_painn_forward_subset: [capS,H], [capS,3,H], [capS,3]
     int64_t capS;
     float* sys;          // [B*16] per-system scratch of the stepper
@@ -167,6 +188,13 @@ static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, co
     return adf_launch_gemm16(A, lda, W16, bias, C, ldc, M, N, K, act, s);
 }
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
+// incremental.hip
+size_t adf_inc_temp_bytes(int64_t n);
+int32_t adf_inc_compare(adf_painn* h, int N, hipStream_t s);  // inc_c0 from (nptr, e_src, e_geom) vs prev_*
+int32_t adf_inc_need_from_list(adf_painn* h, int N, int L, const int32_t* out_idx, int n_out, hipStream_t s);
+int32_t adf_inc_plan_layer(adf_painn* h, int l, int N, bool first, bool have_need, hipStream_t s);
+int32_t adf_inc_scatter_rows(const float* src, const int32_t* idx, int n, int width, float* dst, hipStream_t s);
+int32_t adf_inc_gather_rows(const float* src, const int32_t* idx, int n, int width, float* dst, hipStream_t s);
 size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s,

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                     const float4 p2 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 64 + 4 * c4);
                     if (n < M) {
                         // half-record of (atom n, group g): [32 x (P0, P1, P2, xa)] then [32 x xc]
-                        float* rec = ep.rec + ((size_t)n * (H / 32) + g) * 160;
+                        float* rec = ep.rec + ((size_t)(ep.row_map ? ep.row_map[n] : n) * (H / 32) + g) * 160;
                         float4* ra_ = reinterpret_cast<float4*>(rec + 16 * c4);
                         if (!ep.vec_is_zero) {
                             ra_[0] = make_float4(v0[it].x * p1.x, v1[it].x * p1.x, v2[it].x * p1.x, p0.x);

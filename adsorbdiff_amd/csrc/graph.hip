@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256) void adf_sort_edges_kernel(const int32_t* nptr
 }
 
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
+    ++h->build_serial;
     const int N = b->num_atoms, B = b->num_systems, K = h->hp.max_neighbors;
     GraphParams p;
     p.pos = b->pos; p.cell = b->cell; p.batch = b->batch; p.atom_offset = b->atom_offset;

@@ -20,6 +20,10 @@ Extensions (all optional, defaults reproduce the reference):
   * ``denoising_pos_params["static_atom_cache"]`` (default True): declare the slab static for the loop
     (``adf_graph_set_moving``) so that loop-invariant work — the slab-slab part of the top-K search and the
     layer-0 gather records, which depend on atomic numbers only — is done once.  Bit-identical results.
+  * ``denoising_pos_params["incremental_layers"]`` (default True; needs ``static_atom_cache``): the engine keeps the
+    node state of every layer across the steps and recomputes a row only if one of its inputs changed since it was
+    computed (detected by comparing the new graph with the previous one bit for bit and following the edges; the
+    receptive field of the moving adsorbate grows one neighbour shell per layer).  Bit-identical results.
   * ``denoising_pos_params["scores_on_adsorbate_only"]`` (default False): the update only ever reads the
     model output on tag-2 atoms (reference :263-268, :460-467), so the last layer and the heads can be
     evaluated for those atoms alone (``adf_painn_forward_subset``).  Sampled positions are bit-identical.
@@ -183,6 +187,7 @@ class Denoiser:
             # forward the layer-0 records (loop-invariant; results are bit-identical either way)
             if params.get("static_atom_cache", True):
                 eng.set_moving_atoms(prep, prep.tags == 2)
+            eng.set_incremental(bool(params.get("incremental_layers", True)))
 
             pos0 = pos.clone()  # a run that leaves the f16x3 range is repeated in exact f32 from here
 

@@ -238,6 +238,11 @@ class PaiNNEngine:
         self.exact_f32 = True
         return True
 
+    def set_incremental(self, on: bool = True) -> None:
+        """Incremental layers (adf_painn_set_incremental): keep per-layer node state across the forwards of a
+        static-atom promise and recompute only rows whose inputs changed.  Bit-identical outputs; default on."""
+        _lib.check(self.lib.adf_painn_set_incremental(self.handle, 1 if on else 0))
+
     def build_graph(self, data):
         """Graph only; returns the number of symmetrised edges."""
         prep = self.prepare(data)

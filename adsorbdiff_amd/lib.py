@@ -21,7 +21,7 @@ class NumericRangeError(ArithmeticError):
 
 EXPORTS = (
     "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_graph_set_moving",
-    "adf_check_flags", "adf_painn_set_arithmetic",
+    "adf_check_flags", "adf_painn_set_arithmetic", "adf_painn_set_incremental",
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_lift_adsorbates", "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
@@ -56,6 +56,8 @@ class Counters(C.Structure):
     _fields_ = [
         ("num_edges", C.c_int64), ("num_atoms", C.c_int64), ("message_bytes_per_layer", C.c_int64),
         ("dense_flops", C.c_int64),
+        ("inc_rows", C.c_int64), ("inc_rows_full", C.c_int64), ("inc_msg_launches", C.c_int64),
+        ("inc_msg_edges", C.c_int64),
     ]
 
 
@@ -94,6 +96,7 @@ def load():
         "adf_graph_set_moving": [vp, vp, vp, vp],
         "adf_check_flags": [vp, vp],
         "adf_painn_set_arithmetic": [vp, i32],
+        "adf_painn_set_incremental": [vp, i32],
         "adf_graph_export": [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.POINTER(i64), vp],
         "adf_painn_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp],
         "adf_painn_forward_subset": [vp, C.POINTER(BatchDesc), vp, i32, vp, vp, vp],

@@ -126,6 +126,15 @@ int32_t adf_graph_set_moving(adf_painn_t h, const int32_t* moving, const int32_t
  * ADF_ENUMERIC through adf_check_flags; the host mirror then re-runs the forward / the sampling run in exact f32. */
 int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32);
 
+/* Incremental layers (default on; ADF_INCREMENTAL=0 in the environment at creation = off).  While a static-atom promise
+ * is in force (adf_graph_set_moving: same batch, only flagged atoms move) the handle keeps x / vec / gather records of
+ * every layer and a forward recomputes a node row only if one of its inputs — its own row in the layer below, a
+ * neighbour's, or its in-edge list / geometry, compared bit for bit with the previous build — changed since the row
+ * was computed.  Every output is bit-identical to a full forward; the reference recomputes everything every step
+ * (denoising_torch.py:498 -> painn_denoising.py:460-471).  Costs about 110 KB of HBM per atom (H=512, 6 layers).
+ * Calling this (with either value) drops the kept state and zeroes the counters adf_get_counters reports. */
+int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on);
+
 /* Read the device-side error flags of the last graph build (candidate overflow,
  * empty image).  Synchronises the stream.  adf_painn_forward does not check
  * them itself so that a sampling loop stays free of host round trips. */
@@ -233,6 +242,9 @@ typedef struct {
     int64_t num_atoms;
     int64_t message_bytes_per_layer;  /* SURVEY.md §8d formula on the real E, N */
     int64_t dense_flops;              /* node + edge GEMM flops of one forward  */
+    /* incremental layers, totals since adf_painn_set_incremental: node rows recomputed / rows a full forward would
+     * have computed (layers x atoms), message-kernel launches made and the in-edges of the targets they evaluated */
+    int64_t inc_rows, inc_rows_full, inc_msg_launches, inc_msg_edges;
 } adf_counters;
 int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream);
 

@@ -855,6 +855,73 @@ def test_static_promise_forward_is_bit_identical():
         assert torch.equal(f1, c1) and torch.equal(f2, c2)
 
 
+def test_incremental_layers_forward_is_bit_identical():
+    """Incremental layers (adf_painn_set_incremental): a sequence of forwards under a static-atom promise — adsorbate
+    moved a little, a lot, not at all; all outputs and adsorbate-only outputs interleaved — equals, bit for bit, the
+    same forwards with every row recomputed.  The cutoff is short against the cell so that the recompute lists of the
+    first layers are proper subsets, and the row counters must show it."""
+    b = make_batch(4, n_slab=196, n_ads=4, seed=31).to(DEV)
+    torch.manual_seed(8)
+    L = 4
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=L, num_rbf=32, cutoff=3.6, max_neighbors=12,
+              so3_denoising=True, scale_file={f"upd_out_scalar_scale_{i}": 1.0 for i in range(L)}).to(DEV).eval()
+    eng = m.engine()
+    prep = eng.prepare(b)
+    N = b.pos.shape[0]
+    ads = b.tags == 2
+    idx = torch.nonzero(ads).reshape(-1).to(torch.int32)
+    g = torch.Generator().manual_seed(10)
+    moves = [0.05, 0.05, 0.0, 3.0, 0.2, 0.0, 0.1, 1.5, 0.05, 0.05]
+    subset = [False, False, False, False, True, True, False, True, True, False]
+    seq, pos = [], b.pos.clone()
+    for mv in moves:
+        pos = pos.clone()
+        pos[ads] = pos[ads] + (torch.rand(int(ads.sum()), 3, generator=g).to(DEV) - 0.5) * 2.0 * mv
+        seq.append(pos)
+
+    def run(incremental):
+        eng.set_moving_atoms(prep, ads)
+        eng.set_incremental(incremental)
+        outs = []
+        for p_, sub in zip(seq, subset):
+            f1, f2 = torch.zeros(N, 3, device=DEV), torch.zeros(N, 3, device=DEV)
+            eng.forward_prepared(prep, p_, f1, f2, idx if sub else None)
+            outs.append((f1, f2))
+        torch.cuda.synchronize()
+        c = eng.counters()
+        eng.set_moving_atoms(None, None)
+        return outs, c
+
+    ref, c_ref = run(False)
+    inc, c_inc = run(True)
+    for (a1, a2), (b1, b2), sub in zip(ref, inc, subset):
+        sel = idx.long() if sub else slice(None)
+        assert torch.equal(a1[sel], b1[sel]) and torch.equal(a2[sel], b2[sel])
+    assert c_ref.inc_rows_full == 0  # the plain path does not count
+    assert c_inc.inc_rows_full == len(moves) * L * N
+    assert 0 < c_inc.inc_rows < 0.7 * c_inc.inc_rows_full, (c_inc.inc_rows, c_inc.inc_rows_full)
+    eng.set_incremental(True)
+
+
+def test_incremental_layers_switch_gives_identical_samples():
+    """denoising_pos_params["incremental_layers"]=False recomputes every row every step: same sampled positions, with
+    and without scores_on_adsorbate_only."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("stepper_ode8.npz")
+    tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
+    outs = []
+    for inc, ads_only in ((False, False), (True, False), (True, True)):
+        b = batch_from_fixture(fx, pos_key="pos_in")
+        torch.manual_seed(int(fx["seed"]))
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), incremental_layers=inc, scores_on_adsorbate_only=ads_only),
+                       device=DEV)
+        outs.append(den.run().pos.clone())
+        assert den.steps_applied == 8
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_static_atom_cache_switch_gives_identical_samples():
     """denoising_pos_params["static_atom_cache"]=False recomputes everything every step: same positions."""
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
