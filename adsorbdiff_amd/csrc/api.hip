@@ -594,7 +594,7 @@ static bool inc_prepare(adf_painn* h, int N) {
         if (st == ADF_OK) st = dev_alloc(&h->inc_need, cap * L);
         if (st == ADF_OK) st = dev_alloc(&h->inc_tf, cap * L);
         if (st == ADF_OK) st = dev_alloc(&h->inc_list, cap * L);
-        if (st == ADF_OK) st = dev_alloc(&h->inc_cnt, (size_t)2 * ADF_MAX_LAYERS);
+        if (st == ADF_OK) st = dev_alloc(&h->inc_cnt, (size_t)2 * ADF_MAX_LAYERS + 1);
         if (st == ADF_OK) {
             h->inc_tmp_bytes = adf_inc_temp_bytes((int64_t)cap);
             unsigned char* tmp = nullptr;
@@ -602,7 +602,7 @@ static bool inc_prepare(adf_painn* h, int N) {
             h->inc_tmp = tmp;
         }
         if (st == ADF_OK && !h->inc_cnt_host &&
-            hipHostMalloc(reinterpret_cast<void**>(&h->inc_cnt_host), sizeof(int32_t) * 2 * ADF_MAX_LAYERS) != hipSuccess)
+            hipHostMalloc(reinterpret_cast<void**>(&h->inc_cnt_host), sizeof(int32_t) * (2 * ADF_MAX_LAYERS + 1)) != hipSuccess)
             st = ADF_EOOM;
         if (st != ADF_OK) {
             (void)hipGetLastError();
@@ -639,22 +639,28 @@ static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const 
     } else {
         ADF_TRY(adf_inc_compare(h, N, s));
     }
-    ADF_HIP_CHECK(hipMemsetAsync(h->inc_cnt, 0, sizeof(int32_t) * 2 * ADF_MAX_LAYERS, s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->inc_cnt, 0, sizeof(int32_t) * (2 * ADF_MAX_LAYERS + 1), s));
     if (out_idx) ADF_TRY(adf_inc_need_from_list(h, N, L, out_idx, n_out, s));
     for (int l = 0; l < L; ++l) ADF_TRY(adf_inc_plan_layer(h, l, N, first, out_idx != nullptr, s));
-    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_cnt_host, h->inc_cnt, sizeof(int32_t) * 2 * L, hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_cnt + 2 * L, h->nptr + N, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_cnt_host, h->inc_cnt, sizeof(int32_t) * (2 * L + 1), hipMemcpyDeviceToHost, s));
     ADF_HIP_CHECK(hipStreamSynchronize(s));
     adf_prof_end(h, s);
     h->inc_valid = true;
     if (first) ADF_TRY(make_records(h, 0, N, h->incX[0], nullptr, true, h->incR[0], nullptr, s));
     for (int l = 0; l < L; ++l) {
         const int n = h->inc_cnt_host[l];
-        h->inc_rows += (unsigned long long)n; h->inc_rows_full += (unsigned long long)N;
-        h->inc_edges += (unsigned long long)h->inc_cnt_host[L + l];
+        const bool whole = n == N || (long long)n * 10 >= (long long)N * 9;
+        h->inc_rows += (unsigned long long)(whole ? N : n); h->inc_rows_full += (unsigned long long)N;
+        h->inc_edges += (unsigned long long)(whole ? h->inc_cnt_host[2 * L] : h->inc_cnt_host[L + l]);
         if (n == 0) continue;
         ++h->inc_launches;
         const float* vin = l == 0 ? h->vecA : h->incV[l];  // layer 0: vec is zero, the pointer is not read
-        if (n == N) {  // every row: straight into the next layer's tables
+        // (nearly) every row: straight into the next layer's tables.  Recomputing a row that was not listed is
+        // harmless: a row without pending changes has unchanged inputs and gets the same value again; a pending but
+        // unwanted row keeps its flag and is recomputed before it is next read.  Above ~90 % the compaction costs
+        // more than the rows it saves.
+        if (whole) {
             ADF_TRY(message_layer(h, l, N, h->incX[l], vin, h->incX[l + 1], h->incV[l + 1], l == 0, s, nullptr, 0,
                                   h->incR[l], true));
             ADF_TRY(update_layer(h, l, N, h->incX[l + 1], h->incV[l + 1], s));

@@ -146,7 +146,7 @@ struct adf_painn {
     unsigned char *inc_c0, *inc_chg;   // [capN] in-edges changed; [2][capN] layer input changed (ping-pong)
     unsigned char *inc_pend, *inc_need, *inc_tf;  // [L][capN] row has unapplied changes / is needed / is recomputed now
     int32_t* inc_list;                 // [L][capN] compacted recompute lists (ascending)
-    int32_t* inc_cnt;                  // device [2L]: list lengths, then in-edges of the listed rows
+    int32_t* inc_cnt;                  // device [2L+1]: list lengths, in-edges of the listed rows, all edges
     int32_t* inc_cnt_host;             // pinned copy
     void* inc_tmp; size_t inc_tmp_bytes;  // hipcub select workspace
     unsigned long long inc_rows, inc_rows_full, inc_edges, inc_launches;  // totals since adf_painn_set_incremental
