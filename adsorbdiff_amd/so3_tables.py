@@ -42,7 +42,10 @@ def compute_tables(device: Optional[torch.device] = None, rows=None) -> dict:
     for i, r in enumerate(rows):
         w = (2 * l + 1) * torch.exp(-l * (l + 1) * float(eps_all[int(r)]) ** 2)
         expansion = (w * ratio).sum(0)
-        sc = (w * dratio).sum(0) / expansion
+        # Far in the tail of a narrow distribution the alternating series is pure cancellation noise (|f| ~ 1e-13 of its
+        # peak); a device reduction order can land on exactly 0 there, which the host order never does.  Such angles
+        # carry no probability mass: a non-finite ratio is replaced by 0 so it cannot poison the expectation below.
+        sc = torch.nan_to_num((w * dratio).sum(0) / expansion, nan=0.0, posinf=0.0, neginf=0.0)
         pdf = expansion * marg
         cdf[i] = (pdf.cumsum(0) / X_N * np.pi).cpu().numpy()
         score[i] = sc.cpu().numpy()
