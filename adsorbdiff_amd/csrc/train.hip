@@ -56,9 +56,11 @@ __global__ void tr_transpose_kernel(const float* __restrict__ src, float* __rest
 // dW[n,k] partial = sum over this block's rows m of dC[m,n] * A[m,k]: 64 x 64 output tile per 256-thread block,
 // 4 waves x (32 x 32), rows in chunks of 32 staged row-major in LDS - both MFMA operands are read with the lane index
 // along the contiguous dimension (A operand: lane (i = n, kk = m mod 2) <- dC[m + kk][n0 + i]).
+// bpart != null: the k-tile-0 workgroups also form the column sums of their dC tile (bias gradient partials
+// [splits][N]) from the rows they stage anyway.
 __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A,
                                                         int lda, float* __restrict__ part, int M, int N, int K,
-                                                        int rows_per_split, int tiles_k) {
+                                                        int rows_per_split, int tiles_k, float* __restrict__ bpart) {
     __shared__ float Cs[32][64];
     __shared__ float As[32][64];
     const int tile = blockIdx.x, split = blockIdx.y;
@@ -69,6 +71,8 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool colsum = bpart && k0 == 0 && tid < 64;
+    float bs = 0.f;
     for (int m0 = mbeg; m0 < mend; m0 += 32) {
         __syncthreads();
         for (int i = tid; i < 32 * 64; i += 256) {
@@ -78,6 +82,10 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
             As[r][c] = (m < mend && k0 + c < K) ? A[(size_t)m * lda + k0 + c] : 0.f;
         }
         __syncthreads();
+        if (colsum) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bs += Cs[r][tid];  // rows in order: reproducible
+        }
 #pragma unroll
         for (int mm = 0; mm < 32; mm += 2) {
             const float a = Cs[mm + (lane >> 5)][wn + (lane & 31)];
@@ -92,6 +100,7 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
         const int row = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < N && col < K) out[(size_t)row * K + col] = acc[r];
     }
+    if (colsum && n0 + tid < N) bpart[(size_t)split * N + n0 + tid] = bs;
 }
 
 // dst[i] (+)= sum_s part[s][i] in a fixed order (run-to-run reproducible gradients)
@@ -190,13 +199,14 @@ extern "C" int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W
         if (!A) { adf_set_error("linear_bwd: dW needs A"); return ADF_EINVAL; }
         const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
         hipLaunchKernelGGL(tr_wgrad_kernel, dim3(tiles_n * tiles_k, splits), dim3(256), 0, s, dC, ldc, A, lda, part, (int)M, N,
-                           K, rows, tiles_k);
+                           K, rows, tiles_k, db ? part + (size_t)splits * N * K : (float*)nullptr);
         hipLaunchKernelGGL(tr_reduce_splits_kernel, dim3(tr_grid((long long)N * K)), dim3(256), 0, s, part, (long long)N * K,
                            dW, (long long)N * K, splits, acc_dW);
     }
     if (db) {
         float* bpart = part + (size_t)splits * N * K;
-        hipLaunchKernelGGL(tr_colsum_kernel, dim3((N + 255) / 256, splits), dim3(256), 0, s, dC, ldc, bpart, (int)M, N, rows);
+        if (!dW)  // no weight-gradient pass to ride on
+            hipLaunchKernelGGL(tr_colsum_kernel, dim3((N + 255) / 256, splits), dim3(256), 0, s, dC, ldc, bpart, (int)M, N, rows);
         hipLaunchKernelGGL(tr_reduce_splits_kernel, dim3(tr_grid(N)), dim3(256), 0, s, bpart, (long long)N, db, (long long)N,
                            splits, acc_dW);
     }
