@@ -903,6 +903,56 @@ def test_incremental_layers_forward_is_bit_identical():
     eng.set_incremental(True)
 
 
+def test_incremental_layers_survive_foreign_builds_and_weight_updates():
+    """The kept layer state must not outlive what it was computed from: a stand-alone graph build between two forwards
+    (the previous-CSR buffers then hold a foreign graph) and an in-place weight update both force a full recompute."""
+    b = make_batch(3, n_slab=100, n_ads=4, seed=37).to(DEV)
+    torch.manual_seed(9)
+    L = 3
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=L, num_rbf=32, cutoff=3.6, max_neighbors=12,
+              so3_denoising=True, scale_file={f"upd_out_scalar_scale_{i}": 1.0 for i in range(L)}).to(DEV).eval()
+    eng = m.engine()
+    prep = eng.prepare(b)
+    N = b.pos.shape[0]
+    ads = b.tags == 2
+    g = torch.Generator().manual_seed(12)
+
+    def moved(p, amp):
+        q = p.clone()
+        q[ads] = q[ads] + (torch.rand(int(ads.sum()), 3, generator=g).to(DEV) - 0.5) * 2.0 * amp
+        return q
+
+    def fwd(p):
+        f1, f2 = torch.zeros(N, 3, device=DEV), torch.zeros(N, 3, device=DEV)
+        m.engine().forward_prepared(prep, p, f1, f2)  # engine(): re-binds the weights when they changed
+        return f1, f2
+
+    p0 = b.pos.clone(); p1 = moved(p0, 0.1); p2 = moved(p1, 0.1); p3 = moved(p2, 0.1)
+    eng.set_moving_atoms(prep, ads)
+    eng.set_incremental(True)
+    got = [fwd(p0), fwd(p1)]
+    other = b.clone(); other.pos = moved(p1, 2.0)
+    eng.build_graph(other)  # foreign build: same handle, different positions
+    got.append(fwd(p2))
+    w = m.message_layers[1].x_proj[0].weight
+    w_old = w.detach().clone()
+    w_new = w_old * 1.01
+    with torch.no_grad():   # in-place update, like an optimizer step / EMA copy
+        w.copy_(w_new)
+    got.append(fwd(p3))
+    eng.set_incremental(False)
+    eng.set_moving_atoms(None, None)
+    with torch.no_grad():
+        w.copy_(w_old)
+    ref = [fwd(p0), fwd(p1), fwd(p2)]
+    with torch.no_grad():
+        w.copy_(w_new)
+    ref.append(fwd(p3))
+    eng.set_incremental(True)
+    for k, ((a1, a2), (b1, b2)) in enumerate(zip(got, ref)):
+        assert torch.equal(a1, b1) and torch.equal(a2, b2), k
+
+
 def test_incremental_layers_switch_gives_identical_samples():
     """denoising_pos_params["incremental_layers"]=False recomputes every row every step: same sampled positions, with
     and without scores_on_adsorbate_only."""
