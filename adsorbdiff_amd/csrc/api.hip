@@ -571,13 +571,15 @@ extern "C" int32_t adf_painn_forward_subset(adf_painn_t h, const adf_batch* b, c
     return forward_impl(h, b, out_idx, n_out, f1, f2, stream);
 }
 
-// Incremental layers usable for this forward?  Allocates the kept state on first use (an allocation failure switches
-// the feature off: the plain path needs none of it) and swaps the CSR buffers so that the coming graph build leaves the
-// previous build's CSR in prev_*.
-static bool inc_prepare(adf_painn* h, int N) {
+// Incremental layers usable for this forward?  0 = no; 1 = yes and the kept state is current; 2 = yes, but every row has
+// to be computed.  Allocates the kept state on first use (an allocation failure switches the feature off: the plain
+// path needs none of it) and swaps the CSR buffers so that the coming graph build leaves the previous build's CSR in
+// prev_*.  The state is marked invalid until forward_incremental has finished: an error on the way (graph overflow,
+// launch failure) must not leave rows behind that a later forward would trust.
+static int inc_prepare(adf_painn* h, int N) {
     const int L = h->hp.num_layers, H = h->hp.hidden_channels;
     if (!h->inc_on || !h->moving || h->gemm_f32 || h->msg_f32 || !h->msg_v1 || L > ADF_MAX_LAYERS || !h->prev_nptr)
-        return false;
+        return 0;
     if (N > h->inc_capN) {
         (void)hipDeviceSynchronize();
         inc_free(h);
@@ -609,7 +611,7 @@ static bool inc_prepare(adf_painn* h, int N) {
             inc_free(h);
             h->inc_on = false;
             fprintf(stderr, "adsorbdiff_hip: no memory for incremental layers (%d atoms), continuing without\n", N);
-            return false;
+            return 0;
         }
         h->inc_capN = (int64_t)cap;
     }
@@ -618,7 +620,9 @@ static bool inc_prepare(adf_painn* h, int N) {
     int32_t* tn = h->nptr; h->nptr = h->prev_nptr; h->prev_nptr = tn;
     int32_t* ts = h->e_src; h->e_src = h->prev_src; h->prev_src = ts;
     float4* tg = h->e_geom; h->e_geom = h->prev_geom; h->prev_geom = tg;
-    return true;
+    const int state = h->inc_valid ? 1 : 2;
+    h->inc_valid = false;
+    return state;
 }
 
 __global__ void adf_scatter_rows3_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int n,
@@ -626,11 +630,10 @@ __global__ void adf_scatter_rows3_kernel(const float* __restrict__ src, const in
 
 // One forward on the kept per-layer state.  The graph of this step is built; prev_* hold the previous build's CSR.
 static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const int32_t* out_idx, int32_t n_out,
-                                   float* f1, float* f2, hipStream_t s) {
+                                   float* f1, float* f2, bool first, hipStream_t s) {
     const int L = h->hp.num_layers, H = h->hp.hidden_channels;
     const size_t cap = (size_t)h->inc_capN, row = (size_t)5 * H;
-    const bool first = !h->inc_valid;
-    if (out_idx && n_out == 0) return ADF_OK;
+    if (out_idx && n_out == 0) return ADF_OK;  // nothing wanted; the state stays invalid (this build was not applied)
     adf_prof_begin(h, ADF_PROF_GRAPH, s);
     if (first) {
         ADF_TRY(adf_nodewise_embed(h, Z, N, h->incX[0], s));
@@ -646,7 +649,6 @@ static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const 
     ADF_HIP_CHECK(hipMemcpyAsync(h->inc_cnt_host, h->inc_cnt, sizeof(int32_t) * (2 * L + 1), hipMemcpyDeviceToHost, s));
     ADF_HIP_CHECK(hipStreamSynchronize(s));
     adf_prof_end(h, s);
-    h->inc_valid = true;
     if (first) ADF_TRY(make_records(h, 0, N, h->incX[0], nullptr, true, h->incR[0], nullptr, s));
     for (int l = 0; l < L; ++l) {
         const int n = h->inc_cnt_host[l];
@@ -703,6 +705,7 @@ static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const 
         ADF_HIP_CHECK(hipGetLastError());
     }
     adf_prof_end(h, s);
+    h->inc_valid = true;
     return ADF_OK;
 }
 
@@ -714,13 +717,13 @@ static int32_t forward_impl(adf_painn_t h, const adf_batch* b, const int32_t* ou
     hipStream_t s = (hipStream_t)stream;
     const int N = b->num_atoms;
     ADF_TRY(ensure_capacity(h, N, b->num_systems));
-    const bool inc = inc_prepare(h, N);
+    const int inc = inc_prepare(h, N);
     adf_prof_begin(h, ADF_PROF_GRAPH, s);
     ADF_TRY(adf_graph_build_impl(h, b, s));
     adf_prof_end(h, s);
     if (inc) {
         h->inc_serial = h->build_serial;
-        return forward_incremental(h, N, b->atomic_numbers, out_idx, n_out, f1, f2, s);
+        return forward_incremental(h, N, b->atomic_numbers, out_idx, n_out, f1, f2, inc == 2, s);
     }
     ADF_TRY(zero_pad_rows(h, N, s));
     ADF_TRY(adf_nodewise_embed(h, b->atomic_numbers, N, h->x, s));  // vec = 0 is implicit in layer 0
