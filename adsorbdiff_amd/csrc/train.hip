@@ -103,6 +103,74 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
     if (colsum && n0 + tid < N) bpart[(size_t)split * N + n0 + tid] = bs;
 }
 
+// Same contraction on 128 x 128 tiles (N % 128 == 0, K % 128 == 0): each wave owns 64 x 64 = 2 x 2 MFMA blocks, so an LDS
+// value feeds two MFMAs and a staged row serves twice as many; rows are staged with 16-byte loads.
+__global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A,
+                                                           int lda, float* __restrict__ part, int M, int N, int K,
+                                                           int rows_per_split, int tiles_k, float* __restrict__ bpart) {
+    __shared__ __attribute__((aligned(16))) float Cs[32][128];
+    __shared__ __attribute__((aligned(16))) float As[32][128];
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool colsum = bpart && k0 == 0 && tid < 128;
+    float bs = 0.f;
+    const int lr = tid >> 5, lc = (tid & 31) * 4;  // staging: 8 rows x 32 float4 per pass, 4 passes
+    for (int m0 = mbeg; m0 < mend; m0 += 32) {
+        float4 c4[4], a4[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = m0 + lr + 8 * ps;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            c4[ps] = m < mend ? *reinterpret_cast<const float4*>(dC + (size_t)m * ldc + n0 + lc) : z;
+            a4[ps] = m < mend ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k0 + lc) : z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            *reinterpret_cast<float4*>(&Cs[lr + 8 * ps][lc]) = c4[ps];
+            *reinterpret_cast<float4*>(&As[lr + 8 * ps][lc]) = a4[ps];
+        }
+        __syncthreads();
+        if (colsum) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) bs += Cs[r][tid];  // rows in order: reproducible
+        }
+#pragma unroll
+        for (int mm = 0; mm < 32; mm += 2) {
+            const int rr = mm + (lane >> 5), cc = lane & 31;
+            const float a0 = Cs[rr][wn + cc], a1 = Cs[rr][wn + 32 + cc];
+            const float b0 = As[rr][wk + cc], b1 = As[rr][wk + 32 + cc];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float* out = part + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = k0 + wk + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(size_t)row * K + col] = acc[i][j][r];
+            }
+        }
+    if (colsum) bpart[(size_t)split * N + n0 + tid] = bs;
+}
+
 // dst[i] (+)= sum_s part[s][i] in a fixed order (run-to-run reproducible gradients)
 __global__ void tr_reduce_splits_kernel(const float* __restrict__ part, long long stride, float* __restrict__ dst,
                                         long long n, int splits, int accumulate) {
@@ -197,9 +265,16 @@ extern "C" int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W
     }
     if (dW) {
         if (!A) { adf_set_error("linear_bwd: dW needs A"); return ADF_EINVAL; }
-        const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
-        hipLaunchKernelGGL(tr_wgrad_kernel, dim3(tiles_n * tiles_k, splits), dim3(256), 0, s, dC, ldc, A, lda, part, (int)M, N,
-                           K, rows, tiles_k, db ? part + (size_t)splits * N * K : (float*)nullptr);
+        float* bp = db ? part + (size_t)splits * N * K : (float*)nullptr;
+        if (N % 128 == 0 && K % 128 == 0 && (lda & 3) == 0 && (ldc & 3) == 0 &&
+            ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(dC)) & 15) == 0) {
+            hipLaunchKernelGGL(tr_wgrad128_kernel, dim3((N / 128) * (K / 128), splits), dim3(256), 0, s, dC, ldc, A, lda, part,
+                               (int)M, N, K, rows, K / 128, bp);
+        } else {
+            const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
+            hipLaunchKernelGGL(tr_wgrad_kernel, dim3(tiles_n * tiles_k, splits), dim3(256), 0, s, dC, ldc, A, lda, part, (int)M,
+                               N, K, rows, tiles_k, bp);
+        }
         hipLaunchKernelGGL(tr_reduce_splits_kernel, dim3(tr_grid((long long)N * K)), dim3(256), 0, s, part, (long long)N * K,
                            dW, (long long)N * K, splits, acc_dW);
     }
