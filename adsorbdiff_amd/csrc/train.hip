@@ -12,6 +12,9 @@
 // each incoming edge e' = (i -> j) the reverse edge (j -> i) carries the same rbfh row (a function of the distance
 // only) and the negated unit vector.  The per-edge gradient of rbfh is written at row e' instead of the reverse
 // edge's row - the sum over edges of drbfh[e] (x) rbf[e] that makes dW is invariant under that relabelling.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,6 +42,41 @@ __device__ __forceinline__ float tr_dssilu(float x) {
 }
 
 // ------------------------------------------------------------------------------------------------ linear layers
+// C = A W^T (+ bias) of the forward.  Default: the f16x3 split GEMM of the sampling path (gemm16.hip; ~1e-6 relative on
+// O(1) activations; the data-gradient GEMMs stay exact f32: their operands are ~1e-6 and would need a scale) with the weight
+// split per call - in training the weights change every step; the hi/lo image lives in a per-device scratch that
+// consecutive calls on one stream reuse in order.  ADF_TRAIN_GEMM=f32 selects the exact-f32 MFMA GEMM (gemm.hip).
+static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, long long M, int N,
+                       int K, hipStream_t s) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("ADF_TRAIN_GEMM"); mode = (e && strcmp(e, "f32") == 0) ? 0 : 1; }
+    const bool ok16 = mode == 1 && K % 32 == 0 && (lda & 3) == 0 && M * (long long)lda * 4 < (1ll << 32);
+    if (!ok16) return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
+    static unsigned char* buf[16] = {};
+    static size_t cap[16] = {};
+    int dev = 0;
+    ADF_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
+    const size_t n = (size_t)N * K, need = n * 4 + 256;
+    if (need > cap[dev]) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        if (buf[dev]) (void)hipFree(buf[dev]);
+        buf[dev] = nullptr; cap[dev] = 0;
+        const size_t want = need + need / 4;
+        if (hipMalloc(reinterpret_cast<void**>(&buf[dev]), want) != hipSuccess) {
+            (void)hipGetLastError();
+            return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
+        }
+        cap[dev] = want;
+    }
+    adf_w16 w16;
+    w16.hi = buf[dev]; w16.lo = buf[dev] + n * 2;
+    w16.inv_scale = reinterpret_cast<float*>(buf[dev] + n * 4);
+    w16.bias_perm = nullptr;
+    ADF_TRY(adf_split_weight(W, (long long)n, &w16, reinterpret_cast<unsigned int*>(buf[dev] + n * 4 + 16), s));
+    return adf_launch_gemm16(A, lda, &w16, bias, C, ldc, (int)M, N, K, 0, s);
+}
+
 __global__ void tr_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
     __shared__ float t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -222,7 +260,7 @@ __global__ void tr_add_rows_kernel(const float* __restrict__ src, int lds_, floa
 extern "C" int32_t adf_op_linear_fwd(const float* A, int32_t lda, const float* W, const float* bias, float* C, int32_t ldc,
                                      int64_t M, int32_t N, int32_t K, void* stream) {
     if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) { adf_set_error("linear_fwd: bad argument"); return ADF_EINVAL; }
-    return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, (hipStream_t)stream);
+    return tr_gemm(A, lda, W, bias, C, ldc, M, N, K, (hipStream_t)stream);
 }
 
 // Backward of y = A W^T + b.  dA (optional, [M,K] with row stride ldda) = dC W, written or accumulated;
@@ -249,6 +287,7 @@ extern "C" int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W
         if (N % 32 == 0) {
             hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(32, 8), 0, s, W, Wt, N, K);
             if (!acc_dA) {
+                // exact f32: gradients are ~1e-6 and would sit in the fp16 subnormal range of the unscaled f16x3 split
                 ADF_TRY(adf_launch_gemm(dC, ldc, Wt, N, nullptr, dA, ldda, (int)M, K, N, 0, s));
             } else {
                 float* tmp = part + (size_t)64 * ((size_t)N * K + N);  // [M,K]
