@@ -893,8 +893,8 @@ extern "C" int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, flo
 }
 
 // The whole reverse loop (denoising_torch.py:235-356) in one call: num_steps x (graph build + forward + step), all
-// on `stream`, no host round trip unless poll_every > 0 (then the frozen flag is read back every poll_every steps and
-// the loop ends early, exactly like the reference's `break`).
+// on `stream`.  Host round trips: with poll_every > 0 the frozen flag is read back every poll_every steps and the loop
+// ends early, exactly like the reference's `break`; with incremental layers on, each forward reads its list lengths.
 extern "C" int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                               const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
                               const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,

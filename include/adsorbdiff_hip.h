@@ -132,6 +132,8 @@ int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32);
  * neighbour's, or its in-edge list / geometry, compared bit for bit with the previous build — changed since the row
  * was computed.  Every output is bit-identical to a full forward; the reference recomputes everything every step
  * (denoising_torch.py:498 -> painn_denoising.py:460-471).  Costs about 110 KB of HBM per atom (H=512, 6 layers).
+ * An incremental forward reads the lengths of its recompute lists back once (52 bytes, one stream synchronisation);
+ * with the feature off a forward is enqueued without any host round trip (what a hipGraph capture needs).
  * Calling this (with either value) drops the kept state and zeroes the counters adf_get_counters reports. */
 int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on);
 
@@ -229,8 +231,8 @@ int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, float* pos, co
  * 235-356) in one call: num_steps x (adf_painn_forward[_subset] + adf_sde_step_scheduled), enqueued on `stream`.
  * z_tr_all, z_rot_all: [num_steps][B][3] standard normals (SDE) or both NULL (ODE).  poll_every > 0 (and
  * early_stop_count > 0): every poll_every steps the frozen flag state[1] is read back (one stream synchronisation)
- * and the loop ends once it is set — the reference's `break`; 0 = never synchronise (steps after the stop are
- * no-ops on pos).  out_idx / n_out: optional subset of atoms whose model outputs are evaluated (see
+ * and the loop ends once it is set — the reference's `break`; 0 = never synchronise for that (steps after the stop
+ * are no-ops on pos; incremental layers, if on, synchronise once per forward for their list lengths).  out_idx / n_out: optional subset of atoms whose model outputs are evaluated (see
  * adf_painn_forward_subset), NULL = all.  f1, f2: [N,3] work arrays (last step's outputs on return). */
 int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                    const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
