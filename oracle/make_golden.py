@@ -455,8 +455,18 @@ def main():
     from adsorbdiff.models.equiformer_v2.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos as RefEqV2
     from adsorbdiff.models.equiformer_v2.wigner import wigner_D as ref_wigner_D
 
+    from adsorbdiff.models.equiformer_v2.so3 import SO3_Rotation as RefSO3Rotation
+    from oracle import eqv2_oracle as Q
+
     chk = E3.self_check(ref_wigner_D)
     print("[eqv2] e3nn stand-in self-check:", chk)
+    # the oracle's Wigner matrices (solved from the harmonics) against the reference's (z-rotations x vendored J matrices)
+    frames = Q.edge_frames(torch.randn(64, 3, generator=torch.Generator().manual_seed(11)))
+    rot6 = RefSO3Rotation(6)
+    rot6.set_wigner(frames)
+    wdiff = float((rot6.wigner - Q.wigner_from_rotation(6, frames)).abs().max())
+    print(f"[eqv2] Wigner-D, reference vs oracle: |diff|max = {wdiff:.2e}")
+    assert wdiff < 5e-6
     assert chk["equivariance_max_abs"] < 1e-12 and all(v < 1e-5 for k, v in chk.items() if k.startswith("roundtrip"))
     be = make_batch(2, n_slab=16, n_ads=3, seed=3)
     for lmax_, mmax_ in ((4, 2), (6, 2)):
@@ -484,8 +494,29 @@ def main():
         gauge = float((outs[0][0] - outs[1][0]).abs().max() / f1e.abs().max())
         assert bool(torch.isfinite(f1e).all()) and gauge < 1e-5, gauge
         grid = eq.SO3_grid[lmax_][mmax_]
+        # oracle restatement (oracle/eqv2_oracle.py) on the reference's own edge list: in this small cell the +a / -a
+        # images of an atom tie exactly at the K-th place and the reference's pick is implementation-defined
+        gq = eq.generate_graph(bq.clone(), enforce_max_neighbors_strictly=True)
+        hp_q = dict(lmax=lmax_, mmax=mmax_, num_layers=2, sphere_channels=8, attn_hidden_channels=8, num_heads=2,
+                    attn_alpha_channels=4, attn_value_channels=4, ffn_hidden_channels=16, grid_resolution=18,
+                    max_radius=6.0, max_neighbors=20)
+        sd_q = {k: v.detach().clone() for k, v in eq.state_dict().items()}
+        with torch.no_grad():
+            q1, q2 = Q.eqv2_forward(sd_q, hp_q, bq.pos, bq.atomic_numbers, bq.cell, bq.natoms, graph=(gq[0], gq[2]))
+            r1, r2 = Q.eqv2_forward(sd_q, hp_q, bq.pos, bq.atomic_numbers, bq.cell, bq.natoms, graph=(gq[0], gq[2]),
+                                    atom_radii=eq.atom_radii.detach())
+        eq1 = float((q1 - f1e).norm() / f1e.norm())
+        eq2 = float((q2 - f2e).norm() / f2e.norm())
+        print(f"[eqv2] L={lmax_} M={mmax_}: oracle vs reference rel err {eq1:.2e} / {eq2:.2e} "
+              f"(with the tabulated radii: {float((r1 - f1e).norm() / f1e.norm()):.2e})")
+        assert eq1 < 1e-5 and eq2 < 1e-5 and float((r1 - f1e).norm() / f1e.norm()) < 1e-5
+        own = Q.radius_graph_pbc(bq.pos, bq.cell, bq.natoms, 6.0, 20)
+        own_ei, own_d, _, _ = Q.pbc_distances(bq.pos, own[0], bq.cell, own[1], own[2])
+        key = lambda ei_, d_: sorted((int(a_), int(b_), round(float(c_), 4)) for a_, b_, c_ in zip(ei_[0], ei_[1], d_))
+        assert key(own_ei, own_d) == key(gq[0], gq[1])  # same edges up to the sign of tied self-images
         fxe = dict(f1=f1e, f2=f2e, gauge_dependence=gauge, lmax=lmax_, mmax=mmax_, to_grid_mat=grid.to_grid_mat,
-                   from_grid_mat=grid.from_grid_mat, nan_radius_elements=np.array(sorted(bad)), **batch_inputs(bq))
+                   from_grid_mat=grid.from_grid_mat, nan_radius_elements=np.array(sorted(bad)), edge_index=gq[0],
+                   edge_vec=gq[2], **batch_inputs(bq))
         pnames = {k for k, _ in eq.named_parameters()}
         fxe.update({"sd::" + k: v for k, v in eq.state_dict().items() if k in pnames and k != "atom_radii"})  # parameters only
         fxe["hp"] = np.array("num_layers=2 sphere_channels=8 attn_hidden_channels=8 num_heads=2 attn_alpha_channels=4 "
