@@ -14,7 +14,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libadsorbdiff_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "graph.hip", "message.hip", "message32.hip", "nodewise.hip", "stepper.hip", "peaks.hip", "collect.hip", "train.hip", "incremental.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "graph.hip", "message.hip", "message32.hip", "nodewise.hip", "stepper.hip", "peaks.hip", "collect.hip", "train.hip", "incremental.hip", "eqv2_kernels.hip", "eqv2_api.hip"]
 
 
 def _hipcc() -> str:
@@ -28,7 +28,7 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", PKG.parent / "include" / "adsorbdiff_hip.h"]
+    deps = [CSRC / s for s in SOURCES] + sorted(CSRC.glob("*.h")) + [PKG.parent / "include" / "adsorbdiff_hip.h"]
     return any(d.stat().st_mtime > t for d in deps)
 
 
@@ -57,8 +57,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     cc = _hipcc()
     OBJ_DIR.mkdir(exist_ok=True)
-    hdr_t = max((CSRC / "common.h").stat().st_mtime, (PKG.parent / "include" / "adsorbdiff_hip.h").stat().st_mtime,
-                Path(__file__).stat().st_mtime)
+    hdr_t = max([p.stat().st_mtime for p in CSRC.glob("*.h")] + [(PKG.parent / "include" / "adsorbdiff_hip.h").stat().st_mtime,
+                                                                  Path(__file__).stat().st_mtime])
     jobs, objs = [], []
     for s in SOURCES:
         src, obj = CSRC / s, OBJ_DIR / (s + ".o")

@@ -857,7 +857,7 @@ extern "C" int32_t adf_sde_init_placement(adf_painn_t h, const adf_batch* b, flo
                                           const float* noise, void* stream) {
     ADF_TRY(check_batch(h, b));
     if (!pos || !tags || !noise) { adf_set_error("null argument"); return ADF_EINVAL; }
-    return adf_stepper_init(h, b, pos, tags, noise, (hipStream_t)stream);
+    return adf_stepper_init(b, pos, tags, noise, (hipStream_t)stream);
 }
 
 static int32_t sde_step_common(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags,
@@ -868,7 +868,7 @@ static int32_t sde_step_common(adf_painn_t h, const adf_batch* b, float* pos, co
     if (!pos || !tags || !f1 || !f2 || (!coef && !coefs_dev) || !state) { adf_set_error("null argument"); return ADF_EINVAL; }
     ADF_TRY(ensure_capacity(h, b->num_atoms, b->num_systems));
     adf_prof_begin(h, ADF_PROF_STEPPER, (hipStream_t)stream);
-    const int32_t st = adf_stepper_step(h, b, pos, tags, fixed, f1, f2, coef, coefs_dev, num_steps, z_tr, z_rot,
+    const int32_t st = adf_stepper_step(h->sys, b, pos, tags, fixed, f1, f2, coef, coefs_dev, num_steps, z_tr, z_rot,
                                         early_stop_count, state, dcom, drot, (hipStream_t)stream);
     adf_prof_end(h, (hipStream_t)stream);
     return st;

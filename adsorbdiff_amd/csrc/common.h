@@ -213,9 +213,10 @@ int32_t adf_nodewise_update_prep(const float* vv, const float* x, float* cat, fl
 int32_t adf_nodewise_update_apply(const float* h3, const float* dot, const float* vv, float* x, float* vec,
                                   float scale, int N, int H, hipStream_t s);
 int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const float* vec, float* out, hipStream_t s);
-int32_t adf_stepper_init(adf_painn* h, const adf_batch* b, float* pos, const int32_t* tags, const float* noise,
+int32_t adf_stepper_init(const adf_batch* b, float* pos, const int32_t* tags, const float* noise,
                          hipStream_t s);
-int32_t adf_stepper_step(adf_painn* h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+// sys: [16 B] floats of per-system scratch
+int32_t adf_stepper_step(float* sys, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                          const float* f1, const float* f2, const adf_step_coef* coef, const adf_step_coef* coefs_dev,
                          int num_steps, const float* z_tr, const float* z_rot, int32_t early_stop_count,
                          int32_t* state, float* dcom, float* drot, hipStream_t s);

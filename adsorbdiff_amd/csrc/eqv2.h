@@ -1,0 +1,138 @@
+// Internal declarations of the EquiformerV2 denoiser path (BASELINE config 4).
+// Reference: adsorbdiff/models/equiformer_v2/equiformer_v2_denoising.py:185-318 and the modules it calls.
+#pragma once
+#include "common.h"
+
+#define EQ_MAX_L 6        // register-array kernels are instantiated for lmax = 1..6
+#define EQ_MAX_M 6
+#define EQ_MAX_LAYERS 32
+#define EQ_NFLAGS 8
+
+// nn.Linear weight [out, in] (+ bias) as bound by adf_eqv2_set_weights, plus the library's fp16 hi/lo image
+struct eq_lin {
+    const float* w;
+    const float* b;
+    int out, in;
+    adf_w16 w16;
+    bool has16;
+};
+struct eq_radial {      // RadialFunction: Linear, LayerNorm, SiLU, Linear, LayerNorm, SiLU, Linear (radial_function.py:11-32)
+    eq_lin l0, l3, l6;
+    const float *ln1_w, *ln1_b, *ln4_w, *ln4_b;
+    float* w0t;         // library-owned transpose of l0.w: [in, out]
+};
+struct eq_norm {        // EquivariantLayerNormArraySphericalHarmonics (layer_norm.py:129-250)
+    const float *affine, *l0_w, *l0_b;
+};
+struct eq_attn {        // SO2EquivariantGraphAttention (transformer_block.py:38-372)
+    const float *alpha_dot, *src_emb, *dst_emb, *alpha_ln_w, *alpha_ln_b;
+    eq_lin c1_m0, c1_m[EQ_MAX_M], c2_m0, c2_m[EQ_MAX_M];
+    eq_radial rad;
+    const float *proj_w, *proj_b;  // SO3_LinearV2 [L+1, out, HV], bias [out]
+    eq_lin proj_l[EQ_MAX_L + 1];   // per-degree views of proj_w
+    int out_channels;
+};
+struct eq_ffn {         // FeedForwardNetwork with grid MLP + separable S2 activation (transformer_block.py:375-531)
+    const float *l1_w, *l1_b, *l2_w, *l2_b;
+    eq_lin l1[EQ_MAX_L + 1], l2[EQ_MAX_L + 1];
+    eq_lin scalar, g0, g2, g4;
+};
+struct eq_block {
+    eq_norm n1, n2;
+    eq_attn ga;
+    eq_ffn ffn;
+};
+
+// index bookkeeping shared by host and kernels (passed by value)
+struct eq_dims {
+    int L, M, C, S, Sr, DR, G;
+    int Hd, NH, A, V, HV, F, EC, NB;
+    int d_off[EQ_MAX_L + 2];   // offset of degree l inside an edge's Wigner rows
+    int nrow[EQ_MAX_L + 1];    // kept rows of degree l: 2 min(l, M) + 1
+    int rbase[EQ_MAX_M + 1];   // first m-major reduced index of order m (m = 0: 0)
+    int rad_off[EQ_MAX_M + 1]; // column offset of order m in a radial row, in units of the input channel count
+    int RW;                    // sum_m (L - m + 1)
+    int j_off[EQ_MAX_L + 2];   // offset of J_l in the concatenated table
+    short r_m[64], r_sgn[64], r_l[64];  // m-major reduced index -> (order m, 0: +m or m = 0 / 1: -m, degree l)
+    float resc[EQ_MAX_L + 1];  // m-truncation rescale sqrt((2l+1)/(2M+1)) for l > M (so3.py:160-186)
+};
+
+// A operand / C result row addressing of the dense kernels: row r lives at base + (r / period) * outer + (r % period) * inner
+struct eq_rowmap {
+    long long outer;
+    int period, inner;
+};
+
+struct adf_eqv2 {
+    adf_eqv2_hparams hp;
+    eq_dims d;
+    int device, num_cus;
+    bool weights_set, consts_set, exact_f32;
+    // constants (device)
+    float *jd, *to_red, *from_red, *to_full, *from_full;
+    // weights
+    const float* atom_radii;
+    const float* sphere_emb;
+    const float *ed_src_emb, *ed_dst_emb;
+    eq_radial ed_rad;
+    eq_block blk[EQ_MAX_LAYERS];
+    eq_norm final_norm;
+    eq_attn force[2];
+    unsigned char* w16_arena; size_t w16_bytes; float* w16_scales; unsigned int* w16_scratch;
+    float* wt_arena; size_t wt_bytes;   // transposed first radial layers
+    // graph
+    int64_t capN, capB, capE;
+    int32_t *nbr_cnt, *nbr_src, *nbr_shift, *img_cnt, *eptr, *e_src, *e_dst, *flags;
+    float* e_vec;     // [capE,3]
+    float* wig;       // [capE, DR]
+    void* scan_tmp; size_t scan_tmp_bytes;
+    const int32_t *moving, *mov_idx, *mov_off;
+    float* cache_d2; int32_t *cache_cid, *cache_cnt; bool cache_valid;
+    bool ext_graph;   // edges were supplied by adf_eqv2_set_edges
+    int64_t E_ext; int maxdeg;
+    int32_t *xe_src, *xe_dst; float* xe_vec; int64_t xe_cap;   // the caller's edge list (private copy)
+    int64_t arena_kk;   // edges per target the chunk arena was sized for
+    // node buffers
+    float *x, *y, *agg, *gate, *h1, *h2;
+    // chunk arena
+    int64_t chunk_nodes;          // targets per chunk
+    float* arena; size_t arena_floats;
+    float* garena; size_t garena_floats;   // grid MLP buffers of a node chunk
+    float* sys;
+    int64_t lastN;
+    // HIP-event timing per kernel group (bench.py roofline)
+    bool prof_on;
+    std::vector<hipEvent_t>* prof_ev;
+    std::vector<int>* prof_cat;
+    size_t prof_used;
+};
+
+enum { EQ_PROF_GRAPH = 0, EQ_PROF_RADIAL, EQ_PROF_ROTATE, EQ_PROF_CONV, EQ_PROF_S2ACT, EQ_PROF_ATTN, EQ_PROF_NODE,
+       EQ_PROF_FFN, EQ_PROF_STEPPER, EQ_PROF_NCAT };
+
+// ---- launchers (eqv2_kernels.hip)
+int32_t eq_launch_edges_from_topk(adf_eqv2* h, const adf_batch* b, hipStream_t s);
+int32_t eq_launch_eptr_from_dst(adf_eqv2* h, int N, int64_t E, hipStream_t s);
+int32_t eq_launch_wigner(adf_eqv2* h, int N, hipStream_t s);
+int32_t eq_launch_norm(const adf_eqv2* h, const eq_norm* nm, const float* x, float* y, int N, hipStream_t s);
+int32_t eq_launch_radial_pre(const adf_eqv2* h, const eq_radial* r, const float* src_emb, const float* dst_emb,
+                             const int32_t* Z, int n0, int n1, float* out, int N, hipStream_t s);
+int32_t eq_launch_ln_silu(float* x, const float* w, const float* b, long long rows, int width, hipStream_t s);
+int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int n0, int n1, float* x, hipStream_t s);
+int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, int n0, int n1, float* const* mbuf,
+                            hipStream_t s);
+int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,
+                        float* const* mb, hipStream_t s);
+int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, int ldy, int n0, int n1, float* alpha,
+                        hipStream_t s);
+int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* alpha, int n0, int n1, float* agg,
+                             bool only_l1, hipStream_t s);
+int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, hipStream_t s);
+int32_t eq_launch_from_grid(const adf_eqv2* h, const float* g, const float* gate, int n0, int n1, float* h2, hipStream_t s);
+int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* agg3, int N, float* f, hipStream_t s);
+int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float* W, const float* bias, float* Cm, int ldc,
+                    const eq_rowmap* cmap, long long M, int N, int K, int act, bool accumulate, hipStream_t s);
+int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+// C (+)= act(A . W^T + b): exact f32 for any shape; act: 0 none, 2 SiLU
+int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
+                float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s);

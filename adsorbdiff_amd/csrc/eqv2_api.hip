@@ -1,0 +1,648 @@
+// EquiformerV2 denoiser: handle, weight binding, forward orchestration and the C ABI (include/adsorbdiff_hip.h,
+// "EquiformerV2 denoiser").  Reference: models/equiformer_v2/equiformer_v2_denoising.py:185-318 (forward),
+// transformer_block.py:226-372 (SO2EquivariantGraphAttention.forward), :473-531 (FeedForwardNetwork.forward),
+// :650-728 (TransBlockV2.forward), input_block.py:84-138 (EdgeDegreeEmbedding.forward).
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "eqv2.h"
+
+int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float* W, const float* bias, float* Cm, int ldc,
+                    const eq_rowmap* cmap, long long M, int N, int K, int act, bool accumulate, hipStream_t s);
+int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+
+template <typename T>
+static int32_t eq_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        adf_set_error("eqv2: device allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return ADF_EOOM;
+    }
+    return ADF_OK;
+}
+template <typename T>
+static void eq_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------- profiling
+static void eq_prof_begin(adf_eqv2* h, int cat, hipStream_t s) {
+    if (!h->prof_on) return;
+    if (h->prof_used + 2 > h->prof_ev->size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            h->prof_ev->push_back(e);
+        }
+    }
+    h->prof_cat->push_back(cat);
+    (void)hipEventRecord((*h->prof_ev)[h->prof_used], s);
+}
+static void eq_prof_end(adf_eqv2* h, hipStream_t s) {
+    if (!h->prof_on || h->prof_used + 2 > h->prof_ev->size()) return;
+    (void)hipEventRecord((*h->prof_ev)[h->prof_used + 1], s);
+    h->prof_used += 2;
+}
+struct eq_prof_scope {
+    adf_eqv2* h; hipStream_t s;
+    eq_prof_scope(adf_eqv2* h_, int cat, hipStream_t s_) : h(h_), s(s_) { eq_prof_begin(h, cat, s); }
+    ~eq_prof_scope() { eq_prof_end(h, s); }
+};
+
+// ---------------------------------------------------------------------------------------------- create / destroy
+static void eq_fill_dims(adf_eqv2* h) {
+    const adf_eqv2_hparams& hp = h->hp;
+    eq_dims& d = h->d;
+    memset(&d, 0, sizeof(d));
+    d.L = hp.lmax; d.M = hp.mmax; d.C = hp.sphere_channels; d.S = (d.L + 1) * (d.L + 1);
+    d.G = hp.grid_resolution * hp.grid_resolution;
+    d.Hd = hp.attn_hidden_channels; d.NH = hp.num_heads; d.A = hp.attn_alpha_channels; d.V = hp.attn_value_channels;
+    d.HV = d.NH * d.V; d.F = hp.ffn_hidden_channels; d.EC = hp.edge_channels; d.NB = hp.num_distance_basis;
+    int off = 0, joff = 0;
+    for (int l = 0; l <= d.L; ++l) {
+        const int ml = l < d.M ? l : d.M;
+        d.d_off[l] = off;
+        d.nrow[l] = 2 * ml + 1;
+        off += d.nrow[l] * (2 * l + 1);
+        d.j_off[l] = joff;
+        joff += (2 * l + 1) * (2 * l + 1);
+        d.resc[l] = l > d.M ? sqrtf((float)(2 * l + 1) / (float)(2 * d.M + 1)) : 1.0f;
+    }
+    d.d_off[d.L + 1] = off; d.DR = off; d.j_off[d.L + 1] = joff;
+    int r = 0, ro = 0;
+    for (int m = 0; m <= d.M; ++m) {
+        d.rbase[m] = r;
+        d.rad_off[m] = ro;
+        const int nm = d.L - m + 1;
+        ro += nm;
+        for (int sg = 0; sg < (m == 0 ? 1 : 2); ++sg)
+            for (int l = m; l <= d.L; ++l) { d.r_m[r] = (short)m; d.r_sgn[r] = (short)sg; d.r_l[r] = (short)l; ++r; }
+    }
+    d.Sr = r; d.RW = ro;
+}
+
+extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) {
+    if (!hp || !out) { adf_set_error("eqv2_create: null argument"); return ADF_EINVAL; }
+    if (hp->lmax < 1 || hp->lmax > EQ_MAX_L || hp->mmax < 0 || hp->mmax > hp->lmax || hp->num_layers < 0 ||
+        hp->num_layers > EQ_MAX_LAYERS || hp->sphere_channels < 1 || hp->sphere_channels > 512 || hp->num_heads < 1 ||
+        hp->num_heads > 16 || hp->attn_hidden_channels < 1 || hp->attn_hidden_channels > 256 ||
+        hp->attn_alpha_channels < 1 || hp->attn_value_channels < 1 || hp->num_heads * hp->attn_value_channels > 1024 ||
+        hp->ffn_hidden_channels < 1 || hp->ffn_hidden_channels > 1024 || hp->edge_channels < 1 || hp->edge_channels > 1024 ||
+        hp->grid_resolution < 2 || (hp->grid_resolution & 1) || hp->num_distance_basis < 2 || hp->max_neighbors < 1 ||
+        hp->max_neighbors > ADF_MAX_K || !(hp->max_radius > 0.f) || !(hp->avg_degree > 0.f) || hp->max_num_elements < 1) {
+        adf_set_error("eqv2_create: unsupported hyper-parameters");
+        return ADF_EINVAL;
+    }
+    adf_eqv2* h = new (std::nothrow) adf_eqv2();
+    if (!h) { adf_set_error("eqv2_create: host allocation failed"); return ADF_EOOM; }
+    memset(static_cast<void*>(h), 0, sizeof(*h));
+    h->hp = *hp;
+    eq_fill_dims(h);
+    if ((2 * h->d.M + 1) * (2 * h->d.L + 1) > 13 * 13 || h->d.Sr > 49) { delete h; adf_set_error("eqv2_create: lmax / mmax too large"); return ADF_EINVAL; }
+    ADF_HIP_CHECK(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    ADF_HIP_CHECK(hipGetDeviceProperties(&prop, h->device));
+    h->num_cus = prop.multiProcessorCount;
+    const char* env = getenv("ADF_GEMM");
+    h->exact_f32 = env && !strcmp(env, "f32");
+    h->prof_ev = new std::vector<hipEvent_t>();
+    h->prof_cat = new std::vector<int>();
+    int32_t st = eq_alloc(&h->flags, EQ_NFLAGS);
+    if (st == ADF_OK) { hipError_t e = hipMemset(h->flags, 0, sizeof(int32_t) * EQ_NFLAGS); if (e != hipSuccess) st = ADF_EHIP; }
+    if (st != ADF_OK) { adf_eqv2_destroy(h); return st; }
+    *out = h;
+    return ADF_OK;
+}
+
+static void eq_free_workspaces(adf_eqv2* h) {
+    eq_free(h->nbr_cnt); eq_free(h->nbr_src); eq_free(h->nbr_shift); eq_free(h->img_cnt); eq_free(h->eptr);
+    eq_free(h->e_src); eq_free(h->e_dst); eq_free(h->e_vec); eq_free(h->wig);
+    if (h->scan_tmp) { (void)hipFree(h->scan_tmp); h->scan_tmp = nullptr; }
+    eq_free(h->cache_d2); eq_free(h->cache_cid); eq_free(h->cache_cnt);
+    eq_free(h->x); eq_free(h->y); eq_free(h->agg); eq_free(h->gate); eq_free(h->h1); eq_free(h->h2);
+    eq_free(h->arena); eq_free(h->garena); eq_free(h->sys);
+    h->capN = h->capB = h->capE = 0;
+    h->arena_floats = h->garena_floats = 0;
+}
+
+extern "C" int32_t adf_eqv2_destroy(adf_eqv2_t h) {
+    if (!h) return ADF_OK;
+    (void)hipDeviceSynchronize();
+    eq_free_workspaces(h);
+    eq_free(h->flags);
+    eq_free(h->xe_src); eq_free(h->xe_dst); eq_free(h->xe_vec);
+    eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
+    eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena);
+    if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
+    delete h->prof_cat;
+    delete h;
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_set_constants(adf_eqv2_t h, const float* jd, const float* to_red, const float* from_red,
+                                          const float* to_full, const float* from_full) {
+    if (!h || !jd || !to_red || !from_red || !to_full || !from_full) { adf_set_error("eqv2_set_constants: null argument"); return ADF_EINVAL; }
+    const eq_dims& d = h->d;
+    const size_t nj = d.j_off[d.L + 1], nr = (size_t)d.G * d.Sr, nf = (size_t)d.G * d.S;
+    eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
+    ADF_TRY(eq_alloc(&h->jd, nj)); ADF_TRY(eq_alloc(&h->to_red, nr)); ADF_TRY(eq_alloc(&h->from_red, nr));
+    ADF_TRY(eq_alloc(&h->to_full, nf)); ADF_TRY(eq_alloc(&h->from_full, nf));
+    ADF_HIP_CHECK(hipMemcpy(h->jd, jd, nj * 4, hipMemcpyHostToDevice));
+    ADF_HIP_CHECK(hipMemcpy(h->to_red, to_red, nr * 4, hipMemcpyHostToDevice));
+    ADF_HIP_CHECK(hipMemcpy(h->from_red, from_red, nr * 4, hipMemcpyHostToDevice));
+    ADF_HIP_CHECK(hipMemcpy(h->to_full, to_full, nf * 4, hipMemcpyHostToDevice));
+    ADF_HIP_CHECK(hipMemcpy(h->from_full, from_full, nf * 4, hipMemcpyHostToDevice));
+    h->consts_set = true;
+    return ADF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- weights
+struct eq_wcursor {
+    const void* const* w; int n, i;
+    const float* next() { return i < n ? static_cast<const float*>(w[i++]) : (i++, nullptr); }
+};
+static eq_lin mk_lin(const float* w, const float* b, int out, int in) {
+    eq_lin l; memset(&l, 0, sizeof(l));
+    l.w = w; l.b = b; l.out = out; l.in = in;
+    return l;
+}
+static void bind_radial(eq_wcursor& c, eq_radial* r, int in0, int ec, int out) {
+    const float* w0 = c.next(); const float* b0 = c.next();
+    r->ln1_w = c.next(); r->ln1_b = c.next();
+    const float* w3 = c.next(); const float* b3 = c.next();
+    r->ln4_w = c.next(); r->ln4_b = c.next();
+    const float* w6 = c.next(); const float* b6 = c.next();
+    r->l0 = mk_lin(w0, b0, ec, in0); r->l3 = mk_lin(w3, b3, ec, ec); r->l6 = mk_lin(w6, b6, out, ec);
+}
+static void bind_norm(eq_wcursor& c, eq_norm* n) { n->affine = c.next(); n->l0_w = c.next(); n->l0_b = c.next(); }
+static void bind_attn(eq_wcursor& c, eq_attn* a, const eq_dims& d, int out_channels) {
+    a->out_channels = out_channels;
+    a->alpha_dot = c.next(); a->src_emb = c.next(); a->dst_emb = c.next();
+    const int extra = d.NH * d.A + d.Hd;
+    const float* w = c.next(); const float* b = c.next();
+    a->c1_m0 = mk_lin(w, b, extra + (d.L + 1) * d.Hd, (d.L + 1) * 2 * d.C);
+    for (int m = 1; m <= d.M; ++m) { const int nm = d.L - m + 1; a->c1_m[m - 1] = mk_lin(c.next(), nullptr, 2 * nm * d.Hd, nm * 2 * d.C); }
+    bind_radial(c, &a->rad, d.NB + 2 * d.EC, d.EC, d.RW * 2 * d.C);
+    a->alpha_ln_w = c.next(); a->alpha_ln_b = c.next();
+    w = c.next(); b = c.next();
+    a->c2_m0 = mk_lin(w, b, (d.L + 1) * d.HV, (d.L + 1) * d.Hd);
+    for (int m = 1; m <= d.M; ++m) { const int nm = d.L - m + 1; a->c2_m[m - 1] = mk_lin(c.next(), nullptr, 2 * nm * d.HV, nm * d.Hd); }
+    a->proj_w = c.next(); a->proj_b = c.next();
+    for (int l = 0; l <= d.L; ++l)
+        a->proj_l[l] = mk_lin(a->proj_w ? a->proj_w + (size_t)l * out_channels * d.HV : nullptr, l == 0 ? a->proj_b : nullptr, out_channels, d.HV);
+}
+
+static int eq_expected_weights(const eq_dims& d, int layers) {
+    const int attn = 21 + 2 * d.M;
+    return 14 + layers * (3 + attn + 3 + 9) + 3 + 2 * attn;
+}
+
+extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const void* const* weights, void* stream) {
+    if (!h || !weights) { adf_set_error("eqv2_set_weights: null argument"); return ADF_EINVAL; }
+    const eq_dims& d = h->d;
+    const int want = eq_expected_weights(d, h->hp.num_layers);
+    if (n_weights != want) { adf_set_error("eqv2_set_weights: expected %d tensors, got %d", want, n_weights); return ADF_EINVAL; }
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights[i]) { adf_set_error("eqv2_set_weights: tensor %d is null", i); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    eq_wcursor c{weights, n_weights, 0};
+    h->atom_radii = c.next();
+    h->sphere_emb = c.next();
+    h->ed_src_emb = c.next(); h->ed_dst_emb = c.next();
+    bind_radial(c, &h->ed_rad, d.NB + 2 * d.EC, d.EC, (d.L + 1) * d.C);
+    for (int i = 0; i < h->hp.num_layers; ++i) {
+        eq_block& b = h->blk[i];
+        bind_norm(c, &b.n1);
+        bind_attn(c, &b.ga, d, d.C);
+        bind_norm(c, &b.n2);
+        eq_ffn& f = b.ffn;
+        f.l1_w = c.next(); f.l1_b = c.next();
+        const float* sw = c.next(); const float* sb = c.next();
+        f.scalar = mk_lin(sw, sb, d.F, d.C);
+        f.g0 = mk_lin(c.next(), nullptr, d.F, d.F); f.g2 = mk_lin(c.next(), nullptr, d.F, d.F); f.g4 = mk_lin(c.next(), nullptr, d.F, d.F);
+        f.l2_w = c.next(); f.l2_b = c.next();
+        for (int l = 0; l <= d.L; ++l) {
+            f.l1[l] = mk_lin(f.l1_w + (size_t)l * d.F * d.C, l == 0 ? f.l1_b : nullptr, d.F, d.C);
+            f.l2[l] = mk_lin(f.l2_w + (size_t)l * d.C * d.F, l == 0 ? f.l2_b : nullptr, d.C, d.F);
+        }
+    }
+    bind_norm(c, &h->final_norm);
+    bind_attn(c, &h->force[0], d, 1);
+    bind_attn(c, &h->force[1], d, 1);
+    // transposed first radial layers (one arena)
+    const int nrad = 1 + h->hp.num_layers + 2;
+    const size_t per = (size_t)(d.NB + 2 * d.EC) * d.EC;
+    if (h->wt_bytes < per * nrad * 4) {
+        eq_free(h->wt_arena);
+        ADF_TRY(eq_alloc(&h->wt_arena, per * nrad));
+        h->wt_bytes = per * nrad * 4;
+    }
+    eq_radial* rads[EQ_MAX_LAYERS + 3];
+    int k = 0;
+    rads[k++] = &h->ed_rad;
+    for (int i = 0; i < h->hp.num_layers; ++i) rads[k++] = &h->blk[i].ga.rad;
+    rads[k++] = &h->force[0].rad; rads[k++] = &h->force[1].rad;
+    for (int i = 0; i < k; ++i) {
+        rads[i]->w0t = h->wt_arena + per * i;
+        ADF_TRY(eq_launch_transpose(rads[i]->l0.w, rads[i]->w0t, d.EC, d.NB + 2 * d.EC, s));
+    }
+    h->weights_set = true;
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_set_arithmetic(adf_eqv2_t h, int32_t exact_f32) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    h->exact_f32 = exact_f32 != 0;
+    return ADF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- capacity
+static size_t eq_arena_floats_per_edge(const eq_dims& d) {
+    const size_t extra = (size_t)d.NH * d.A + d.Hd;
+    size_t y = extra + (size_t)(d.L + 1) * d.Hd, z = (size_t)(d.L + 1) * d.HV;
+    for (int m = 1; m <= d.M; ++m) { const size_t nm = d.L - m + 1; y += 4 * nm * d.Hd; z += 4 * nm * d.HV; }
+    return 2 * (size_t)d.EC + (size_t)d.RW * 2 * d.C + (size_t)d.Sr * 2 * d.C + y + d.NH + (size_t)d.Sr * d.Hd + z + 16;
+}
+
+static int32_t eq_ensure_capacity(adf_eqv2* h, int64_t N, int64_t B, int64_t Eneed) {
+    const eq_dims& d = h->d;
+    const int K = h->hp.max_neighbors;
+    int64_t kk = K;
+    if (h->ext_graph && h->maxdeg > kk) kk = h->maxdeg;
+    if (N > h->capN || B > h->capB || Eneed > h->capE || kk > h->arena_kk) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        const int64_t cN = N > h->capN ? N : h->capN, cB = B > h->capB ? B : h->capB;
+        int64_t cE = cN * K;
+        if (Eneed > cE) cE = Eneed;
+        if (h->capE > cE) cE = h->capE;
+        eq_free_workspaces(h);
+        ADF_TRY(eq_alloc(&h->nbr_cnt, (size_t)cN + 1));
+        ADF_HIP_CHECK(hipMemset(h->nbr_cnt, 0, sizeof(int32_t) * ((size_t)cN + 1)));
+        ADF_TRY(eq_alloc(&h->nbr_src, (size_t)cN * K)); ADF_TRY(eq_alloc(&h->nbr_shift, (size_t)cN * K));
+        ADF_TRY(eq_alloc(&h->img_cnt, (size_t)cB)); ADF_TRY(eq_alloc(&h->eptr, (size_t)cN + 2));
+        ADF_TRY(eq_alloc(&h->e_src, (size_t)cE)); ADF_TRY(eq_alloc(&h->e_dst, (size_t)cE));
+        ADF_TRY(eq_alloc(&h->e_vec, (size_t)cE * 3)); ADF_TRY(eq_alloc(&h->wig, (size_t)cE * d.DR));
+        size_t bytes = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (int32_t*)nullptr, (int32_t*)nullptr, (int)(cN + 1));
+        h->scan_tmp_bytes = bytes;
+        ADF_HIP_CHECK(hipMalloc(&h->scan_tmp, bytes ? bytes : 16));
+        ADF_TRY(eq_alloc(&h->cache_d2, (size_t)cN * K)); ADF_TRY(eq_alloc(&h->cache_cid, (size_t)cN * K));
+        ADF_TRY(eq_alloc(&h->cache_cnt, (size_t)cN));
+        h->cache_valid = false;
+        const size_t ns = (size_t)cN * d.S;
+        const size_t wmax = (size_t)(d.C > d.F ? d.C : d.F);
+        ADF_TRY(eq_alloc(&h->x, ns * d.C)); ADF_TRY(eq_alloc(&h->y, ns * d.C));
+        ADF_TRY(eq_alloc(&h->agg, ns * (d.HV > (int)wmax ? d.HV : wmax)));
+        ADF_TRY(eq_alloc(&h->gate, (size_t)cN * d.F));
+        ADF_TRY(eq_alloc(&h->h1, ns * d.F)); ADF_TRY(eq_alloc(&h->h2, ns * d.F));
+        ADF_TRY(eq_alloc(&h->sys, (size_t)cB * 16));
+        // chunk size: bounded edge-arena (ADF_EQV2_CHUNK_EDGES, default 2^19 edges)
+        int64_t chunk_edges = 1 << 19;
+        if (const char* e = getenv("ADF_EQV2_CHUNK_EDGES")) { const long long v = atoll(e); if (v > 0) chunk_edges = v; }
+        if (h->arena_kk > kk) kk = h->arena_kk;
+        h->arena_kk = kk;
+        int64_t cn = chunk_edges / kk;
+        if (cn < 1) cn = 1;
+        if (cn > cN) cn = cN;
+        h->chunk_nodes = cn;
+        h->arena_floats = eq_arena_floats_per_edge(d) * (size_t)(cn * kk);
+        ADF_TRY(eq_alloc(&h->arena, h->arena_floats));
+        h->garena_floats = 2 * (size_t)cn * d.G * d.F;
+        ADF_TRY(eq_alloc(&h->garena, h->garena_floats));
+        h->capN = cN; h->capB = cB; h->capE = cE;
+    }
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_set_edges(adf_eqv2_t h, int64_t num_edges, const int32_t* src, const int32_t* dst,
+                                      const float* vec, int32_t max_in_degree, void* stream) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    if (num_edges <= 0) { h->ext_graph = false; h->E_ext = 0; return ADF_OK; }
+    if (!src || !dst || !vec || max_in_degree < 1 || max_in_degree > 128) { adf_set_error("eqv2_set_edges: bad argument"); return ADF_EINVAL; }
+    // private copy; the forward moves it into the (possibly re-allocated) graph workspaces
+    if (num_edges > h->xe_cap) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        eq_free(h->xe_src); eq_free(h->xe_dst); eq_free(h->xe_vec);
+        ADF_TRY(eq_alloc(&h->xe_src, (size_t)num_edges)); ADF_TRY(eq_alloc(&h->xe_dst, (size_t)num_edges));
+        ADF_TRY(eq_alloc(&h->xe_vec, (size_t)num_edges * 3));
+        h->xe_cap = num_edges;
+    }
+    ADF_HIP_CHECK(hipMemcpyAsync(h->xe_src, src, sizeof(int32_t) * num_edges, hipMemcpyDeviceToDevice, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->xe_dst, dst, sizeof(int32_t) * num_edges, hipMemcpyDeviceToDevice, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->xe_vec, vec, sizeof(float) * 3 * num_edges, hipMemcpyDeviceToDevice, s));
+    h->ext_graph = true; h->E_ext = num_edges; h->maxdeg = max_in_degree;
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, const int32_t* mov_idx, const int32_t* mov_off) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    if (moving && (!mov_idx || !mov_off)) { adf_set_error("eqv2_set_moving: need mov_idx and mov_off"); return ADF_EINVAL; }
+    h->moving = moving; h->mov_idx = moving ? mov_idx : nullptr; h->mov_off = moving ? mov_off : nullptr;
+    h->cache_valid = false;
+    return ADF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- dense product dispatch
+int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
+                float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s) {
+    (void)h;
+    return eq_gemm_f32(A, lda, amap, W->w, use_bias ? W->b : nullptr, Cm, ldc, cmap, M, W->out, W->in, act, accumulate, s);
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+struct eq_chunk_bufs {
+    float *radh, *radh2, *rad, *alpha, *y0, *z0;
+    float* m[EQ_MAX_M + 1];
+    float* y[EQ_MAX_M + 1];
+    float* mb[EQ_MAX_M + 1];
+    float* z[EQ_MAX_M + 1];
+};
+
+static void eq_carve(const adf_eqv2* h, long long Eub, eq_chunk_bufs* b) {
+    const eq_dims& d = h->d;
+    float* p = h->arena;
+    auto take = [&](size_t n) { float* q = p; p += (n + 3) / 4 * 4; return q; };
+    const size_t extra = (size_t)d.NH * d.A + d.Hd;
+    b->radh = take((size_t)Eub * d.EC); b->radh2 = take((size_t)Eub * d.EC);
+    b->rad = take((size_t)Eub * d.RW * 2 * d.C);
+    b->alpha = take((size_t)Eub * d.NH);
+    for (int m = 0; m <= d.M; ++m) {
+        const size_t nm = d.L - m + 1, rows = m == 0 ? Eub : 2 * Eub;
+        b->m[m] = take(rows * nm * 2 * d.C);
+        b->y[m] = take(rows * (m == 0 ? extra + nm * d.Hd : 2 * nm * d.Hd));
+        b->mb[m] = take(rows * nm * d.Hd);
+        b->z[m] = take(rows * (m == 0 ? nm * d.HV : 2 * nm * d.HV));
+    }
+    b->y0 = b->y[0]; b->z0 = b->z[0];
+}
+
+// RadialFunction on the edges of targets [n0, n1): out [Eub, r->l6.out]
+static int32_t eq_radial(adf_eqv2* h, const eq_radial* r, const float* semb, const float* temb, const int32_t* Z, int n0,
+                         int n1, long long Eub, eq_chunk_bufs* b, float* out, int N, hipStream_t s) {
+    const eq_dims& d = h->d;
+    eq_prof_scope ps(h, EQ_PROF_RADIAL, s);
+    ADF_TRY(eq_launch_radial_pre(h, r, semb, temb, Z, n0, n1, b->radh, N, s));
+    ADF_TRY(eq_launch_ln_silu(b->radh, r->ln1_w, r->ln1_b, Eub, d.EC, s));
+    ADF_TRY(eq_gemm(h, b->radh, d.EC, nullptr, &r->l3, true, b->radh2, d.EC, nullptr, Eub, 0, false, s));
+    ADF_TRY(eq_launch_ln_silu(b->radh2, r->ln4_w, r->ln4_b, Eub, d.EC, s));
+    ADF_TRY(eq_gemm(h, b->radh2, d.EC, nullptr, &r->l6, true, out, r->l6.out, nullptr, Eub, 0, false, s));
+    return ADF_OK;
+}
+
+// SO2EquivariantGraphAttention up to (not including) the final SO3 linear: agg [N, S, HV] (or [N, 3, HV] when only_l1)
+static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, const int32_t* Z, int N, float* agg, bool only_l1,
+                            hipStream_t s) {
+    const eq_dims& d = h->d;
+    const int extra = d.NH * d.A + d.Hd;
+    for (int n0 = 0; n0 < N; n0 += (int)h->chunk_nodes) {
+        const int n1 = (int)((n0 + h->chunk_nodes < N) ? n0 + h->chunk_nodes : N);
+        const long long Eub = (long long)(n1 - n0) * (h->ext_graph ? h->maxdeg : h->hp.max_neighbors);
+        eq_chunk_bufs b;
+        eq_carve(h, Eub, &b);
+        ADF_TRY(eq_radial(h, &at->rad, at->src_emb, at->dst_emb, Z, n0, n1, Eub, &b, b.rad, N, s));
+        { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_in(h, y, b.rad, n0, n1, b.m, s)); }
+        {
+            eq_prof_scope ps(h, EQ_PROF_CONV, s);
+            ADF_TRY(eq_gemm(h, b.m[0], at->c1_m0.in, nullptr, &at->c1_m0, true, b.y[0], at->c1_m0.out, nullptr, Eub, 0, false, s));
+            for (int m = 1; m <= d.M; ++m)
+                ADF_TRY(eq_gemm(h, b.m[m], at->c1_m[m - 1].in, nullptr, &at->c1_m[m - 1], false, b.y[m], at->c1_m[m - 1].out,
+                                nullptr, 2 * Eub, 0, false, s));
+        }
+        { eq_prof_scope ps(h, EQ_PROF_ATTN, s); ADF_TRY(eq_launch_alpha(h, at, b.y[0], at->c1_m0.out, n0, n1, b.alpha, s)); }
+        { eq_prof_scope ps(h, EQ_PROF_S2ACT, s); ADF_TRY(eq_launch_s2act(h, b.y[0], b.y, extra, d.NH * d.A, n0, n1, b.mb, s)); }
+        {
+            eq_prof_scope ps(h, EQ_PROF_CONV, s);
+            ADF_TRY(eq_gemm(h, b.mb[0], at->c2_m0.in, nullptr, &at->c2_m0, true, b.z[0], at->c2_m0.out, nullptr, Eub, 0, false, s));
+            for (int m = 1; m <= d.M; ++m)
+                ADF_TRY(eq_gemm(h, b.mb[m], at->c2_m[m - 1].in, nullptr, &at->c2_m[m - 1], false, b.z[m], at->c2_m[m - 1].out,
+                                nullptr, 2 * Eub, 0, false, s));
+        }
+        { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_out(h, b.z, b.alpha, n0, n1, agg, only_l1, s)); }
+    }
+    return ADF_OK;
+}
+
+// SO3_LinearV2 (so3.py:694-745): one weight matrix per degree, bias on l = 0; in [N, S, cin] -> out [N, S, cout]
+static int32_t eq_so3_linear(adf_eqv2* h, const eq_lin* per_l, const float* in, int cin, float* out, int cout, int N,
+                             bool accumulate, hipStream_t s) {
+    const eq_dims& d = h->d;
+    for (int l = 0; l <= d.L; ++l) {
+        const int P = 2 * l + 1;
+        eq_rowmap am = {(long long)d.S * cin, P, cin}, cm = {(long long)d.S * cout, P, cout};
+        ADF_TRY(eq_gemm(h, in + (size_t)l * l * cin, cin, &am, &per_l[l], l == 0, out + (size_t)l * l * cout, cout, &cm,
+                        (long long)N * P, 0, accumulate, s));
+    }
+    return ADF_OK;
+}
+
+static int32_t eq_check_batch(const adf_eqv2* h, const adf_batch* b) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    if (!b || b->num_atoms <= 0 || b->num_systems <= 0 || !b->pos || !b->cell || !b->atomic_numbers || !b->batch || !b->atom_offset) {
+        adf_set_error("eqv2: incomplete batch descriptor");
+        return ADF_EINVAL;
+    }
+    if (!h->weights_set || !h->consts_set) { adf_set_error("eqv2: set_constants / set_weights first"); return ADF_EINVAL; }
+    return ADF_OK;
+}
+
+static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float* f2, float* x_blocks, hipStream_t s) {
+    const eq_dims& d = h->d;
+    const int N = b->num_atoms, B = b->num_systems;
+    ADF_TRY(eq_ensure_capacity(h, N, B, h->ext_graph ? h->E_ext : 0));
+    const int32_t* Z = b->atomic_numbers;
+    {
+        eq_prof_scope ps(h, EQ_PROF_GRAPH, s);
+        if (h->ext_graph) {
+            ADF_HIP_CHECK(hipMemcpyAsync(h->e_src, h->xe_src, sizeof(int32_t) * h->E_ext, hipMemcpyDeviceToDevice, s));
+            ADF_HIP_CHECK(hipMemcpyAsync(h->e_dst, h->xe_dst, sizeof(int32_t) * h->E_ext, hipMemcpyDeviceToDevice, s));
+            ADF_HIP_CHECK(hipMemcpyAsync(h->e_vec, h->xe_vec, sizeof(float) * 3 * h->E_ext, hipMemcpyDeviceToDevice, s));
+            ADF_TRY(eq_launch_eptr_from_dst(h, N, h->E_ext, s));
+        } else {
+            ADF_TRY(eq_launch_edges_from_topk(h, b, s));
+        }
+        ADF_TRY(eq_launch_wigner(h, N, s));
+    }
+    h->lastN = N;
+    const size_t xs = (size_t)N * d.S * d.C;
+    // node embedding + edge-degree embedding (equiformer_v2_denoising.py:232-285)
+    for (int n0 = 0; n0 < N; n0 += (int)h->chunk_nodes) {
+        const int n1 = (int)((n0 + h->chunk_nodes < N) ? n0 + h->chunk_nodes : N);
+        const long long Eub = (long long)(n1 - n0) * (h->ext_graph ? h->maxdeg : h->hp.max_neighbors);
+        eq_chunk_bufs cb;
+        eq_carve(h, Eub, &cb);
+        ADF_TRY(eq_radial(h, &h->ed_rad, h->ed_src_emb, h->ed_dst_emb, Z, n0, n1, Eub, &cb, cb.rad, N, s));
+        eq_prof_scope ps(h, EQ_PROF_ROTATE, s);
+        ADF_TRY(eq_launch_edge_degree(h, cb.rad, Z, n0, n1, h->x, s));
+    }
+    if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks, h->x, xs * 4, hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < h->hp.num_layers; ++i) {
+        const eq_block& bk = h->blk[i];
+        // x = x + ga(norm_1(x))   (transformer_block.py:650-700; drop path / dropout are identity in eval mode)
+        { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &bk.n1, h->x, h->y, N, s)); }
+        ADF_TRY(eq_attention(h, &bk.ga, h->y, Z, N, h->agg, false, s));
+        { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_so3_linear(h, bk.ga.proj_l, h->agg, d.HV, h->x, d.C, N, true, s)); }
+        // x = x + ffn(norm_2(x))
+        { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &bk.n2, h->x, h->y, N, s)); }
+        {
+            eq_prof_scope ps(h, EQ_PROF_FFN, s);
+            const eq_ffn& f = bk.ffn;
+            // scalar gate from the l = 0 row of every node (row stride S*C)
+            ADF_TRY(eq_gemm(h, h->y, d.S * d.C, nullptr, &f.scalar, true, h->gate, d.F, nullptr, N, 2, false, s));
+            ADF_TRY(eq_so3_linear(h, f.l1, h->y, d.C, h->h1, d.F, N, false, s));
+            for (int n0 = 0; n0 < N; n0 += (int)h->chunk_nodes) {
+                const int n1 = (int)((n0 + h->chunk_nodes < N) ? n0 + h->chunk_nodes : N);
+                const long long rows = (long long)(n1 - n0) * d.G;
+                float* ga = h->garena;
+                float* gb = h->garena + (size_t)h->chunk_nodes * d.G * d.F;
+                ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, s));
+                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g0, false, gb, d.F, nullptr, rows, 2, false, s));
+                ADF_TRY(eq_gemm(h, gb, d.F, nullptr, &f.g2, false, ga, d.F, nullptr, rows, 2, false, s));
+                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g4, false, gb, d.F, nullptr, rows, 0, false, s));
+                ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
+            }
+            ADF_TRY(eq_so3_linear(h, f.l2, h->h2, d.F, h->x, d.C, N, true, s));
+        }
+        if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks + (size_t)(i + 1) * xs, h->x, xs * 4, hipMemcpyDeviceToDevice, s));
+    }
+    { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &h->final_norm, h->x, h->y, N, s)); }
+    for (int k = 0; k < 2; ++k) {
+        float* f = k == 0 ? f1 : f2;
+        if (!f) continue;
+        ADF_TRY(eq_attention(h, &h->force[k], h->y, Z, N, h->agg, true, s));
+        eq_prof_scope ps(h, EQ_PROF_NODE, s);
+        ADF_TRY(eq_launch_force_out(h, &h->force[k], h->agg, N, f, s));
+    }
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_forward(adf_eqv2_t h, const adf_batch* b, float* f1, float* f2, float* x_blocks, void* stream) {
+    ADF_TRY(eq_check_batch(h, b));
+    if (!f1) { adf_set_error("eqv2_forward: f1 is null"); return ADF_EINVAL; }
+    return eq_forward_impl(h, b, f1, f2, x_blocks, (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_eqv2_check_flags(adf_eqv2_t h, void* stream) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    int32_t fl[EQ_NFLAGS];
+    ADF_HIP_CHECK(hipMemcpyAsync(fl, h->flags, sizeof(fl), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    bool any = false;
+    for (int i = 0; i < EQ_NFLAGS; ++i) any = any || fl[i];
+    if (any) ADF_HIP_CHECK(hipMemsetAsync(h->flags, 0, sizeof(fl), s));
+    if (fl[0]) { adf_set_error("eqv2 graph: more in-cutoff candidates around one atom than the search holds"); return ADF_EOVERFLOW; }
+    if (fl[2]) { adf_set_error("eqv2 graph: edge capacity exceeded"); return ADF_EOVERFLOW; }
+    if (fl[3]) { adf_set_error("eqv2: more than 128 incoming edges on one atom"); return ADF_EOVERFLOW; }
+    if (fl[4]) { adf_set_error("eqv2: atomic number outside the embedding / radius tables"); return ADF_EINVAL; }
+    if (fl[1]) { adf_set_error("An image has no neighbors"); return ADF_ENONEIGHBOR; }
+    return ADF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stepper on this handle
+extern "C" int32_t adf_eqv2_init_placement(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                                           const float* noise, void* stream) {
+    ADF_TRY(eq_check_batch(h, b));
+    if (!pos || !tags || !noise) { adf_set_error("null argument"); return ADF_EINVAL; }
+    return adf_stepper_init(b, pos, tags, noise, (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_eqv2_sde_step(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                                     const float* f1, const float* f2, const adf_step_coef* coef,
+                                     const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr, const float* z_rot,
+                                     int32_t early_stop_count, int32_t* state, float* dcom, float* drot, void* stream) {
+    ADF_TRY(eq_check_batch(h, b));
+    if (!pos || !tags || !f1 || !f2 || (!coef && !coefs_dev) || !state) { adf_set_error("null argument"); return ADF_EINVAL; }
+    if (!coef && num_steps <= 0) { adf_set_error("num_steps must be positive"); return ADF_EINVAL; }
+    ADF_TRY(eq_ensure_capacity(h, b->num_atoms, b->num_systems, h->ext_graph ? h->E_ext : 0));
+    eq_prof_scope ps(h, EQ_PROF_STEPPER, (hipStream_t)stream);
+    return adf_stepper_step(h->sys, b, pos, tags, fixed, f1, f2, coef, coef ? nullptr : coefs_dev, num_steps, z_tr, z_rot,
+                            early_stop_count, state, dcom, drot, (hipStream_t)stream);
+}
+
+extern "C" int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                                   const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
+                                   const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
+                                   float* f1, float* f2, void* stream) {
+    ADF_TRY(eq_check_batch(h, b));
+    if (num_steps <= 0 || !f1 || !f2 || !state || !coefs_dev || !pos || !tags) { adf_set_error("eqv2_sample: bad argument"); return ADF_EINVAL; }
+    if ((z_tr_all == nullptr) != (z_rot_all == nullptr)) { adf_set_error("eqv2_sample: need both noise tables or none"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t zs = (size_t)b->num_systems * 3;
+    for (int t = 0; t < num_steps; ++t) {
+        ADF_TRY(eq_forward_impl(h, b, f1, f2, nullptr, s));
+        ADF_TRY(adf_eqv2_sde_step(h, b, pos, tags, fixed, f1, f2, nullptr, coefs_dev, num_steps,
+                                  z_tr_all ? z_tr_all + t * zs : nullptr, z_rot_all ? z_rot_all + t * zs : nullptr,
+                                  early_stop_count, state, nullptr, nullptr, stream));
+        if (early_stop_count > 0 && poll_every > 0 && (t % poll_every) == poll_every - 1 && t + 1 < num_steps) {
+            int32_t frozen = 0;
+            ADF_HIP_CHECK(hipMemcpyAsync(&frozen, state + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            ADF_HIP_CHECK(hipStreamSynchronize(s));
+            if (frozen) break;
+        }
+    }
+    return ADF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- counters / profile
+extern "C" int32_t adf_eqv2_get_counters(adf_eqv2_t h, adf_eqv2_counters* out, void* stream) {
+    if (!h || !out || h->lastN <= 0) { adf_set_error("eqv2: no forward has run"); return ADF_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    const eq_dims& d = h->d;
+    int32_t e = 0;
+    ADF_HIP_CHECK(hipMemcpyAsync(&e, h->eptr + h->lastN, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t E = e, N = h->lastN;
+    const int64_t extra = (int64_t)d.NH * d.A + d.Hd;
+    int64_t conv1 = (int64_t)(d.L + 1) * 2 * d.C * (extra + (int64_t)(d.L + 1) * d.Hd);
+    int64_t conv2 = (int64_t)(d.L + 1) * d.Hd * (int64_t)(d.L + 1) * d.HV;
+    for (int m = 1; m <= d.M; ++m) {
+        const int64_t nm = d.L - m + 1;
+        conv1 += 2 * (nm * 2 * d.C) * (2 * nm * d.Hd);
+        conv2 += 2 * (nm * d.Hd) * (2 * nm * d.HV);
+    }
+    const int64_t radial = (int64_t)d.EC * (2 * d.EC) + (int64_t)d.EC * d.EC + (int64_t)d.EC * d.RW * 2 * d.C;
+    const int64_t s2 = 2ll * d.G * d.Sr * d.Hd;
+    const int64_t rot = (int64_t)d.DR * (2 * d.C + d.HV);
+    const int64_t per_edge_block = conv1 + conv2 + radial + s2 + rot;
+    const int64_t per_node_block = (int64_t)d.S * d.HV * d.C + (int64_t)d.C * d.F + 2ll * d.S * d.C * d.F + 2ll * d.G * d.S * d.F +
+                                   3ll * d.G * d.F * d.F;
+    const int64_t blocks = h->hp.num_layers;
+    const int64_t macs = E * per_edge_block * (blocks + 2) + N * per_node_block * blocks;
+    out->num_edges = E; out->num_atoms = N;
+    out->dense_flops = 2 * macs;
+    out->conv_flops = 2 * E * (conv1 + conv2) * (blocks + 2);
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_profile_enable(adf_eqv2_t h, int32_t on) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    h->prof_on = on != 0;
+    h->prof_used = 0;
+    h->prof_cat->clear();
+    return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_profile_read(adf_eqv2_t h, float* ms, int64_t* count, void* stream) {
+    if (!h || !ms || !count) { adf_set_error("null argument"); return ADF_EINVAL; }
+    ADF_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < EQ_PROF_NCAT; ++i) { ms[i] = 0.f; count[i] = 0; }
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, (*h->prof_ev)[i], (*h->prof_ev)[i + 1]) == hipSuccess) {
+            const int c = (*h->prof_cat)[i / 2];
+            ms[c] += t; count[c] += 1;
+        }
+    }
+    h->prof_used = 0;
+    h->prof_cat->clear();
+    return ADF_OK;
+}

@@ -1,0 +1,831 @@
+// Edge- and node-side kernels of the EquiformerV2 denoiser (everything that is not a plain dense product).
+//
+// Reference (adsorbdiff/models/equiformer_v2/): edge frames edge_rot_mat.py:6-63, Wigner rows so3.py:493-531 +
+// wigner.py:16-40, rotate in / out so3.py:493-506, SO(2) convolution bookkeeping so2_ops.py:158-262, separable S2
+// activation activation.py:155-202, attention weights transformer_block.py:312-345, norm layer_norm.py:129-250,
+// edge-degree embedding input_block.py:84-138, grid MLP transformer_block.py:497-531.
+//
+// Layouts.  Node features [N, S, C] degree-major like the reference (S = (L+1)^2).  Edges are grouped by TARGET atom
+// (CSR eptr[N+1]); an edge keeps, for every degree l, only the rows |m'| <= min(l, M) of its Wigner matrix D_l (the
+// rows an SO(2) convolution reads and the columns the rotation back needs): DR floats per edge, degree l at d_off[l],
+// row-major [2 min(l,M)+1][2l+1].  In an edge's frame the |m| <= M coefficients are kept order-major ("m-major"):
+// m = 0 for l = 0..L, then per m the +m entries for l = m..L and the -m entries; the operands of the per-order dense
+// maps are separate buffers: order 0 [E, (L+1) c], order m >= 1 [2E, (L-m+1) c] with row 2e = +m, row 2e+1 = -m.
+// A chunk of targets [n0, n1) is processed at a time; its edges are [eptr[n0], eptr[n1]) and every edge buffer is
+// indexed by e - eptr[n0].
+#include <hipcub/hipcub.hpp>
+
+#include "eqv2.h"
+#include "graph.h"
+
+#define EQ_FOR_L(L_, MACRO) \
+    switch (L_) {           \
+        case 1: MACRO(1); break; \
+        case 2: MACRO(2); break; \
+        case 3: MACRO(3); break; \
+        case 4: MACRO(4); break; \
+        case 5: MACRO(5); break; \
+        case 6: MACRO(6); break; \
+        default: adf_set_error("eqv2: lmax %d not instantiated (1..6)", L_); return ADF_EINVAL; \
+    }
+
+__device__ __forceinline__ float eq_silu(float x) { return x / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float eq_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// sum over a workgroup of up to 1024 threads; every thread gets the result
+__device__ __forceinline__ float eq_block_sum(float v, float* red) {
+    v = eq_wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------ graph -> edges
+__global__ void eq_edges_kernel(GraphParams p, const int32_t* __restrict__ eptr, int32_t* __restrict__ e_src,
+                                int32_t* __restrict__ e_dst, float* __restrict__ e_vec, long long capE, int32_t* flags) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(t / p.K);
+    const int k = (int)(t - (long long)i * p.K);
+    if (i >= p.N || k >= p.nbr_cnt[i]) return;
+    const int j = p.nbr_src[(size_t)i * p.K + k];
+    const int c = p.nbr_shift[(size_t)i * p.K + k];
+    float sa, sb, sc;
+    decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
+    const float* cl = p.cell + 9 * p.batch[i];
+    // shift (row vector) . cell, then pos[j] - pos[i] + offset   (utils.py:529-533)
+    const float ox = __fadd_rn(__fadd_rn(__fmul_rn(sa, cl[0]), __fmul_rn(sb, cl[3])), __fmul_rn(sc, cl[6]));
+    const float oy = __fadd_rn(__fadd_rn(__fmul_rn(sa, cl[1]), __fmul_rn(sb, cl[4])), __fmul_rn(sc, cl[7]));
+    const float oz = __fadd_rn(__fadd_rn(__fmul_rn(sa, cl[2]), __fmul_rn(sb, cl[5])), __fmul_rn(sc, cl[8]));
+    const long long e = (long long)eptr[i] + k;
+    if (e >= capE) { atomicExch(&flags[2], 1); return; }
+    e_src[e] = j;
+    e_dst[e] = i;
+    e_vec[3 * e] = __fadd_rn(__fsub_rn(p.pos[3 * j], p.pos[3 * i]), ox);
+    e_vec[3 * e + 1] = __fadd_rn(__fsub_rn(p.pos[3 * j + 1], p.pos[3 * i + 1]), oy);
+    e_vec[3 * e + 2] = __fadd_rn(__fsub_rn(p.pos[3 * j + 2], p.pos[3 * i + 2]), oz);
+}
+
+__global__ void eq_flag_images_kernel(const int32_t* img_cnt, int B, int32_t* flags) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B && img_cnt[t] == 0) atomicExch(&flags[1], 1);
+}
+
+int32_t eq_launch_edges_from_topk(adf_eqv2* h, const adf_batch* b, hipStream_t s) {
+    const int N = b->num_atoms, B = b->num_systems, K = h->hp.max_neighbors;
+    GraphParams p;
+    p.pos = b->pos; p.cell = b->cell; p.batch = b->batch; p.atom_offset = b->atom_offset;
+    p.r0 = b->reps[0]; p.r1 = b->reps[1]; p.r2 = b->reps[2];
+    p.rc2 = h->hp.max_radius * h->hp.max_radius;
+    p.K = K; p.N = N;
+    p.nbr_cnt = h->nbr_cnt; p.nbr_src = h->nbr_src; p.nbr_shift = h->nbr_shift;
+    p.img_cnt = h->img_cnt; p.flags = h->flags;
+    p.moving = h->moving; p.mov_idx = h->mov_idx; p.mov_off = h->mov_off;
+    p.cache_d2 = h->cache_d2; p.cache_cid = h->cache_cid; p.cache_cnt = h->cache_cnt;
+    ADF_HIP_CHECK(hipMemsetAsync(h->img_cnt, 0, sizeof(int32_t) * B, s));
+    int mode = 0;
+    if (h->moving) { mode = h->cache_valid ? 2 : 1; h->cache_valid = true; }
+    ADF_TRY(adf_topk_launch(p, mode, s));
+    size_t tmp = h->scan_tmp_bytes;
+    // eptr[i] = sum_{i' < i} nbr_cnt[i'], eptr[N] = E   (nbr_cnt[N] is kept 0)
+    ADF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(h->scan_tmp, tmp, h->nbr_cnt, h->eptr, N + 1, s));
+    hipLaunchKernelGGL(eq_flag_images_kernel, dim3((B + 255) / 256), dim3(256), 0, s, h->img_cnt, B, h->flags);
+    const long long slots = (long long)N * K;
+    hipLaunchKernelGGL(eq_edges_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, p, h->eptr, h->e_src,
+                       h->e_dst, h->e_vec, (long long)h->capE, h->flags);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// eptr from a target-sorted edge list: eptr[i] = first edge with dst >= i
+__global__ void eq_eptr_kernel(const int32_t* __restrict__ dst, long long E, int N, int32_t* __restrict__ eptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    long long lo = 0, hi = E;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (dst[mid] < i) lo = mid + 1; else hi = mid;
+    }
+    eptr[i] = (int32_t)lo;
+}
+
+int32_t eq_launch_eptr_from_dst(adf_eqv2* h, int N, int64_t E, hipStream_t s) {
+    hipLaunchKernelGGL(eq_eptr_kernel, dim3((N + 256) / 256), dim3(256), 0, s, h->e_dst, (long long)E, N, h->eptr);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Wigner rows
+// One wave per edge.  Frame: R = Rx(b) Ry(g) with Ry(g) turning the edge direction n into the y-z plane and Rx(b)
+// turning it onto +y, i.e. (cos g, sin g) = (n_z, -n_x) / rho, (cos b, sin b) = (n_y, -rho), rho = |(n_x, n_z)| — one
+// of the frames "second row = edge direction" of edge_rot_mat.py:51-63 (the reference rolls it at random about the
+// edge; the outputs do not depend on the roll).  D_l(R) = J_l Z_l(b) J_l Z_l(g) (wigner.py:16-40 with alpha = 0), Z the
+// rotation about y: cos(f_i t) on the diagonal, sin(f_i t) on the anti-diagonal, f_i = l - i.  cos / sin of the
+// multiples come from the Chebyshev recurrence on (cos, sin) of the frame itself: no inverse trigonometric function.
+__global__ __launch_bounds__(256) void eq_wigner_kernel(const float* __restrict__ e_vec, const int32_t* __restrict__ eptr,
+                                                        int N, const float* __restrict__ jd, eq_dims d,
+                                                        float* __restrict__ wig) {
+    __shared__ float Jl[1024];
+    __shared__ float trig[4][4][EQ_MAX_L + 2];
+    extern __shared__ float Pdyn[];  // [4][(2M+1) * (2L+1)]: rows l-ml..l+ml of J Z(b) J
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nJ = d.j_off[d.L + 1];
+    for (int t = threadIdx.x; t < nJ; t += 256) Jl[t] = jd[t];
+    __syncthreads();
+    const long long e = (long long)blockIdx.x * 4 + w;
+    const long long E = eptr[N];
+    if (e >= E) return;
+    float* P = Pdyn + w * ((2 * d.M + 1) * (2 * d.L + 1));
+    float nx = e_vec[3 * e], ny = e_vec[3 * e + 1], nz = e_vec[3 * e + 2];
+    const float inv = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+    nx *= inv; ny *= inv; nz *= inv;
+    const float rho = sqrtf(nx * nx + nz * nz);
+    float cg = 1.f, sg = 0.f;
+    if (rho > 1e-20f) { cg = nz / rho; sg = -nx / rho; }
+    const float cb = ny, sb = -rho;
+    if (lane <= d.L) {
+        float c0 = 1.f, s0 = 0.f, c1 = cb, s1 = sb, g0 = 1.f, h0 = 0.f, g1 = cg, h1 = sg;
+        for (int k = 1; k < lane; ++k) {
+            const float c2 = 2.f * cb * c1 - c0, s2 = 2.f * cb * s1 - s0;
+            c0 = c1; s0 = s1; c1 = c2; s1 = s2;
+            const float g2 = 2.f * cg * g1 - g0, h2 = 2.f * cg * h1 - h0;
+            g0 = g1; h0 = h1; g1 = g2; h1 = h2;
+        }
+        trig[w][0][lane] = lane == 0 ? 1.f : c1;
+        trig[w][1][lane] = lane == 0 ? 0.f : s1;
+        trig[w][2][lane] = lane == 0 ? 1.f : g1;
+        trig[w][3][lane] = lane == 0 ? 0.f : h1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* out = wig + (size_t)e * d.DR;
+    for (int l = 0; l <= d.L; ++l) {
+        const int n = 2 * l + 1, ml = min(l, d.M), nr = 2 * ml + 1;
+        const float* J = Jl + d.j_off[l];
+        for (int t = lane; t < nr * n; t += 64) {
+            const int ri = t / n, dc = t - ri * n;
+            const int i = l - ml + ri;
+            float acc = 0.f;
+            for (int b = 0; b < n; ++b) {
+                const int f = l - b, af = f < 0 ? -f : f;
+                const float cbf = trig[w][0][af], sbf = f < 0 ? -trig[w][1][af] : trig[w][1][af];
+                acc += J[i * n + b] * (cbf * J[b * n + dc] + sbf * J[(n - 1 - b) * n + dc]);
+            }
+            P[t] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < nr * n; t += 64) {
+            const int ri = t / n, j = t - ri * n;
+            const int f = l - j, af = f < 0 ? -f : f;
+            const float cgf = trig[w][2][af], sgf = f < 0 ? -trig[w][3][af] : trig[w][3][af];
+            out[d.d_off[l] + t] = P[ri * n + j] * cgf - P[ri * n + (n - 1 - j)] * sgf;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+static inline long long eq_edge_bound(const adf_eqv2* h, long long nodes) {
+    return h->ext_graph ? nodes * (long long)h->maxdeg : nodes * (long long)h->hp.max_neighbors;
+}
+
+int32_t eq_launch_wigner(adf_eqv2* h, int N, hipStream_t s) {
+    const long long Eub = h->ext_graph ? h->E_ext : (long long)N * h->hp.max_neighbors;
+    if (Eub <= 0) return ADF_OK;
+    const eq_dims& d = h->d;
+    const size_t dyn = sizeof(float) * 4 * (2 * d.M + 1) * (2 * d.L + 1);
+    hipLaunchKernelGGL(eq_wigner_kernel, dim3((unsigned)((Eub + 3) / 4)), dim3(256), dyn, s, h->e_vec, h->eptr, N, h->jd,
+                       d, h->wig);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ norm
+// layer_norm.py:129-250: LayerNorm over the channels of l = 0; for l > 0 one scale per node from the degree-balanced
+// mean square (every degree weighs 1/L, every order of a degree 1/(2l+1)), times a per-degree, per-channel weight.
+__global__ void eq_norm_kernel(const float* __restrict__ x, const float* __restrict__ aff, const float* __restrict__ w0,
+                               const float* __restrict__ b0, float* __restrict__ y, int N, eq_dims d, float eps) {
+    __shared__ float red[16];
+    const int n = blockIdx.x, c = threadIdx.x;
+    const bool on = c < d.C;
+    const float* xr = x + (size_t)n * d.S * d.C;
+    float* yr = y + (size_t)n * d.S * d.C;
+    const float v0 = on ? xr[c] : 0.f;
+    const float mean = eq_block_sum(v0, red) / d.C;
+    const float dv = on ? v0 - mean : 0.f;
+    const float var = eq_block_sum(dv * dv, red) / d.C;
+    if (on) yr[c] = dv * rsqrtf(var + eps) * w0[c] + b0[c];
+    float q = 0.f;
+    if (on) {
+        for (int l = 1; l <= d.L; ++l) {
+            const float wl = 1.0f / (float)(2 * l + 1) / (float)d.L;
+            float a = 0.f;
+            for (int s = l * l; s < (l + 1) * (l + 1); ++s) { const float t = xr[(size_t)s * d.C + c]; a += t * t; }
+            q += a * wl;
+        }
+    }
+    const float ms = eq_block_sum(q, red) / d.C;
+    const float sc = 1.0f / sqrtf(ms + eps);
+    if (on) {
+        for (int l = 1; l <= d.L; ++l) {
+            const float f = sc * aff[(size_t)(l - 1) * d.C + c];
+            for (int s = l * l; s < (l + 1) * (l + 1); ++s) yr[(size_t)s * d.C + c] = xr[(size_t)s * d.C + c] * f;
+        }
+    }
+}
+
+int32_t eq_launch_norm(const adf_eqv2* h, const eq_norm* nm, const float* x, float* y, int N, hipStream_t s) {
+    const int bd = (h->d.C + 63) / 64 * 64;
+    hipLaunchKernelGGL(eq_norm_kernel, dim3(N), dim3(bd), 0, s, x, nm->affine, nm->l0_w, nm->l0_b, y, N, h->d, 1e-5f);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ radial MLP, first layer
+// RadialFunction.net[0] on [Gaussian basis of (d - r[Z_src] - r[Z_dst]) | source embedding | target embedding]
+// (transformer_block.py:247-262, equiformer_v2_denoising.py:208-213, 267).  Only basis functions that do not underflow
+// to zero are visited (GaussianSmearing: exp(coeff (x - mu_k)^2), coeff = -0.5 / (2 delta)^2, equiformer_v2_oc20.py:
+// 41-62); with the reference's radii (tabulated in pm, subtracted from Angstrom) the window is empty on every edge.
+// w0t: [NB + 2 EC, EC] (transposed at set_weights so that the lanes of a wave read consecutive outputs).
+__global__ void eq_radial_pre_kernel(const float* __restrict__ e_vec, const int32_t* __restrict__ e_src,
+                                     const int32_t* __restrict__ e_dst, const int32_t* __restrict__ eptr,
+                                     const int32_t* __restrict__ Z, const float* __restrict__ radii,
+                                     const float* __restrict__ w0t, const float* __restrict__ b0,
+                                     const float* __restrict__ semb, const float* __restrict__ temb, int n0, int n1,
+                                     int EC, int NB, float rc, int max_elem, float* __restrict__ out, int32_t* flags) {
+    const long long e0 = eptr[n0];
+    const long long e = e0 + blockIdx.x;
+    if (e >= eptr[n1]) return;
+    const int j = threadIdx.x;
+    const int zs = Z[e_src[e]], zt = Z[e_dst[e]];
+    if (zs < 0 || zs >= max_elem || zt < 0 || zt >= max_elem || zs > 100 || zt > 100) {
+        if (j == 0) atomicExch(&flags[4], 1);
+        return;
+    }
+    const float vx = e_vec[3 * e], vy = e_vec[3 * e + 1], vz = e_vec[3 * e + 2];
+    const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float dd = dist - radii[zs] - radii[zt];
+    if (j >= EC) return;
+    float acc = b0[j];
+    const float delta = rc / (float)(NB - 1);
+    const float coeff = -0.5f / ((2.0f * delta) * (2.0f * delta));
+    if (!(dd == dd)) {
+        acc = dd;  // NaN radius (elements without a tabulated value): the reference's output is NaN too
+    } else {
+        const float tmax = sqrtf(104.0f / -coeff);
+        int k0 = (int)ceilf((dd - tmax) / delta), k1 = (int)floorf((dd + tmax) / delta);
+        k0 = max(k0, 0); k1 = min(k1, NB - 1);
+        for (int k = k0; k <= k1; ++k) {
+            const float t = dd - delta * (float)k;
+            acc += expf(coeff * t * t) * w0t[(size_t)k * EC + j];
+        }
+    }
+    const float* se = semb + (size_t)zs * EC;
+    const float* te = temb + (size_t)zt * EC;
+    const float* ws = w0t + (size_t)NB * EC;
+    const float* wt = ws + (size_t)EC * EC;
+    for (int q = 0; q < EC; ++q) acc += se[q] * ws[(size_t)q * EC + j];
+    for (int q = 0; q < EC; ++q) acc += te[q] * wt[(size_t)q * EC + j];
+    out[(size_t)(e - e0) * EC + j] = acc;
+}
+
+int32_t eq_launch_radial_pre(const adf_eqv2* h, const eq_radial* r, const float* src_emb, const float* dst_emb,
+                             const int32_t* Z, int n0, int n1, float* out, int N, hipStream_t s) {
+    const long long Eub = eq_edge_bound(h, n1 - n0);
+    if (Eub <= 0) return ADF_OK;
+    const int EC = h->d.EC;
+    hipLaunchKernelGGL(eq_radial_pre_kernel, dim3((unsigned)Eub), dim3((EC + 63) / 64 * 64), 0, s, h->e_vec, h->e_src,
+                       h->e_dst, h->eptr, Z, h->atom_radii, r->w0t, r->l0.b, src_emb, dst_emb, n0, n1, EC, h->d.NB,
+                       h->hp.max_radius, h->hp.max_num_elements, out, h->flags);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// LayerNorm (biased variance, eps 1e-5) followed by SiLU on rows of `width` floats, in place; one wave per row
+__global__ __launch_bounds__(256) void eq_ln_silu_kernel(float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, long long rows, int width) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float* xr = x + (size_t)r * width;
+    float sum = 0.f;
+    for (int c = lane; c < width; c += 64) sum += xr[c];
+    const float mean = eq_wave_sum(sum) / width;
+    float q = 0.f;
+    for (int c = lane; c < width; c += 64) { const float t = xr[c] - mean; q += t * t; }
+    const float rstd = rsqrtf(eq_wave_sum(q) / width + 1e-5f);
+    for (int c = lane; c < width; c += 64) xr[c] = eq_silu((xr[c] - mean) * rstd * w[c] + b[c]);
+}
+
+int32_t eq_launch_ln_silu(float* x, const float* w, const float* b, long long rows, int width, hipStream_t s) {
+    if (rows <= 0) return ADF_OK;
+    hipLaunchKernelGGL(eq_ln_silu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, w, b, rows, width);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ edge-degree embedding
+// input_block.py:84-138: the radial MLP gives the m = 0 coefficients (l = 0..L) of every edge in its own frame; they are
+// rotated back (row m' = 0 of D_l, with the m-truncation rescale), summed per target, divided by the average degree, and
+// added to the element embedding on l = 0.  One workgroup per target, thread = channel.
+template <int LT>
+__global__ void eq_edge_degree_kernel(const float* __restrict__ m0, const float* __restrict__ wig,
+                                      const int32_t* __restrict__ eptr, const int32_t* __restrict__ Z,
+                                      const float* __restrict__ emb, int n0, int n1, eq_dims d, float inv_avg,
+                                      int max_elem, float* __restrict__ x, int32_t* flags) {
+    const int n = n0 + blockIdx.x, c = threadIdx.x;
+    if (n >= n1 || c >= d.C) return;
+    const long long ebase = eptr[n0];
+    float acc[(LT + 1) * (LT + 1)];
+#pragma unroll
+    for (int s = 0; s < (LT + 1) * (LT + 1); ++s) acc[s] = 0.f;
+    for (long long e = eptr[n]; e < eptr[n + 1]; ++e) {
+        const float* D = wig + (size_t)e * d.DR;
+        const float* mr = m0 + (size_t)(e - ebase) * ((LT + 1) * d.C);
+#pragma unroll
+        for (int l = 0; l <= LT; ++l) {
+            const int ml = l < d.M ? l : d.M;
+            const float v = mr[l * d.C + c] * d.resc[l];
+            const float* Dr = D + d.d_off[l] + ml * (2 * l + 1);  // row m' = 0
+#pragma unroll
+            for (int m = 0; m < 2 * l + 1; ++m) acc[l * l + m] += Dr[m] * v;
+        }
+    }
+    const int z = Z[n];
+    if (z < 0 || z >= max_elem) { if (c == 0) atomicExch(&flags[4], 1); return; }
+    float* xr = x + (size_t)n * d.S * d.C;
+#pragma unroll
+    for (int s = 0; s < (LT + 1) * (LT + 1); ++s) xr[(size_t)s * d.C + c] = acc[s] * inv_avg + (s == 0 ? emb[(size_t)z * d.C + c] : 0.f);
+}
+
+int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int n0, int n1, float* x, hipStream_t s) {
+    if (n1 <= n0) return ADF_OK;
+    const int bd = (h->d.C + 63) / 64 * 64;
+#define EQ_ED(LT_) hipLaunchKernelGGL(eq_edge_degree_kernel<LT_>, dim3(n1 - n0), dim3(bd), 0, s, m0, h->wig, h->eptr, Z, \
+                                      h->sphere_emb, n0, n1, h->d, 1.0f / h->hp.avg_degree, h->hp.max_num_elements, x, h->flags)
+    EQ_FOR_L(h->d.L, EQ_ED)
+#undef EQ_ED
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ rotate in
+// so3.py:493-499 + so2_ops.py:188-213: [x_src | x_tgt] rotated into the edge's frame (rows |m'| <= M of D_l), multiplied
+// by the radial weights, written as the per-order operands of the first SO(2) convolution.  One workgroup per edge,
+// thread = one of the 2C input channels.
+struct eq_ptrs { float* p[EQ_MAX_M + 1]; };
+
+template <int LT>
+__global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __restrict__ rad, const float* __restrict__ wig,
+                                    const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src,
+                                    const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb) {
+    const long long ebase = eptr[n0];
+    const long long e = ebase + blockIdx.x;
+    if (e >= eptr[n1]) return;
+    const int c = threadIdx.x, C2 = 2 * d.C;
+    if (c >= C2) return;
+    const long long el = e - ebase;
+    const int node = c < d.C ? e_src[e] : e_dst[e];
+    const float* yr = y + (size_t)node * d.S * d.C + (c < d.C ? c : c - d.C);
+    const float* D = wig + (size_t)e * d.DR;
+    const float* rr = rad + (size_t)el * d.RW * C2;
+#pragma unroll
+    for (int l = 0; l <= LT; ++l) {
+        float v[2 * LT + 1];
+#pragma unroll
+        for (int m = 0; m < 2 * l + 1; ++m) v[m] = yr[(size_t)(l * l + m) * d.C];
+        const int ml = l < d.M ? l : d.M;
+        const float* Dl = D + d.d_off[l];
+        for (int ri = 0; ri < 2 * ml + 1; ++ri) {
+            float a = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2 * l + 1; ++m) a += Dl[ri * (2 * l + 1) + m] * v[m];
+            const int mp = ri - ml, am = mp < 0 ? -mp : mp;
+            const int nm = LT - am + 1;
+            a *= rr[(size_t)(d.rad_off[am] + (l - am)) * C2 + c];
+            const long long row = am == 0 ? el : 2 * el + (mp < 0 ? 1 : 0);
+            mb.p[am][(size_t)row * nm * C2 + (size_t)(l - am) * C2 + c] = a;
+        }
+    }
+}
+
+int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, int n0, int n1, float* const* mbuf,
+                            hipStream_t s) {
+    const long long Eub = eq_edge_bound(h, n1 - n0);
+    if (Eub <= 0) return ADF_OK;
+    eq_ptrs mb;
+    for (int m = 0; m <= h->d.M; ++m) mb.p[m] = mbuf[m];
+    const int bd = (2 * h->d.C + 63) / 64 * 64;
+#define EQ_RI(LT_) hipLaunchKernelGGL(eq_rotate_in_kernel<LT_>, dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
+                                      h->e_src, h->e_dst, n0, n1, h->d, mb)
+    EQ_FOR_L(h->d.L, EQ_RI)
+#undef EQ_RI
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// value of the m-major reduced coefficient r of an SO(2) convolution's output (so2_ops.py:52-66: the +m / -m pair mixes
+// like a complex product): y0 [E, ld0] (order 0 at column off0), ym[m] [2E, 2 nm cw]
+__device__ __forceinline__ float eq_conv_out(const float* __restrict__ y0, int ld0, int off0, const eq_ptrs& ym,
+                                             const eq_dims& d, long long el, int r, int cw, int c) {
+    const int m = d.r_m[r], l = d.r_l[r];
+    if (m == 0) return y0[(size_t)el * ld0 + off0 + l * cw + c];
+    const int nm = d.L - m + 1, half = nm * cw, W = 2 * half, q = (l - m) * cw + c;
+    const float* a = ym.p[m] + (size_t)(2 * el) * W;
+    if (d.r_sgn[r] == 0) return a[q] - a[W + half + q];
+    return a[W + q] + a[half + q];
+}
+
+// ------------------------------------------------------------------------------------------------ separable S2 activation
+// activation.py:176-202 on the hidden message of an attention block: the l = 0 output is SiLU of the extra scalar gate,
+// the l > 0 outputs go through the S2 grid: to_grid (res^2 x S_r), point-wise SiLU, from_grid.  First version: VALU,
+// thread = (edge, hidden channel), coefficients in registers, both matrices in LDS.
+template <int SRT>
+__global__ __launch_bounds__(256) void eq_s2act_kernel(const float* __restrict__ y0, int ld0, int off0, int gate_off,
+                                                       eq_ptrs ym, const int32_t* __restrict__ eptr, int n0, int n1,
+                                                       eq_dims d, const float* __restrict__ tg, const float* __restrict__ fg,
+                                                       eq_ptrs mb, int epb) {
+    extern __shared__ float lds[];  // T [G][SRT], F [G][SRT]
+    float* T = lds;
+    float* Fm = lds + (size_t)d.G * SRT;
+    for (int t = threadIdx.x; t < d.G * SRT; t += blockDim.x) {
+        const int p = t / SRT, r = t - p * SRT;
+        T[t] = r < d.Sr ? tg[(size_t)p * d.Sr + r] : 0.f;
+        Fm[t] = r < d.Sr ? fg[(size_t)p * d.Sr + r] : 0.f;
+    }
+    __syncthreads();
+    const long long ebase = eptr[n0];
+    const int sub = threadIdx.x / d.Hd, c = threadIdx.x - sub * d.Hd;
+    const long long el = (long long)blockIdx.x * epb + sub;
+    if (sub >= epb || ebase + el >= eptr[n1]) return;
+    float in[SRT], out[SRT];
+#pragma unroll
+    for (int r = 0; r < SRT; ++r) {
+        in[r] = r < d.Sr ? eq_conv_out(y0, ld0, off0, ym, d, el, r, d.Hd, c) : 0.f;
+        out[r] = 0.f;
+    }
+    for (int p = 0; p < d.G; ++p) {
+        const float* tp = T + p * SRT;
+        float g = 0.f;
+#pragma unroll
+        for (int r = 0; r < SRT; ++r) g += tp[r] * in[r];
+        const float sv = eq_silu(g);
+        const float* fp = Fm + p * SRT;
+#pragma unroll
+        for (int r = 0; r < SRT; ++r) out[r] += fp[r] * sv;
+    }
+    out[0] = eq_silu(y0[(size_t)el * ld0 + gate_off + c]);
+#pragma unroll
+    for (int r = 0; r < SRT; ++r) {
+        if (r < d.Sr) {
+            const int m = d.r_m[r], l = d.r_l[r], nm = d.L - m + 1;
+            const long long row = m == 0 ? el : 2 * el + d.r_sgn[r];
+            mb.p[m][(size_t)row * nm * d.Hd + (size_t)(l - m) * d.Hd + c] = out[r];
+        }
+    }
+}
+
+int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,
+                        float* const* mbp, hipStream_t s) {
+    const long long Eub = eq_edge_bound(h, n1 - n0);
+    if (Eub <= 0) return ADF_OK;
+    const eq_dims& d = h->d;
+    if (d.Hd > 256) { adf_set_error("eqv2: attn_hidden_channels > 256"); return ADF_EINVAL; }
+    eq_ptrs a, b;
+    for (int m = 0; m <= d.M; ++m) { a.p[m] = ym[m]; b.p[m] = mbp[m]; }
+    const int epb = 256 / d.Hd;
+    const int ld0 = extra + (d.L + 1) * d.Hd;
+    const unsigned grid = (unsigned)((Eub + epb - 1) / epb);
+    if (d.Sr <= 32) {
+        const size_t dyn = sizeof(float) * 2 * d.G * 32;
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_s2act_kernel<32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(eq_s2act_kernel<32>, dim3(grid), dim3(256), dyn, s, y0, ld0, extra, gate_off, a, h->eptr, n0, n1,
+                           d, h->to_red, h->from_red, b, epb);
+    } else if (d.Sr <= 49) {
+        const size_t dyn = sizeof(float) * 2 * d.G * 49;
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_s2act_kernel<49>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(eq_s2act_kernel<49>, dim3(grid), dim3(256), dyn, s, y0, ld0, extra, gate_off, a, h->eptr, n0, n1,
+                           d, h->to_red, h->from_red, b, epb);
+    } else {
+        adf_set_error("eqv2: more than 49 reduced coefficients");
+        return ADF_EINVAL;
+    }
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ attention weights
+// transformer_block.py:312-345: per head LayerNorm over the alpha channels, smooth leaky ReLU, dot with alpha_dot,
+// softmax over the edges that share a target (torch_geometric.utils.softmax: exp(a - max) / (sum + 1e-16)).
+// One workgroup per target; thread = (edge of the segment, head).
+#define EQ_MAXDEG 128
+__global__ __launch_bounds__(256) void eq_alpha_kernel(const float* __restrict__ y0, int ldy, const int32_t* __restrict__ eptr,
+                                                       int n0, int n1, const float* __restrict__ lnw,
+                                                       const float* __restrict__ lnb, const float* __restrict__ adot,
+                                                       int NH, int A, float* __restrict__ alpha, int32_t* flags) {
+    __shared__ float lg[EQ_MAXDEG * 16];
+    const int n = n0 + blockIdx.x;
+    if (n >= n1) return;
+    const long long ebase = eptr[n0], e0 = eptr[n];
+    int deg = (int)(eptr[n + 1] - e0);
+    if (deg > EQ_MAXDEG) { if (threadIdx.x == 0) atomicExch(&flags[3], 1); deg = EQ_MAXDEG; }
+    for (int t = threadIdx.x; t < deg * NH; t += blockDim.x) {
+        const int k = t / NH, hd = t - k * NH;
+        const float* v = y0 + (size_t)(e0 + k - ebase) * ldy + hd * A;
+        float sum = 0.f;
+        for (int a = 0; a < A; ++a) sum += v[a];
+        const float mean = sum / A;
+        float q = 0.f;
+        for (int a = 0; a < A; ++a) { const float u = v[a] - mean; q += u * u; }
+        const float rstd = rsqrtf(q / A + 1e-5f);
+        float acc = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float u = (v[a] - mean) * rstd * lnw[a] + lnb[a];
+            // SmoothLeakyReLU(0.2): (1 + a)/2 x + (1 - a)/2 x (2 sigmoid(x) - 1)   (activation.py:30-45)
+            const float sl = 0.6f * u + 0.4f * u * (2.0f / (1.0f + expf(-u)) - 1.0f);
+            acc += sl * adot[hd * A + a];
+        }
+        lg[t] = acc;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < deg * NH; t += blockDim.x) {
+        const int k = t / NH, hd = t - k * NH;
+        float mx = -3.0e38f;
+        for (int kk = 0; kk < deg; ++kk) mx = fmaxf(mx, lg[kk * NH + hd]);
+        float den = 0.f;
+        for (int kk = 0; kk < deg; ++kk) den += expf(lg[kk * NH + hd] - mx);
+        alpha[(size_t)(e0 + k - ebase) * NH + hd] = expf(lg[t] - mx) / (den + 1e-16f);
+    }
+}
+
+int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, int ldy, int n0, int n1, float* alpha,
+                        hipStream_t s) {
+    if (n1 <= n0) return ADF_OK;
+    if (h->d.NH > 16) { adf_set_error("eqv2: more than 16 heads"); return ADF_EINVAL; }
+    hipLaunchKernelGGL(eq_alpha_kernel, dim3(n1 - n0), dim3(256), 0, s, y0, ldy, h->eptr, n0, n1, at->alpha_ln_w,
+                       at->alpha_ln_b, at->alpha_dot, h->d.NH, h->d.A, alpha, h->flags);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ rotate out + aggregate
+// transformer_block.py:347-366 + so3.py:501-506: the value message of every edge, weighted per head, is rotated back
+// (D_l^T on the kept rows, with the m-truncation rescale) and summed over the edges of its target — one workgroup per
+// target, thread = value channel, the target's S coefficients in registers, edges in CSR order (run-to-run identical).
+// ONLY1: only the l = 1 coefficients (all a force block's projection reads), written as [N, 3, HV].
+template <int LT, bool ONLY1>
+__global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, const float* __restrict__ alpha,
+                                     const float* __restrict__ wig, const int32_t* __restrict__ eptr, int n0, int n1,
+                                     eq_dims d, float* __restrict__ agg) {
+    const int n = n0 + blockIdx.x, c = threadIdx.x;
+    if (n >= n1 || c >= d.HV) return;
+    const long long ebase = eptr[n0];
+    constexpr int NS = ONLY1 ? 3 : (LT + 1) * (LT + 1);
+    float acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+    const int hd = c / d.V;
+    const int ld0 = (d.L + 1) * d.HV;
+    for (long long e = eptr[n]; e < eptr[n + 1]; ++e) {
+        const long long el = e - ebase;
+        const float a = alpha[(size_t)el * d.NH + hd];
+        const float* D = wig + (size_t)e * d.DR;
+#pragma unroll
+        for (int l = (ONLY1 ? 1 : 0); l <= (ONLY1 ? 1 : LT); ++l) {
+            const int ml = l < d.M ? l : d.M;
+            const float* Dl = D + d.d_off[l];
+            const float sc = a * d.resc[l];
+            for (int ri = 0; ri < 2 * ml + 1; ++ri) {
+                const int mp = ri - ml, am = mp < 0 ? -mp : mp;
+                float v;
+                if (am == 0) {
+                    v = z0[(size_t)el * ld0 + l * d.HV + c];
+                } else {
+                    const int nm = d.L - am + 1, half = nm * d.HV, W = 2 * half, q = (l - am) * d.HV + c;
+                    const float* zr = zm.p[am] + (size_t)(2 * el) * W;
+                    v = mp > 0 ? zr[q] - zr[W + half + q] : zr[W + q] + zr[half + q];
+                }
+                v *= sc;
+#pragma unroll
+                for (int m = 0; m < 2 * l + 1; ++m) acc[(ONLY1 ? 0 : l * l) + m] += Dl[ri * (2 * l + 1) + m] * v;
+            }
+        }
+    }
+    float* out = agg + (size_t)n * NS * d.HV + c;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) out[(size_t)s * d.HV] = acc[s];
+}
+
+int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* alpha, int n0, int n1, float* agg,
+                             bool only_l1, hipStream_t s) {
+    if (n1 <= n0) return ADF_OK;
+    eq_ptrs zm;
+    for (int m = 0; m <= h->d.M; ++m) zm.p[m] = z[m];
+    const int bd = (h->d.HV + 63) / 64 * 64;
+#define EQ_RO(LT_)                                                                                                     \
+    if (only_l1)                                                                                                       \
+        hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, true>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
+                           h->eptr, n0, n1, h->d, agg);                                                                \
+    else                                                                                                               \
+        hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, false>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
+                           h->eptr, n0, n1, h->d, agg)
+    EQ_FOR_L(h->d.L, EQ_RO)
+#undef EQ_RO
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// l = 1 rows of a force block's SO3_LinearV2 with one output channel (so3.py:694-745; no bias above l = 0):
+// f[n, m] = sum_i agg3[n, m, i] * W[1, 0, i]; one wave per atom
+__global__ __launch_bounds__(256) void eq_force_out_kernel(const float* __restrict__ agg3, const float* __restrict__ w1,
+                                                           int N, int HV, float* __restrict__ f) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float* r = agg3 + (size_t)n * 3 * HV;
+    for (int i = lane; i < HV; i += 64) {
+        const float w = w1[i];
+        a0 += r[i] * w; a1 += r[HV + i] * w; a2 += r[2 * HV + i] * w;
+    }
+    a0 = eq_wave_sum(a0); a1 = eq_wave_sum(a1); a2 = eq_wave_sum(a2);
+    if (lane == 0) { f[3 * n] = a0; f[3 * n + 1] = a1; f[3 * n + 2] = a2; }
+}
+
+int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* agg3, int N, float* f, hipStream_t s) {
+    hipLaunchKernelGGL(eq_force_out_kernel, dim3((N + 3) / 4), dim3(256), 0, s, agg3, at->proj_w + (size_t)1 * 1 * h->d.HV,
+                       N, h->d.HV, f);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ S2 grid of the feed-forward
+// transformer_block.py:497-531: SO3 features -> res^2 grid points (to_full), point-wise MLP (dense products elsewhere),
+// grid -> SO3 (from_full), l = 0 replaced by the scalar gate.  One workgroup per node, thread = hidden channel.
+template <int LT>
+__global__ void eq_to_grid_kernel(const float* __restrict__ h1, const float* __restrict__ tg, int n0, int n1, eq_dims d,
+                                  float* __restrict__ g) {
+    extern __shared__ float T[];  // [G][S]
+    constexpr int S = (LT + 1) * (LT + 1);
+    for (int t = threadIdx.x; t < d.G * S; t += blockDim.x) T[t] = tg[t];
+    __syncthreads();
+    const int n = n0 + blockIdx.x, f = threadIdx.x;
+    if (n >= n1 || f >= d.F) return;
+    float in[S];
+    const float* hr = h1 + (size_t)n * S * d.F + f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) in[s] = hr[(size_t)s * d.F];
+    float* gr = g + (size_t)(n - n0) * d.G * d.F + f;
+    for (int p = 0; p < d.G; ++p) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) a += T[p * S + s] * in[s];
+        gr[(size_t)p * d.F] = a;
+    }
+}
+
+template <int LT>
+__global__ void eq_from_grid_kernel(const float* __restrict__ g, const float* __restrict__ fg, const float* __restrict__ gate,
+                                    int n0, int n1, eq_dims d, float* __restrict__ h2) {
+    extern __shared__ float Fm[];  // [G][S]
+    constexpr int S = (LT + 1) * (LT + 1);
+    for (int t = threadIdx.x; t < d.G * S; t += blockDim.x) Fm[t] = fg[t];
+    __syncthreads();
+    const int n = n0 + blockIdx.x, f = threadIdx.x;
+    if (n >= n1 || f >= d.F) return;
+    float acc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s] = 0.f;
+    const float* gr = g + (size_t)(n - n0) * d.G * d.F + f;
+    for (int p = 0; p < d.G; ++p) {
+        const float v = gr[(size_t)p * d.F];
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] += Fm[p * S + s] * v;
+    }
+    float* hr = h2 + (size_t)n * S * d.F + f;
+    hr[0] = gate[(size_t)n * d.F + f];
+#pragma unroll
+    for (int s = 1; s < S; ++s) hr[(size_t)s * d.F] = acc[s];
+}
+
+int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, hipStream_t s) {
+    if (n1 <= n0) return ADF_OK;
+    const int bd = (h->d.F + 63) / 64 * 64;
+    const size_t dyn = sizeof(float) * h->d.G * h->d.S;
+#define EQ_TG(LT_) hipLaunchKernelGGL(eq_to_grid_kernel<LT_>, dim3(n1 - n0), dim3(bd), dyn, s, h1, h->to_full, n0, n1, h->d, g)
+    EQ_FOR_L(h->d.L, EQ_TG)
+#undef EQ_TG
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+int32_t eq_launch_from_grid(const adf_eqv2* h, const float* g, const float* gate, int n0, int n1, float* h2, hipStream_t s) {
+    if (n1 <= n0) return ADF_OK;
+    const int bd = (h->d.F + 63) / 64 * 64;
+    const size_t dyn = sizeof(float) * h->d.G * h->d.S;
+#define EQ_FG(LT_) hipLaunchKernelGGL(eq_from_grid_kernel<LT_>, dim3(n1 - n0), dim3(bd), dyn, s, g, h->from_full, gate, n0, n1, h->d, h2)
+    EQ_FOR_L(h->d.L, EQ_FG)
+#undef EQ_FG
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ dense products (any shape)
+// C (+)= act(A . W^T + bias), exact f32 on the vector ALU: 64 x 64 tile per 256-thread workgroup, 4 x 4 per thread,
+// K in steps of 16 through LDS.  Rows of A and C may be strided in two levels (eq_rowmap) so that the per-degree maps of an
+// SO3_LinearV2 read and write [N, S, C] tensors in place.  The f16x3 matrix-core kernel (gemm16.hip) takes over for
+// aligned shapes (eqv2_api.hip).
+__global__ __launch_bounds__(256) void eq_gemm_kernel(const float* __restrict__ A, int lda, eq_rowmap am,
+                                                      const float* __restrict__ W, const float* __restrict__ bias,
+                                                      float* __restrict__ Cm, int ldc, eq_rowmap cm, long long M, int N,
+                                                      int K, int act, int accumulate) {
+    __shared__ float As[16][68];
+    __shared__ float Ws[16][68];
+    const int tid = threadIdx.x;
+    const long long m0 = (long long)blockIdx.x * 64;
+    const int nb = blockIdx.y * 64;
+    const int tr = tid >> 4, tc = tid & 15;  // thread tile: rows 4 tr.., columns 4 tc..
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    // loader: thread -> (row = tid / 4, k quad = tid % 4)
+    const int lr = tid >> 2, lk = (tid & 3) * 4;
+    const long long arow = m0 + lr;
+    const float* ap = nullptr;
+    if (arow < M) ap = A + (arow / am.period) * am.outer + (arow % am.period) * (long long)am.inner;
+    const int wrow = nb + lr;
+    const float* wp = wrow < N ? W + (size_t)wrow * K : nullptr;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + lk + u;
+            As[lk + u][lr] = (ap && k < K) ? ap[k] : 0.f;
+            Ws[lk + u][lr] = (wp && k < K) ? wp[k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[k][4 * tr + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Ws[k][4 * tc + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long row = m0 + 4 * tr + i;
+        if (row >= M) continue;
+        float* cp = Cm + (row / cm.period) * cm.outer + (row % cm.period) * (long long)cm.inner;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = nb + 4 * tc + j;
+            if (col >= N) continue;
+            float v = acc[i][j] + (bias ? bias[col] : 0.f);
+            if (act == 2) v = eq_silu(v);
+            if (accumulate) v += cp[col];
+            cp[col] = v;
+        }
+    }
+}
+
+int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float* W, const float* bias, float* Cm, int ldc,
+                    const eq_rowmap* cmap, long long M, int N, int K, int act, bool accumulate, hipStream_t s) {
+    if (M <= 0 || N <= 0) return ADF_OK;
+    const eq_rowmap a1 = {lda, 1, 0}, c1 = {ldc, 1, 0};  // plain rows: r * ld
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+    hipLaunchKernelGGL(eq_gemm_kernel, grid, dim3(256), 0, s, A, lda, amap ? *amap : a1, W, bias, Cm, ldc,
+                       cmap ? *cmap : c1, M, N, K, act, accumulate ? 1 : 0);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// [rows, cols] -> [cols, rows]
+__global__ void eq_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)rows * cols) return;
+    const int r = (int)(t / cols), c = (int)(t - (long long)r * cols);
+    out[(size_t)c * rows + r] = in[t];
+}
+
+int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s) {
+    const long long n = (long long)rows * cols;
+    hipLaunchKernelGGL(eq_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, rows, cols);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}

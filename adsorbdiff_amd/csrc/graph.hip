@@ -23,40 +23,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "common.h"
-
-struct GraphParams {
-    const float* pos;
-    const float* cell;
-    const int32_t* batch;
-    const int32_t* atom_offset;
-    int r0, r1, r2;
-    float rc2;
-    int K;
-    int N;
-    int32_t* nbr_cnt;
-    int32_t* nbr_src;
-    int32_t* nbr_shift;
-    int32_t* img_cnt;
-    int32_t* flags;
-    // static-atom cache (optional)
-    const int32_t* moving;   // [N] 1 = atom moves between graph builds
-    const int32_t* mov_idx;  // moving atoms, grouped by system
-    const int32_t* mov_off;  // [B+1]
-    float* cache_d2;         // [N,K]
-    int32_t* cache_cid;      // [N,K]
-    int32_t* cache_cnt;      // [N]
-};
-
-__device__ __forceinline__ void decode_shift(int c, int r0, int r1, int r2, float& sa, float& sb, float& sc) {
-    const int n2 = 2 * r2 + 1, n1 = 2 * r1 + 1;
-    const int ia = c / (n1 * n2);
-    const int rem = c - ia * (n1 * n2);
-    const int ib = rem / n2;
-    const int ic = rem - ib * n2;
-    sa = (float)(ia - r0);
-    sb = (float)(ib - r1);
-    sc = (float)(ic - r2);
-}
+#include "graph.h"
 
 // One wave per centre atom, 4 centres per workgroup.  Lane = neighbour atom j (64 per pass), inner
 // loop over the lattice shifts; in-cutoff candidates are compacted into the wave's LDS list with
@@ -371,6 +338,17 @@ __global__ __launch_bounds__(256) void adf_sort_edges_kernel(const int32_t* nptr
         e_geom[e0 + rank] = g;
         e_src[e0 + rank] = sj;
     }
+}
+
+// The directed strict top-K stage alone (the EquiformerV2 path uses it without the symmetrisation): mode 0 full
+// evaluation, 1 full + fill the static-atom cache, 2 rebuild static centres from the cache.
+int32_t adf_topk_launch(const GraphParams& p, int mode, hipStream_t s) {
+    const dim3 tg((p.N + 3) / 4);
+    if (mode == 0) hipLaunchKernelGGL(adf_topk_kernel<0>, tg, dim3(256), 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL(adf_topk_kernel<1>, tg, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(adf_topk_kernel<2>, tg, dim3(256), 0, s, p);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
 }
 
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {

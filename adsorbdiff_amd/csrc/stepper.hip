@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64) void adf_step_apply_kernel(StepParams p) {
         }
 }
 
-int32_t adf_stepper_init(adf_painn* h, const adf_batch* b, float* pos, const int32_t* tags, const float* noise,
+int32_t adf_stepper_init(const adf_batch* b, float* pos, const int32_t* tags, const float* noise,
                          hipStream_t s) {
     hipLaunchKernelGGL(adf_init_placement_kernel, dim3(b->num_systems), dim3(64), 0, s, b->cell, b->atom_offset, tags,
                        pos, noise, b->num_systems);
@@ -200,13 +200,13 @@ int32_t adf_stepper_init(adf_painn* h, const adf_batch* b, float* pos, const int
     return ADF_OK;
 }
 
-int32_t adf_stepper_step(adf_painn* h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+int32_t adf_stepper_step(float* sys, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                          const float* f1, const float* f2, const adf_step_coef* coef, const adf_step_coef* coefs_dev,
                          int num_steps, const float* z_tr, const float* z_rot, int32_t early_stop_count,
                          int32_t* state, float* dcom, float* drot, hipStream_t s) {
     StepParams p;
     p.cell = b->cell; p.atom_offset = b->atom_offset; p.tags = tags; p.fixed = fixed; p.pos = pos;
-    p.f1 = f1; p.f2 = f2; p.z_tr = z_tr; p.z_rot = z_rot; p.sys = h->sys; p.state = state;
+    p.f1 = f1; p.f2 = f2; p.z_tr = z_tr; p.z_rot = z_rot; p.sys = sys; p.state = state;
     p.dcom_out = dcom; p.drot_out = drot; p.B = b->num_systems; p.early_stop_count = early_stop_count;
     if (coef) p.c = *coef; else p.c = adf_step_coef{};
     p.coefs_dev = coefs_dev; p.num_steps = num_steps;

@@ -26,6 +26,9 @@ EXPORTS = (
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_lift_adsorbates", "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
     "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_bwd", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
+    "adf_eqv2_create", "adf_eqv2_destroy", "adf_eqv2_set_constants", "adf_eqv2_set_weights", "adf_eqv2_set_arithmetic",
+    "adf_eqv2_set_edges", "adf_eqv2_set_moving", "adf_eqv2_forward", "adf_eqv2_check_flags", "adf_eqv2_init_placement",
+    "adf_eqv2_sde_step", "adf_eqv2_sample", "adf_eqv2_get_counters", "adf_eqv2_profile_enable", "adf_eqv2_profile_read",
     "adf_last_error", "adf_version",
 )
 
@@ -36,6 +39,20 @@ class Hparams(C.Structure):
         ("num_elements", C.c_int32), ("max_neighbors", C.c_int32), ("envelope_exponent", C.c_int32),
         ("num_heads", C.c_int32), ("cutoff", C.c_float),
     ]
+
+
+class EqV2Hparams(C.Structure):
+    _fields_ = [
+        ("lmax", C.c_int32), ("mmax", C.c_int32), ("num_layers", C.c_int32), ("sphere_channels", C.c_int32),
+        ("attn_hidden_channels", C.c_int32), ("num_heads", C.c_int32), ("attn_alpha_channels", C.c_int32),
+        ("attn_value_channels", C.c_int32), ("ffn_hidden_channels", C.c_int32), ("grid_resolution", C.c_int32),
+        ("edge_channels", C.c_int32), ("num_distance_basis", C.c_int32), ("max_num_elements", C.c_int32),
+        ("max_neighbors", C.c_int32), ("max_radius", C.c_float), ("avg_degree", C.c_float),
+    ]
+
+
+class EqV2Counters(C.Structure):
+    _fields_ = [("num_edges", C.c_int64), ("num_atoms", C.c_int64), ("dense_flops", C.c_int64), ("conv_flops", C.c_int64)]
 
 
 class BatchDesc(C.Structure):
@@ -138,6 +155,21 @@ def load():
         "adf_op_score_loss": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
         "adf_op_sqnorm_accumulate": [vp, i64, vp, vp],
         "adf_op_adamw_step": [vp, vp, vp, vp, vp, i64, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float, vp],
+        "adf_eqv2_create": [C.POINTER(EqV2Hparams), C.POINTER(vp)],
+        "adf_eqv2_destroy": [vp],
+        "adf_eqv2_set_constants": [vp, vp, vp, vp, vp, vp],
+        "adf_eqv2_set_weights": [vp, i32, C.POINTER(vp), vp],
+        "adf_eqv2_set_arithmetic": [vp, i32],
+        "adf_eqv2_set_edges": [vp, i64, vp, vp, vp, i32, vp],
+        "adf_eqv2_set_moving": [vp, vp, vp, vp],
+        "adf_eqv2_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp],
+        "adf_eqv2_check_flags": [vp, vp],
+        "adf_eqv2_init_placement": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp],
+        "adf_eqv2_sde_step": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, vp, C.POINTER(StepCoef), vp, i32, vp, vp, i32, vp, vp, vp, vp],
+        "adf_eqv2_sample": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp],
+        "adf_eqv2_get_counters": [vp, C.POINTER(EqV2Counters), vp],
+        "adf_eqv2_profile_enable": [vp, i32],
+        "adf_eqv2_profile_read": [vp, C.POINTER(C.c_float), C.POINTER(i64), vp],
         "adf_sample": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp],
     }
     for name, argtypes in sigs.items():

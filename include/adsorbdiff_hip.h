@@ -337,6 +337,93 @@ int32_t adf_op_adamw_step(float* p, const float* g, float* m, float* v, float* e
                           float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                           float ema_decay, void* stream);
 
+/* ---- EquiformerV2 denoiser (BASELINE config 4).  Replaces
+ * EquiformerV2S_OC20_DenoisingPos.forward(data) (models/equiformer_v2/equiformer_v2_denoising.py:185-318) for the
+ * configuration the repository ships (configs/denoising/eqv2_so3.yml): one resolution, layer_norm_sh, SiLU attention
+ * with re-normalised alpha, separable S2 activation, grid MLP feed-forward, per-block atom edge embeddings, Gaussian
+ * distance expansion with 600 functions (equiformer_v2_oc20.py:251-264), FOR_denoising = two force blocks. */
+typedef struct adf_eqv2* adf_eqv2_t;
+typedef struct {
+    int32_t lmax, mmax;              /* lmax_list[0] (1..6), mmax_list[0] (<= lmax)                        */
+    int32_t num_layers;
+    int32_t sphere_channels;         /* C                                                               */
+    int32_t attn_hidden_channels;
+    int32_t num_heads, attn_alpha_channels, attn_value_channels;
+    int32_t ffn_hidden_channels;
+    int32_t grid_resolution;         /* res: the S2 grid has res x res points                           */
+    int32_t edge_channels;
+    int32_t num_distance_basis;      /* 600 in the reference, whatever the constructor argument says    */
+    int32_t max_num_elements;
+    int32_t max_neighbors;           /* K of the strict top-K cap                                       */
+    float max_radius;                /* cutoff, Angstrom                                                */
+    float avg_degree;                /* rescale of the edge-degree embedding (_AVG_DEGREE)              */
+} adf_eqv2_hparams;
+
+int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out);
+int32_t adf_eqv2_destroy(adf_eqv2_t h);
+
+/* Constant tables the reference takes from e3nn / Jd.pt (so3.py:509-531,566-613; wigner.py:8), HOST float32 arrays
+ * computed by adsorbdiff_amd/so3_math.py:  jd = J_l row-major, l = 0..lmax concatenated;  to_red / from_red
+ * [res*res, S_r] with the |m| <= mmax coefficients in m-major order;  to_full / from_full [res*res, (lmax+1)^2]. */
+int32_t adf_eqv2_set_constants(adf_eqv2_t h, const float* jd, const float* to_red, const float* from_red,
+                               const float* to_full, const float* from_full);
+
+/* Bind the weights: caller-owned DEVICE float32 tensors in torch layout, reference state_dict names:
+ *   0 atom_radii [101]  1 sphere_embedding.weight  2,3 edge_degree_embedding.{source,target}_embedding.weight
+ *   4..13 edge_degree_embedding.rad_func  (RAD = net.0.weight, net.0.bias, net.1.weight, net.1.bias, net.3.weight,
+ *         net.3.bias, net.4.weight, net.4.bias, net.6.weight, net.6.bias)
+ *   then per block i:  norm_1 (NORM = affine_weight, norm_l0.weight, norm_l0.bias), ga (ATTN), norm_2 (NORM),
+ *         ffn (so3_linear_1.weight, .bias, scalar_mlp.0.weight, .bias, grid_mlp.0.weight, grid_mlp.2.weight,
+ *         grid_mlp.4.weight, so3_linear_2.weight, .bias)
+ *   then norm (NORM), force_block (ATTN), force_block2 (ATTN)
+ *   ATTN = alpha_dot, source_embedding.weight, target_embedding.weight, so2_conv_1.fc_m0.weight, .bias,
+ *          so2_conv_1.so2_m_conv.{0..mmax-1}.fc.weight, so2_conv_1.rad_func (RAD), alpha_norm.weight, .bias,
+ *          so2_conv_2.fc_m0.weight, .bias, so2_conv_2.so2_m_conv.{0..mmax-1}.fc.weight, proj.weight, proj.bias */
+int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const void* const* weights, void* stream);
+
+/* 0 = f16x3 split products on the f16 matrix cores where the shapes allow (default), 1 = exact f32 everywhere. */
+int32_t adf_eqv2_set_arithmetic(adf_eqv2_t h, int32_t exact_f32);
+
+/* Use this edge list (source, target, vector target -> source image; target non-decreasing; DEVICE arrays, copied)
+ * instead of building one, until adf_eqv2_set_edges(h, 0, ...) — parity tests against reference runs whose pick among
+ * exactly tied K-th neighbours is implementation-defined. */
+int32_t adf_eqv2_set_edges(adf_eqv2_t h, int64_t num_edges, const int32_t* src, const int32_t* dst, const float* vec,
+                           int32_t max_in_degree, void* stream);
+/* Static-atom cache of the neighbour search, as adf_graph_set_moving. */
+int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, const int32_t* mov_idx, const int32_t* mov_off);
+
+/* The forward: graph (models/base.py:33-123, NOT symmetrised), edge frames + Wigner rows, embeddings, num_layers
+ * transformer blocks, final norm, two force blocks.  f1, f2: [N,3] = the l = 1 coefficients (m = -1, 0, 1) of the two
+ * force blocks (equiformer_v2_denoising.py:307-318).  x_blocks (optional, may be NULL): [num_layers + 1][N][S][C]
+ * node embeddings after the edge-degree embedding and after every block (parity tests). */
+int32_t adf_eqv2_forward(adf_eqv2_t h, const adf_batch* b, float* f1, float* f2, float* x_blocks, void* stream);
+int32_t adf_eqv2_check_flags(adf_eqv2_t h, void* stream);
+
+/* Reverse-diffusion stepper on an EquiformerV2 handle: same contracts as adf_sde_init_placement,
+ * adf_sde_step_scheduled and adf_sample above. */
+int32_t adf_eqv2_init_placement(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const float* noise,
+                                void* stream);
+int32_t adf_eqv2_sde_step(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                          const float* f1, const float* f2, const adf_step_coef* coef, const adf_step_coef* coefs_dev,
+                          int32_t num_steps, const float* z_tr, const float* z_rot, int32_t early_stop_count,
+                          int32_t* state, float* dcom, float* drot, void* stream);
+int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                        const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
+                        int32_t early_stop_count, int32_t poll_every, int32_t* state, float* f1, float* f2, void* stream);
+
+/* Work of the last forward and HIP-event time per kernel group (bench.py roofline).  Categories: 0 graph + Wigner,
+ * 1 radial MLPs, 2 rotate in / out, 3 SO(2) convolution products, 4 S2 activation, 5 attention weights, 6 node-side
+ * norms / SO(3) linears, 7 feed-forward grid MLP, 8 stepper. */
+#define ADF_EQV2_PROF_NCAT 9
+typedef struct {
+    int64_t num_edges, num_atoms;
+    int64_t dense_flops;       /* 2 x multiply-adds of every dense product of one forward */
+    int64_t conv_flops;        /* the SO(2) convolution share of it                       */
+} adf_eqv2_counters;
+int32_t adf_eqv2_get_counters(adf_eqv2_t h, adf_eqv2_counters* out, void* stream);
+int32_t adf_eqv2_profile_enable(adf_eqv2_t h, int32_t on);
+int32_t adf_eqv2_profile_read(adf_eqv2_t h, float* ms, int64_t* count, void* stream);
+
 const char* adf_last_error(void);
 const char* adf_version(void);
 
