@@ -99,6 +99,7 @@ struct adf_eqv2 {
     float* arena; size_t arena_floats;
     float* garena; size_t garena_floats;   // grid MLP buffers of a node chunk
     float* sys;
+    float* rs; int64_t rs_cap;   // per-row lifts of the A operand of an f16x3 product
     int64_t lastN;
     // HIP-event timing per kernel group (bench.py roofline)
     bool prof_on;

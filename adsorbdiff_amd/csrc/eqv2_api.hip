@@ -14,6 +14,11 @@
 int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float* W, const float* bias, float* Cm, int ldc,
                     const eq_rowmap* cmap, long long M, int N, int K, int act, bool accumulate, hipStream_t s);
 int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+bool eq_gemm16_ok(const float* A, const eq_rowmap* am, const float* Cm, const eq_rowmap* cm, int N, int K);
+int32_t eq_launch_rowscale(const float* A, const eq_rowmap* am, long long M, int K, float* rs, hipStream_t s);
+int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscale, const adf_w16* W, const float* bias,
+                         float* Cm, const eq_rowmap* cm, long long M, int N, int K, int act, bool accumulate,
+                         hipStream_t s);
 
 template <typename T>
 static int32_t eq_alloc(T** p, size_t count) {
@@ -128,7 +133,8 @@ static void eq_free_workspaces(adf_eqv2* h) {
     if (h->scan_tmp) { (void)hipFree(h->scan_tmp); h->scan_tmp = nullptr; }
     eq_free(h->cache_d2); eq_free(h->cache_cid); eq_free(h->cache_cnt);
     eq_free(h->x); eq_free(h->y); eq_free(h->agg); eq_free(h->gate); eq_free(h->h1); eq_free(h->h2);
-    eq_free(h->arena); eq_free(h->garena); eq_free(h->sys);
+    eq_free(h->arena); eq_free(h->garena); eq_free(h->sys); eq_free(h->rs);
+    h->rs_cap = 0;
     h->capN = h->capB = h->capE = 0;
     h->arena_floats = h->garena_floats = 0;
 }
@@ -205,6 +211,58 @@ static int eq_expected_weights(const eq_dims& d, int layers) {
     return 14 + layers * (3 + attn + 3 + 9) + 3 + 2 * attn;
 }
 
+// fp16 hi/lo images (per-matrix power-of-two scale, gemm16.hip) of every weight a dense product reads
+static void eq_collect_lins(adf_eqv2* h, std::vector<eq_lin*>& v) {
+    const eq_dims& d = h->d;
+    auto rad = [&](eq_radial* r) { v.push_back(&r->l3); v.push_back(&r->l6); };
+    auto attn = [&](eq_attn* a, bool with_proj) {
+        v.push_back(&a->c1_m0); v.push_back(&a->c2_m0);
+        for (int m = 1; m <= d.M; ++m) { v.push_back(&a->c1_m[m - 1]); v.push_back(&a->c2_m[m - 1]); }
+        rad(&a->rad);
+        if (with_proj) for (int l = 0; l <= d.L; ++l) v.push_back(&a->proj_l[l]);
+    };
+    rad(&h->ed_rad);
+    for (int i = 0; i < h->hp.num_layers; ++i) {
+        eq_block& b = h->blk[i];
+        attn(&b.ga, true);
+        v.push_back(&b.ffn.scalar); v.push_back(&b.ffn.g0); v.push_back(&b.ffn.g2); v.push_back(&b.ffn.g4);
+        for (int l = 0; l <= d.L; ++l) { v.push_back(&b.ffn.l1[l]); v.push_back(&b.ffn.l2[l]); }
+    }
+    attn(&h->force[0], false); attn(&h->force[1], false);
+}
+
+static int32_t eq_split_weights(adf_eqv2* h, hipStream_t s) {
+    std::vector<eq_lin*> v;
+    eq_collect_lins(h, v);
+    size_t halves = 0, nmat = 0;
+    for (eq_lin* l : v) {
+        l->has16 = false;
+        if (l->in % 32 != 0 || (l->out & 3)) continue;
+        halves += 2 * (size_t)l->out * l->in;
+        ++nmat;
+    }
+    if (h->w16_bytes < halves * 2 + 64) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        eq_free(h->w16_arena);
+        ADF_TRY(eq_alloc(&h->w16_arena, halves * 2 + 64));
+        h->w16_bytes = halves * 2 + 64;
+    }
+    eq_free(h->w16_scales);
+    ADF_TRY(eq_alloc(&h->w16_scales, nmat + 1));
+    if (!h->w16_scratch) ADF_TRY(eq_alloc(&h->w16_scratch, 4));
+    unsigned char* p = h->w16_arena;
+    size_t k = 0;
+    for (eq_lin* l : v) {
+        if (l->in % 32 != 0 || (l->out & 3)) continue;
+        const size_t n = (size_t)l->out * l->in;
+        l->w16.hi = p; l->w16.lo = p + n * 2; l->w16.inv_scale = h->w16_scales + k; l->w16.bias_perm = nullptr;
+        p += n * 4; ++k;
+        ADF_TRY(adf_split_weight(l->w, (long long)n, &l->w16, h->w16_scratch, s));
+        l->has16 = true;
+    }
+    return ADF_OK;
+}
+
 extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const void* const* weights, void* stream) {
     if (!h || !weights) { adf_set_error("eqv2_set_weights: null argument"); return ADF_EINVAL; }
     const eq_dims& d = h->d;
@@ -254,6 +312,7 @@ extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const v
         rads[i]->w0t = h->wt_arena + per * i;
         ADF_TRY(eq_launch_transpose(rads[i]->l0.w, rads[i]->w0t, d.EC, d.NB + 2 * d.EC, s));
     }
+    ADF_TRY(eq_split_weights(h, s));
     h->weights_set = true;
     return ADF_OK;
 }
@@ -317,6 +376,11 @@ static int32_t eq_ensure_capacity(adf_eqv2* h, int64_t N, int64_t B, int64_t Ene
         ADF_TRY(eq_alloc(&h->arena, h->arena_floats));
         h->garena_floats = 2 * (size_t)cn * d.G * d.F;
         ADF_TRY(eq_alloc(&h->garena, h->garena_floats));
+        int64_t rc = 2 * cn * kk;
+        if (cn * d.G > rc) rc = cn * d.G;
+        if (cN * (2 * d.L + 1) > rc) rc = cN * (2 * d.L + 1);
+        ADF_TRY(eq_alloc(&h->rs, (size_t)rc));
+        h->rs_cap = rc;
         h->capN = cN; h->capB = cB; h->capE = cE;
     }
     return ADF_OK;
@@ -354,7 +418,14 @@ extern "C" int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, cons
 // ---------------------------------------------------------------------------------------------- dense product dispatch
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
                 float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s) {
-    (void)h;
+    const eq_rowmap a1 = {lda, 1, 0}, c1 = {ldc, 1, 0};
+    const eq_rowmap* am = amap ? amap : &a1;
+    const eq_rowmap* cm = cmap ? cmap : &c1;
+    if (!h->exact_f32 && W->has16 && M <= h->rs_cap && eq_gemm16_ok(A, am, Cm, cm, W->out, W->in)) {
+        // per-row power-of-two lift of A (eqv2_gemm16.hip), then the f16x3 product
+        ADF_TRY(eq_launch_rowscale(A, am, M, W->in, h->rs, s));
+        return eq_launch_gemm16(A, am, h->rs, &W->w16, use_bias ? W->b : nullptr, Cm, cm, M, W->out, W->in, act, accumulate, s);
+    }
     return eq_gemm_f32(A, lda, amap, W->w, use_bias ? W->b : nullptr, Cm, ldc, cmap, M, W->out, W->in, act, accumulate, s);
 }
 

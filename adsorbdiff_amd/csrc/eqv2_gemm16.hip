@@ -1,0 +1,257 @@
+// Dense products of the EquiformerV2 path on the f16 matrix cores with the 3-product split of gemm16.hip
+// (a = a_hi + a_lo, w s = w_hi + w_lo, three v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate), plus what the
+// PaiNN kernel does not have:
+//   * a power-of-two scale PER ROW of A applied before the split (and divided out in the epilogue).  The matrix core
+//     flushes fp16 subnormals, so an unscaled element below ~0.1 loses its a_lo term (2^-11 instead of 2^-22 relative);
+//     EquiformerV2's operands are products of O(1e-3) embeddings and would sit there.  With the row's largest element
+//     lifted to [2^14, 2^15) every element down to 8e-6 of the row maximum keeps both terms, and smaller ones contribute
+//     less than 4e-9 of the row's scale.  The scale is a function of the row alone, so results do not depend on which
+//     rows share a launch (sharded / chunked runs reproduce bit for bit).
+//   * two-level row addressing of A and C (eq_rowmap): the per-degree maps of an SO3_LinearV2 work on [N, S, C] in place;
+//   * accumulate-into-C (residual connections) and plain SiLU.
+// Tiling as gemm16.hip: 128 x (64 NJ) x 32 per 256-thread workgroup, 4 waves as 2 x 2, fp32 A split while staged, weights
+// pre-split at set_weights, one K-tile of global loads in flight, XCD-aware tile order, 16-byte stores through LDS.
+#include "eqv2.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+#define GK 32
+#define GLD 40  // halves per LDS row (32 + 8 pad: conflict-free ds_read_b128)
+#define GTLD 64
+
+__device__ __forceinline__ float eq16_silu(float x) { return x / (1.0f + expf(-x)); }
+
+// rs[r] = 2^(14 - exponent(max_k |A[r, k]|)), 1 for an all-zero row; one wave per row
+__global__ __launch_bounds__(256) void eq_rowscale_kernel(const float* __restrict__ A, eq_rowmap am, long long M, int K,
+                                                          float* __restrict__ rs) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= M) return;
+    const float* a = A + (r / am.period) * am.outer + (r % am.period) * (long long)am.inner;
+    float mx = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(a + k);
+        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) {
+        float s = 1.0f;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int e;
+            (void)frexpf(mx, &e);  // mx = m 2^e, m in [0.5, 1)
+            e = 15 - e;
+            e = e > 120 ? 120 : (e < -120 ? -120 : e);
+            s = ldexpf(1.0f, e);
+        }
+        rs[r] = s;
+    }
+}
+
+int32_t eq_launch_rowscale(const float* A, const eq_rowmap* am, long long M, int K, float* rs, hipStream_t s) {
+    if (M <= 0) return ADF_OK;
+    hipLaunchKernelGGL(eq_rowscale_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, A, *am, M, K, rs);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+template <int ACT, int NJ, bool ACCUM>
+__global__ __launch_bounds__(256, 2) void eq_gemm16_kernel(const float* __restrict__ A, eq_rowmap am,
+                                                           const float* __restrict__ rscale,
+                                                           const _Float16* __restrict__ Whi,
+                                                           const _Float16* __restrict__ Wlo,
+                                                           const float* __restrict__ inv_scale,
+                                                           const float* __restrict__ bias, float* __restrict__ Cm,
+                                                           eq_rowmap cm, long long M, int N, int K, int tiles_n) {
+    constexpr int MI = 2;
+    constexpr int TM = 64 * MI, TN = 64 * NJ, NA = TM / 32;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * GLD];
+    __shared__ float rinv[TM];
+    _Float16* Ahi = lds;
+    _Float16* Alo = Ahi + TM * GLD;
+    _Float16* Bhi = Alo + TM * GLD;
+    _Float16* Blo = Bhi + TN * GLD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * (32 * MI), wn = (wave & 1) * (32 * NJ);
+    const int id = blockIdx.x, xcd = id & 7, qd = id >> 3;
+    const long long tile_m = (long long)(qd / tiles_n) * 8 + xcd;
+    const int tile_n = qd % tiles_n;
+    const long long m0 = tile_m * TM;
+    const int n0 = tile_n * TN;
+    if (m0 >= M) return;
+
+    const float* a_ptr[NA];
+    float a_rs[NA];
+    int a_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + 256 * i;
+        const int row = f >> 3, kq = f & 7;
+        long long grow = m0 + row;
+        if (grow > M - 1) grow = M - 1;
+        a_ptr[i] = A + (grow / am.period) * am.outer + (grow % am.period) * (long long)am.inner + kq * 4;
+        a_rs[i] = rscale ? rscale[grow] : 1.0f;
+        a_off[i] = row * GLD + kq * 4;
+    }
+    if (tid < TM) {
+        long long grow = m0 + tid;
+        if (grow > M - 1) grow = M - 1;
+        rinv[tid] = rscale ? 1.0f / rscale[grow] : 1.0f;
+    }
+    int w_src[NJ], w_off[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int f = tid + 256 * i;
+        const int row = f >> 2, part = f & 3;
+        w_src[i] = min(n0 + row, N - 1) * K + part * 8;
+        w_off[i] = row * GLD + part * 8;
+    }
+    float4 ra[NA];
+    half8 rwh[NJ], rwl[NJ];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i]);
+        rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i]);
+    }
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / GK;
+    const int fa = (wm + (lane & 31)) * GLD + (lane >> 5) * 8;
+    const int fb = (wn + (lane & 31)) * GLD + (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const float sx = ra[i].x * a_rs[i], sy = ra[i].y * a_rs[i], sz = ra[i].z * a_rs[i], sw = ra[i].w * a_rs[i];
+            half4 h, l;
+            h[0] = (_Float16)sx; h[1] = (_Float16)sy; h[2] = (_Float16)sz; h[3] = (_Float16)sw;
+            l[0] = (_Float16)(sx - (float)h[0]); l[1] = (_Float16)(sy - (float)h[1]);
+            l[2] = (_Float16)(sz - (float)h[2]); l[3] = (_Float16)(sw - (float)h[3]);
+            *reinterpret_cast<half4*>(Ahi + a_off[i]) = h;
+            *reinterpret_cast<half4*>(Alo + a_off[i]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < NJ; ++i) {
+            *reinterpret_cast<half8*>(Bhi + w_off[i]) = rwh[i];
+            *reinterpret_cast<half8*>(Blo + w_off[i]) = rwl[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int k1 = (kt + 1) * GK;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + k1);
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + k1);
+                rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + k1);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 bh[NJ], bl[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = *reinterpret_cast<const half8*>(Bhi + fb + j * 32 * GLD + ks * 16);
+                bl[j] = *reinterpret_cast<const half8*>(Blo + fb + j * 32 * GLD + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const half8 ah = *reinterpret_cast<const half8*>(Ahi + fa + i * 32 * GLD + ks * 16);
+                const half8 al = *reinterpret_cast<const half8*>(Alo + fa + i * 32 * GLD + ks * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float isc = *inv_scale;
+    const int q = lane & 31;
+    __syncthreads();  // all waves are done reading the operand tiles
+    float* T = reinterpret_cast<float*>(lds) + wave * (32 * GTLD);  // [32 rows][64] floats per wave
+#pragma unroll
+    for (int jj = 0; jj < NJ / 2; ++jj) {
+        const int cb = n0 + wn + 64 * jj;
+        const float bv0 = (bias && cb + q < N) ? bias[cb + q] : 0.f;
+        const float bv1 = (bias && cb + 32 + q < N) ? bias[cb + 32 + q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float sc = isc * rinv[wm + 32 * i + lr];
+                float v0 = acc[i][2 * jj][r] * sc + bv0, v1 = acc[i][2 * jj + 1][r] * sc + bv1;
+                if (ACT == 2) { v0 = eq16_silu(v0); v1 = eq16_silu(v1); }
+                T[lr * GTLD + q] = v0;
+                T[lr * GTLD + 32 + q] = v1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int item = lane + 64 * it;
+                const int lr = item >> 4, c4 = item & 15;
+                const long long row = m0 + wm + 32 * i + lr;
+                const int col = cb + 4 * c4;
+                if (row < M && col < N) {
+                    float* cp = Cm + (row / cm.period) * cm.outer + (row % cm.period) * (long long)cm.inner + col;
+                    float4 v = *reinterpret_cast<const float4*>(T + lr * GTLD + 4 * c4);
+                    if (ACCUM) {
+                        const float4 o = *reinterpret_cast<const float4*>(cp);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(cp) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// shapes the kernel takes: K % 32 == 0, N % 4 == 0, 16-byte aligned rows of A and C
+bool eq_gemm16_ok(const float* A, const eq_rowmap* am, const float* Cm, const eq_rowmap* cm, int N, int K) {
+    if (K % GK != 0 || (N & 3)) return false;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(Cm) & 15)) return false;
+    if ((am->outer & 3) || (am->inner & 3) || (cm->outer & 3) || (cm->inner & 3)) return false;
+    return true;
+}
+
+int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscale, const adf_w16* W, const float* bias,
+                         float* Cm, const eq_rowmap* cm, long long M, int N, int K, int act, bool accumulate,
+                         hipStream_t s) {
+    if (M <= 0 || N <= 0) return ADF_OK;
+    const int NJ = N <= 128 ? 2 : 4;
+    const int TN = 64 * NJ;
+    const int tiles_n = (N + TN - 1) / TN;
+    const long long tiles_m = (M + 127) / 128;
+    const long long tiles_m8 = (tiles_m + 7) / 8 * 8;
+    const long long nblocks = tiles_m8 * tiles_n;
+    if (nblocks > 0x7fffffffLL) { adf_set_error("eq_gemm16: grid too large"); return ADF_EINVAL; }
+    dim3 grid((unsigned)nblocks);
+#define EQ_L16(ACT_, NJ_, ACC_)                                                                                       \
+    hipLaunchKernelGGL((eq_gemm16_kernel<ACT_, NJ_, ACC_>), grid, dim3(256), 0, s, A, *am, rscale,                    \
+                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n)
+    if (NJ == 2) {
+        if (act == 2) { if (accumulate) EQ_L16(2, 2, true); else EQ_L16(2, 2, false); }
+        else { if (accumulate) EQ_L16(0, 2, true); else EQ_L16(0, 2, false); }
+    } else {
+        if (act == 2) { if (accumulate) EQ_L16(2, 4, true); else EQ_L16(2, 4, false); }
+        else { if (accumulate) EQ_L16(0, 4, true); else EQ_L16(0, 4, false); }
+    }
+#undef EQ_L16
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
