@@ -66,6 +66,7 @@ struct eq_rowmap {
 struct adf_eqv2 {
     adf_eqv2_hparams hp;
     eq_dims d;
+    eq_dims* d_dev;   // device copy (kernels that index its tables per lane)
     int device, num_cus;
     bool weights_set, consts_set, exact_f32;
     // constants (device)
@@ -99,6 +100,7 @@ struct adf_eqv2 {
     float* arena; size_t arena_floats;
     float* garena; size_t garena_floats;   // grid MLP buffers of a node chunk
     float* sys;
+    void* s2tab; int s2_npb; float s2_inv_sT, s2_inv_sF, s2_gain_shift;  // fragment-order fp16 hi/lo images of to_red / from_red
     float* rs; int64_t rs_cap;   // per-row lifts of the A operand of an f16x3 product
     int64_t lastN;
     // HIP-event timing per kernel group (bench.py roofline)
@@ -122,8 +124,10 @@ int32_t eq_launch_ln_silu(float* x, const float* w, const float* b, long long ro
 int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int n0, int n1, float* x, hipStream_t s);
 int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, int n0, int n1, float* const* mbuf,
                             hipStream_t s);
+// rsp (optional): per-order arrays that receive the power-of-two lifts of the output rows (matrix-core version only;
+// *rs_written tells whether they were filled)
 int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,
-                        float* const* mb, hipStream_t s);
+                        float* const* mb, float* const* rsp, bool* rs_written, hipStream_t s);
 int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, int ldy, int n0, int n1, float* alpha,
                         hipStream_t s);
 int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* alpha, int n0, int n1, float* agg,
@@ -136,4 +140,5 @@ int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float*
 int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
 // C (+)= act(A . W^T + b): exact f32 for any shape; act: 0 none, 2 SiLU
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
-                float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s);
+                float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s,
+                const float* rs_pre = nullptr);

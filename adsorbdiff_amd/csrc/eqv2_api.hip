@@ -121,6 +121,8 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     h->prof_ev = new std::vector<hipEvent_t>();
     h->prof_cat = new std::vector<int>();
     int32_t st = eq_alloc(&h->flags, EQ_NFLAGS);
+    if (st == ADF_OK) st = eq_alloc(&h->d_dev, 1);
+    if (st == ADF_OK && hipMemcpy(h->d_dev, &h->d, sizeof(eq_dims), hipMemcpyHostToDevice) != hipSuccess) st = ADF_EHIP;
     if (st == ADF_OK) { hipError_t e = hipMemset(h->flags, 0, sizeof(int32_t) * EQ_NFLAGS); if (e != hipSuccess) st = ADF_EHIP; }
     if (st != ADF_OK) { adf_eqv2_destroy(h); return st; }
     *out = h;
@@ -143,8 +145,9 @@ extern "C" int32_t adf_eqv2_destroy(adf_eqv2_t h) {
     if (!h) return ADF_OK;
     (void)hipDeviceSynchronize();
     eq_free_workspaces(h);
-    eq_free(h->flags);
+    eq_free(h->flags); eq_free(h->d_dev);
     eq_free(h->xe_src); eq_free(h->xe_dst); eq_free(h->xe_vec);
+    { unsigned char* t = (unsigned char*)h->s2tab; eq_free(t); h->s2tab = nullptr; }
     eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
     eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
@@ -159,6 +162,7 @@ extern "C" int32_t adf_eqv2_set_constants(adf_eqv2_t h, const float* jd, const f
     const eq_dims& d = h->d;
     const size_t nj = d.j_off[d.L + 1], nr = (size_t)d.G * d.Sr, nf = (size_t)d.G * d.S;
     eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
+    { unsigned char* t = (unsigned char*)h->s2tab; eq_free(t); h->s2tab = nullptr; }
     ADF_TRY(eq_alloc(&h->jd, nj)); ADF_TRY(eq_alloc(&h->to_red, nr)); ADF_TRY(eq_alloc(&h->from_red, nr));
     ADF_TRY(eq_alloc(&h->to_full, nf)); ADF_TRY(eq_alloc(&h->from_full, nf));
     ADF_HIP_CHECK(hipMemcpy(h->jd, jd, nj * 4, hipMemcpyHostToDevice));
@@ -166,6 +170,51 @@ extern "C" int32_t adf_eqv2_set_constants(adf_eqv2_t h, const float* jd, const f
     ADF_HIP_CHECK(hipMemcpy(h->from_red, from_red, nr * 4, hipMemcpyHostToDevice));
     ADF_HIP_CHECK(hipMemcpy(h->to_full, to_full, nf * 4, hipMemcpyHostToDevice));
     ADF_HIP_CHECK(hipMemcpy(h->from_full, from_full, nf * 4, hipMemcpyHostToDevice));
+    // fragment-order fp16 hi/lo images of to_red / from_red for the matrix-core S2 activation (eqv2_kernels.hip)
+    if (d.Sr <= 32) {
+        const int npb = (d.G + 31) / 32;
+        float tmax = 0.f, fmax_ = 0.f, gain = 0.f;
+        for (int p = 0; p < d.G; ++p) {
+            float row = 0.f;
+            for (int r = 0; r < d.Sr; ++r) {
+                const float t = fabsf(to_red[(size_t)p * d.Sr + r]);
+                row += t;
+                tmax = t > tmax ? t : tmax;
+                const float f = fabsf(from_red[(size_t)p * d.Sr + r]);
+                fmax_ = f > fmax_ ? f : fmax_;
+            }
+            gain = row > gain ? row : gain;
+        }
+        auto pow2_for = [](float amax) { int e = 0; if (amax > 0.f) (void)frexpf(amax, &e); return ldexpf(1.0f, 10 - e); };
+        const float sT = pow2_for(tmax), sF = pow2_for(fmax_);
+        int ge = 0;
+        if (gain > 1.0f) { (void)frexpf(gain, &ge); if (ldexpf(1.0f, ge - 1) >= gain) --ge; }
+        const size_t nh8 = (size_t)npb * 2 * 2 * 64;  // half8 entries per table
+        std::vector<_Float16> img(2 * nh8 * 8);
+        for (int pb = 0; pb < npb; ++pb)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int kh = lane >> 5, q = lane & 31;
+                        // first product, A = to_grid: row = grid point 32 pb + q, k = coefficient 16 ks + 8 kh + j
+                        const int p1 = 32 * pb + q, r1 = 16 * ks + 8 * kh + j;
+                        const float tv = (p1 < d.G && r1 < d.Sr) ? to_red[(size_t)p1 * d.Sr + r1] * sT : 0.f;
+                        // second product, A = from_grid^T: row = coefficient q, k = grid point in accumulator-row order
+                        const int p2 = 32 * pb + 16 * ks + 8 * (j >> 2) + 4 * kh + (j & 3), r2 = q;
+                        const float fv = (p2 < d.G && r2 < d.Sr) ? from_red[(size_t)p2 * d.Sr + r2] * sF : 0.f;
+                        const size_t base = ((size_t)(pb * 2 + ks) * 2) * 64;
+                        const _Float16 th = (_Float16)tv, fh = (_Float16)fv;
+                        img[((base + lane) * 8) + j] = th;
+                        img[((base + 64 + lane) * 8) + j] = (_Float16)(tv - (float)th);
+                        img[((nh8 + base + lane) * 8) + j] = fh;
+                        img[((nh8 + base + 64 + lane) * 8) + j] = (_Float16)(fv - (float)fh);
+                    }
+        unsigned char* dev = nullptr;
+        ADF_TRY(eq_alloc(&dev, img.size() * 2));
+        ADF_HIP_CHECK(hipMemcpy(dev, img.data(), img.size() * 2, hipMemcpyHostToDevice));
+        h->s2tab = dev; h->s2_npb = npb; h->s2_inv_sT = 1.0f / sT; h->s2_inv_sF = 1.0f / sF;
+        h->s2_gain_shift = ldexpf(1.0f, -ge);
+    }
     h->consts_set = true;
     return ADF_OK;
 }
@@ -328,7 +377,7 @@ static size_t eq_arena_floats_per_edge(const eq_dims& d) {
     const size_t extra = (size_t)d.NH * d.A + d.Hd;
     size_t y = extra + (size_t)(d.L + 1) * d.Hd, z = (size_t)(d.L + 1) * d.HV;
     for (int m = 1; m <= d.M; ++m) { const size_t nm = d.L - m + 1; y += 4 * nm * d.Hd; z += 4 * nm * d.HV; }
-    return 2 * (size_t)d.EC + (size_t)d.RW * 2 * d.C + (size_t)d.Sr * 2 * d.C + y + d.NH + (size_t)d.Sr * d.Hd + z + 16;
+    return 2 * (size_t)d.EC + (size_t)d.RW * 2 * d.C + (size_t)d.Sr * 2 * d.C + y + d.NH + (size_t)d.Sr * d.Hd + z + 2 * (size_t)d.M + 1 + 32;
 }
 
 static int32_t eq_ensure_capacity(adf_eqv2* h, int64_t N, int64_t B, int64_t Eneed) {
@@ -417,14 +466,16 @@ extern "C" int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, cons
 
 // ---------------------------------------------------------------------------------------------- dense product dispatch
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
-                float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s) {
+                float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s,
+                const float* rs_pre) {
     const eq_rowmap a1 = {lda, 1, 0}, c1 = {ldc, 1, 0};
     const eq_rowmap* am = amap ? amap : &a1;
     const eq_rowmap* cm = cmap ? cmap : &c1;
-    if (!h->exact_f32 && W->has16 && M <= h->rs_cap && eq_gemm16_ok(A, am, Cm, cm, W->out, W->in)) {
-        // per-row power-of-two lift of A (eqv2_gemm16.hip), then the f16x3 product
-        ADF_TRY(eq_launch_rowscale(A, am, M, W->in, h->rs, s));
-        return eq_launch_gemm16(A, am, h->rs, &W->w16, use_bias ? W->b : nullptr, Cm, cm, M, W->out, W->in, act, accumulate, s);
+    if (!h->exact_f32 && W->has16 && (rs_pre || M <= h->rs_cap) && eq_gemm16_ok(A, am, Cm, cm, W->out, W->in)) {
+        // per-row power-of-two lift of A (eqv2_gemm16.hip; rs_pre: already written by the producer of A), then the product
+        if (!rs_pre) ADF_TRY(eq_launch_rowscale(A, am, M, W->in, h->rs, s));
+        return eq_launch_gemm16(A, am, rs_pre ? rs_pre : h->rs, &W->w16, use_bias ? W->b : nullptr, Cm, cm, M, W->out, W->in,
+                                act, accumulate, s);
     }
     return eq_gemm_f32(A, lda, amap, W->w, use_bias ? W->b : nullptr, Cm, ldc, cmap, M, W->out, W->in, act, accumulate, s);
 }
@@ -436,6 +487,7 @@ struct eq_chunk_bufs {
     float* y[EQ_MAX_M + 1];
     float* mb[EQ_MAX_M + 1];
     float* z[EQ_MAX_M + 1];
+    float* rsb[EQ_MAX_M + 1];  // power-of-two lifts of the rows of mb[m] (written by the S2 activation)
 };
 
 static void eq_carve(const adf_eqv2* h, long long Eub, eq_chunk_bufs* b) {
@@ -452,6 +504,7 @@ static void eq_carve(const adf_eqv2* h, long long Eub, eq_chunk_bufs* b) {
         b->y[m] = take(rows * (m == 0 ? extra + nm * d.Hd : 2 * nm * d.Hd));
         b->mb[m] = take(rows * nm * d.Hd);
         b->z[m] = take(rows * (m == 0 ? nm * d.HV : 2 * nm * d.HV));
+        b->rsb[m] = take(rows);
     }
     b->y0 = b->y[0]; b->z0 = b->z[0];
 }
@@ -489,13 +542,15 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
                                 nullptr, 2 * Eub, 0, false, s));
         }
         { eq_prof_scope ps(h, EQ_PROF_ATTN, s); ADF_TRY(eq_launch_alpha(h, at, b.y[0], at->c1_m0.out, n0, n1, b.alpha, s)); }
-        { eq_prof_scope ps(h, EQ_PROF_S2ACT, s); ADF_TRY(eq_launch_s2act(h, b.y[0], b.y, extra, d.NH * d.A, n0, n1, b.mb, s)); }
+        bool rs_ok = false;
+        { eq_prof_scope ps(h, EQ_PROF_S2ACT, s); ADF_TRY(eq_launch_s2act(h, b.y[0], b.y, extra, d.NH * d.A, n0, n1, b.mb, b.rsb, &rs_ok, s)); }
         {
             eq_prof_scope ps(h, EQ_PROF_CONV, s);
-            ADF_TRY(eq_gemm(h, b.mb[0], at->c2_m0.in, nullptr, &at->c2_m0, true, b.z[0], at->c2_m0.out, nullptr, Eub, 0, false, s));
+            ADF_TRY(eq_gemm(h, b.mb[0], at->c2_m0.in, nullptr, &at->c2_m0, true, b.z[0], at->c2_m0.out, nullptr, Eub, 0, false, s,
+                            rs_ok ? b.rsb[0] : nullptr));
             for (int m = 1; m <= d.M; ++m)
                 ADF_TRY(eq_gemm(h, b.mb[m], at->c2_m[m - 1].in, nullptr, &at->c2_m[m - 1], false, b.z[m], at->c2_m[m - 1].out,
-                                nullptr, 2 * Eub, 0, false, s));
+                                nullptr, 2 * Eub, 0, false, s, rs_ok ? b.rsb[m] : nullptr));
         }
         { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_out(h, b.z, b.alpha, n0, n1, agg, only_l1, s)); }
     }

@@ -492,16 +492,201 @@ __global__ __launch_bounds__(256) void eq_s2act_kernel(const float* __restrict__
     }
 }
 
+// ---- matrix-core version.  Per edge (one wave): G = T . in (M = grid point, K = coefficient, N = hidden channel),
+// SiLU on the accumulators, out = F^T . silu(G) (M = coefficient, K = grid point, N = channel) with G's accumulator tile
+// taken as the B operand of the second product without leaving the registers (its k order is the accumulator's row
+// order, the constant operand is laid out to match).  f16x3 split products; the edge's inputs are lifted by a power
+// of two chosen from the edge's own maximum (row-local: results do not depend on the batch), the SiLU outputs by
+// that lift over a bound of the grid transform's gain.  Constant operands (fp16 hi/lo, fragment order) live in LDS.
+typedef float eqf32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 eqhalf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float eq_pow2_lift(float mx) {
+    // 2^e such that mx 2^e in [2^14, 2^15); 1 for mx == 0 or non-finite
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(mx, &e);
+    e = 15 - e;
+    e = e > 120 ? 120 : (e < -120 ? -120 : e);
+    return ldexpf(1.0f, e);
+}
+
+// where the m-major reduced coefficient r of an SO(2) convolution's output lives: value = base[o1] + sg * base[o2] with
+// base = the edge's first row in the order-m buffer (m = 0: y0 + el * ld0)
+struct eq_rdesc { int m, o1, o2; float sg; };
+
+template <int NBK>
+__global__ __launch_bounds__(512, 2) void eq_s2act_mfma_kernel(const float* __restrict__ y0, int ld0, int off0, int gate_off,
+                                                               eq_ptrs ym, const int32_t* __restrict__ eptr, int n0, int n1,
+                                                               const eq_dims* __restrict__ dg, int Sr, int L, int M, int Hd,
+                                                               const eqhalf8* __restrict__ tabs, int npb, float inv_sT,
+                                                               float inv_sF, float gain_shift, eq_ptrs mb) {
+    extern __shared__ eqhalf8 tab[];  // TA [npb][2 ks][hi|lo][64], then FA likewise
+    __shared__ eq_rdesc rdesc[32];    // input side, by coefficient r
+    __shared__ int4 odesc[32];        // output side, by coefficient r': (m, row sign, column base, -)
+    __shared__ const float* in_ptr[EQ_MAX_M + 1];
+    __shared__ float* out_ptr[EQ_MAX_M + 1];
+    const int ntab = npb * 2 * 2 * 64;
+    for (int t = threadIdx.x; t < 2 * ntab; t += 512) tab[t] = tabs[t];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + EQ_MAX_M + 1) {
+        const int m = threadIdx.x - 64;
+        in_ptr[m] = m == 0 ? y0 : ym.p[m <= M ? m : 0];
+        out_ptr[m] = mb.p[m <= M ? m : 0];
+    }
+    if (threadIdx.x < 32) {
+        const int r = threadIdx.x;
+        eq_rdesc q = {-1, 0, 0, 0.f};
+        int4 o = make_int4(-1, 0, 0, 0);
+        if (r < Sr) {
+            const int m = dg->r_m[r], l = dg->r_l[r], sg = dg->r_sgn[r];
+            const int nm = L - m + 1, half = nm * Hd, W = 2 * half, c0 = (l - m) * Hd;
+            q.m = m;
+            if (m == 0) { q.o1 = off0 + l * Hd; q.o2 = q.o1; q.sg = 0.f; }
+            else if (sg == 0) { q.o1 = c0; q.o2 = W + half + c0; q.sg = -1.f; }
+            else { q.o1 = W + c0; q.o2 = half + c0; q.sg = 1.f; }
+            o = make_int4(m, sg, c0, m == 0 ? 0 : 2 * m - 1 + sg);
+        }
+        rdesc[r] = q;
+        odesc[r] = o;
+    }
+    __syncthreads();
+    const eqhalf8* TA = tab;
+    const eqhalf8* FA = tab + ntab;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cl = lane & 31, kh = lane >> 5;
+    const long long ebase = eptr[n0];
+    const long long Ec = eptr[n1] - ebase;
+    // one wave per (edge, block of 32 hidden channels)
+    const int nblk = Hd >> 5;
+    for (long long item = (long long)blockIdx.x * 8 + wave; item < Ec * nblk; item += (long long)gridDim.x * 8) {
+        const long long el = item / nblk;
+        const int cb = (int)(item - el * nblk) * 32;
+        const float* base0 = y0 + (size_t)el * ld0;
+        eqhalf8 b1h[NBK][2], b1l[NBK][2];
+        float lift;
+        {
+            float vin[NBK][2][8];
+            float mx = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const eq_rdesc q = rdesc[16 * ks + 8 * kh + j];
+                    const int nm = L - q.m + 1;
+                    const float* bp = q.m <= 0 ? base0 : in_ptr[q.m] + (size_t)(2 * el) * (2 * nm * Hd);
+#pragma unroll
+                    for (int nb = 0; nb < NBK; ++nb) {
+                        const int c = cb + 32 * nb + cl;
+                        const float v = q.m < 0 ? 0.f : bp[q.o1 + c] + q.sg * bp[q.o2 + c];
+                        vin[nb][ks][j] = v;
+                        mx = fmaxf(mx, fabsf(v));
+                    }
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            lift = eq_pow2_lift(mx);
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float sv = vin[nb][ks][j] * lift;
+                        const _Float16 hh = (_Float16)sv;
+                        b1h[nb][ks][j] = hh;
+                        b1l[nb][ks][j] = (_Float16)(sv - (float)hh);
+                    }
+        }
+        const float lift2 = lift * gain_shift;  // SiLU outputs: |silu(g)| <= |g| <= gain * max|in|
+        eqf32x16 acc2[NBK];
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
+        const float sc1 = inv_sT / lift;
+        for (int pb = 0; pb < npb; ++pb) {
+            eqf32x16 acc1[NBK];
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[nb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const eqhalf8 ah = TA[((pb * 2 + ks) * 2 + 0) * 64 + lane];
+                const eqhalf8 al = TA[((pb * 2 + ks) * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb) {
+                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h[nb][ks], acc1[nb], 0, 0, 0);
+                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l[nb][ks], acc1[nb], 0, 0, 0);
+                    acc1[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h[nb][ks], acc1[nb], 0, 0, 0);
+                }
+            }
+            eqhalf8 b2h[NBK][2], b2l[NBK][2];
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float g = acc1[nb][r] * sc1;
+                    const float sv = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * lift2;
+                    const _Float16 hh = (_Float16)sv;
+                    b2h[nb][r >> 3][r & 7] = hh;
+                    b2l[nb][r >> 3][r & 7] = (_Float16)(sv - (float)hh);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const eqhalf8 fh = FA[((pb * 2 + ks) * 2 + 0) * 64 + lane];
+                const eqhalf8 fl = FA[((pb * 2 + ks) * 2 + 1) * 64 + lane];
+#pragma unroll
+                for (int nb = 0; nb < NBK; ++nb) {
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, b2h[nb][ks], acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, b2l[nb][ks], acc2[nb], 0, 0, 0);
+                    acc2[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, b2h[nb][ks], acc2[nb], 0, 0, 0);
+                }
+            }
+        }
+        const float sc2 = inv_sF / lift2;
+        // outputs (row r' = (reg & 3) + 8 (reg >> 2) + 4 kh), the l = 0 row replaced by SiLU of the scalar gate
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int4 o = odesc[(r & 3) + 8 * (r >> 2) + 4 * kh];
+            if (o.x < 0) continue;
+            const int nm = L - o.x + 1;
+            const long long row = o.x == 0 ? el : 2 * el + o.y;
+            float* dst = out_ptr[o.x] + (size_t)row * nm * Hd + o.z;
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+                const int c = cb + 32 * nb + cl;
+                float v = acc2[nb][r] * sc2;
+                if (r == 0 && kh == 0) v = eq_silu(base0[gate_off + c]);
+                dst[c] = v;
+            }
+        }
+    }
+}
+
 int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,
-                        float* const* mbp, hipStream_t s) {
+                        float* const* mbp, float* const* rsp, bool* rs_written, hipStream_t s) {
     const long long Eub = eq_edge_bound(h, n1 - n0);
     if (Eub <= 0) return ADF_OK;
     const eq_dims& d = h->d;
     if (d.Hd > 256) { adf_set_error("eqv2: attn_hidden_channels > 256"); return ADF_EINVAL; }
     eq_ptrs a, b;
     for (int m = 0; m <= d.M; ++m) { a.p[m] = ym[m]; b.p[m] = mbp[m]; }
-    const int epb = 256 / d.Hd;
     const int ld0 = extra + (d.L + 1) * d.Hd;
+    (void)rsp;
+    if (!h->exact_f32 && h->s2tab && d.Sr <= 32 && d.Hd % 32 == 0) {
+        const size_t dyn = (size_t)h->s2_npb * 2 * 2 * 64 * 16 * 2;
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_s2act_mfma_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(eq_s2act_mfma_kernel<1>, dim3(h->num_cus), dim3(512), dyn, s, y0, ld0, extra, gate_off, a, h->eptr,
+                           n0, n1, h->d_dev, d.Sr, d.L, d.M, d.Hd, (const eqhalf8*)h->s2tab, h->s2_npb, h->s2_inv_sT,
+                           h->s2_inv_sF, h->s2_gain_shift, b);
+        ADF_HIP_CHECK(hipGetLastError());
+        *rs_written = false;
+        return ADF_OK;
+    }
+    *rs_written = false;
+    const int epb = 256 / d.Hd;
     const unsigned grid = (unsigned)((Eub + epb - 1) / epb);
     if (d.Sr <= 32) {
         const size_t dyn = sizeof(float) * 2 * d.G * 32;
