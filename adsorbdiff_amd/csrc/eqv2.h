@@ -101,6 +101,7 @@ struct adf_eqv2 {
     float* garena; size_t garena_floats;   // grid MLP buffers of a node chunk
     float* sys;
     void* s2tab; int s2_npb; float s2_inv_sT, s2_inv_sF, s2_gain_shift;  // fragment-order fp16 hi/lo images of to_red / from_red
+    void *gtab_to, *gtab_from; int g_npb, g_nkst; float g_inv_sT, g_inv_sF;  // likewise for to_full / from_full
     float* rs; int64_t rs_cap;   // per-row lifts of the A operand of an f16x3 product
     int64_t lastN;
     // HIP-event timing per kernel group (bench.py roofline)
@@ -122,8 +123,9 @@ int32_t eq_launch_radial_pre(const adf_eqv2* h, const eq_radial* r, const float*
                              const int32_t* Z, int n0, int n1, float* out, int N, hipStream_t s);
 int32_t eq_launch_ln_silu(float* x, const float* w, const float* b, long long rows, int width, hipStream_t s);
 int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int n0, int n1, float* x, hipStream_t s);
+// rsp (optional): per-order arrays that receive the power-of-two lifts of the operand rows it writes
 int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, int n0, int n1, float* const* mbuf,
-                            hipStream_t s);
+                            float* const* rsp, hipStream_t s);
 // rsp (optional): per-order arrays that receive the power-of-two lifts of the output rows (matrix-core version only;
 // *rs_written tells whether they were filled)
 int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,

@@ -148,6 +148,8 @@ extern "C" int32_t adf_eqv2_destroy(adf_eqv2_t h) {
     eq_free(h->flags); eq_free(h->d_dev);
     eq_free(h->xe_src); eq_free(h->xe_dst); eq_free(h->xe_vec);
     { unsigned char* t = (unsigned char*)h->s2tab; eq_free(t); h->s2tab = nullptr; }
+    { unsigned char* t = (unsigned char*)h->gtab_to; eq_free(t); h->gtab_to = nullptr; }
+    { unsigned char* t = (unsigned char*)h->gtab_from; eq_free(t); h->gtab_from = nullptr; }
     eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
     eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
@@ -163,6 +165,8 @@ extern "C" int32_t adf_eqv2_set_constants(adf_eqv2_t h, const float* jd, const f
     const size_t nj = d.j_off[d.L + 1], nr = (size_t)d.G * d.Sr, nf = (size_t)d.G * d.S;
     eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
     { unsigned char* t = (unsigned char*)h->s2tab; eq_free(t); h->s2tab = nullptr; }
+    { unsigned char* t = (unsigned char*)h->gtab_to; eq_free(t); h->gtab_to = nullptr; }
+    { unsigned char* t = (unsigned char*)h->gtab_from; eq_free(t); h->gtab_from = nullptr; }
     ADF_TRY(eq_alloc(&h->jd, nj)); ADF_TRY(eq_alloc(&h->to_red, nr)); ADF_TRY(eq_alloc(&h->from_red, nr));
     ADF_TRY(eq_alloc(&h->to_full, nf)); ADF_TRY(eq_alloc(&h->from_full, nf));
     ADF_HIP_CHECK(hipMemcpy(h->jd, jd, nj * 4, hipMemcpyHostToDevice));
@@ -214,6 +218,42 @@ extern "C" int32_t adf_eqv2_set_constants(adf_eqv2_t h, const float* jd, const f
         ADF_HIP_CHECK(hipMemcpy(dev, img.data(), img.size() * 2, hipMemcpyHostToDevice));
         h->s2tab = dev; h->s2_npb = npb; h->s2_inv_sT = 1.0f / sT; h->s2_inv_sF = 1.0f / sF;
         h->s2_gain_shift = ldexpf(1.0f, -ge);
+    }
+    // and of to_full / from_full for the feed-forward grid transforms
+    if (d.S <= 64) {
+        const int npb = (d.G + 31) / 32, nkst = (d.G + 15) / 16;
+        float tmax = 0.f, fmx = 0.f;
+        for (size_t i = 0; i < nf; ++i) { tmax = fmaxf(tmax, fabsf(to_full[i])); fmx = fmaxf(fmx, fabsf(from_full[i])); }
+        auto pow2_for = [](float amax) { int e = 0; if (amax > 0.f) (void)frexpf(amax, &e); return ldexpf(1.0f, 10 - e); };
+        const float sT = pow2_for(tmax), sF = pow2_for(fmx);
+        std::vector<_Float16> ti((size_t)npb * 4 * 2 * 64 * 8), fi((size_t)nkst * 2 * 2 * 64 * 8);
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+                const int kh = lane >> 5, q = lane & 31;
+                for (int pb = 0; pb < npb; ++pb)
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const int pp = 32 * pb + q, sidx = 16 * ks + 8 * kh + j;
+                        const float v = (pp < d.G && sidx < d.S) ? to_full[(size_t)pp * d.S + sidx] * sT : 0.f;
+                        const size_t base = ((size_t)(pb * 4 + ks) * 2) * 64;
+                        const _Float16 hh = (_Float16)v;
+                        ti[(base + lane) * 8 + j] = hh;
+                        ti[(base + 64 + lane) * 8 + j] = (_Float16)(v - (float)hh);
+                    }
+                for (int kst = 0; kst < nkst; ++kst)
+                    for (int sb = 0; sb < 2; ++sb) {
+                        const int pp = 16 * kst + 8 * kh + j, sidx = 32 * sb + q;
+                        const float v = (pp < d.G && sidx < d.S) ? from_full[(size_t)pp * d.S + sidx] * sF : 0.f;
+                        const size_t base = ((size_t)(kst * 2 + sb) * 2) * 64;
+                        const _Float16 hh = (_Float16)v;
+                        fi[(base + lane) * 8 + j] = hh;
+                        fi[(base + 64 + lane) * 8 + j] = (_Float16)(v - (float)hh);
+                    }
+            }
+        unsigned char *dt = nullptr, *df = nullptr;
+        ADF_TRY(eq_alloc(&dt, ti.size() * 2)); ADF_TRY(eq_alloc(&df, fi.size() * 2));
+        ADF_HIP_CHECK(hipMemcpy(dt, ti.data(), ti.size() * 2, hipMemcpyHostToDevice));
+        ADF_HIP_CHECK(hipMemcpy(df, fi.data(), fi.size() * 2, hipMemcpyHostToDevice));
+        h->gtab_to = dt; h->gtab_from = df; h->g_npb = npb; h->g_nkst = nkst; h->g_inv_sT = 1.0f / sT; h->g_inv_sF = 1.0f / sF;
     }
     h->consts_set = true;
     return ADF_OK;
@@ -533,13 +573,15 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
         eq_chunk_bufs b;
         eq_carve(h, Eub, &b);
         ADF_TRY(eq_radial(h, &at->rad, at->src_emb, at->dst_emb, Z, n0, n1, Eub, &b, b.rad, N, s));
-        { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_in(h, y, b.rad, n0, n1, b.m, s)); }
+        const bool lifts = !h->exact_f32;
+        { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_in(h, y, b.rad, n0, n1, b.m, lifts ? b.rsb : nullptr, s)); }
         {
             eq_prof_scope ps(h, EQ_PROF_CONV, s);
-            ADF_TRY(eq_gemm(h, b.m[0], at->c1_m0.in, nullptr, &at->c1_m0, true, b.y[0], at->c1_m0.out, nullptr, Eub, 0, false, s));
+            ADF_TRY(eq_gemm(h, b.m[0], at->c1_m0.in, nullptr, &at->c1_m0, true, b.y[0], at->c1_m0.out, nullptr, Eub, 0, false, s,
+                            lifts ? b.rsb[0] : nullptr));
             for (int m = 1; m <= d.M; ++m)
                 ADF_TRY(eq_gemm(h, b.m[m], at->c1_m[m - 1].in, nullptr, &at->c1_m[m - 1], false, b.y[m], at->c1_m[m - 1].out,
-                                nullptr, 2 * Eub, 0, false, s));
+                                nullptr, 2 * Eub, 0, false, s, lifts ? b.rsb[m] : nullptr));
         }
         { eq_prof_scope ps(h, EQ_PROF_ATTN, s); ADF_TRY(eq_launch_alpha(h, at, b.y[0], at->c1_m0.out, n0, n1, b.alpha, s)); }
         bool rs_ok = false;

@@ -31,6 +31,16 @@
 
 __device__ __forceinline__ float eq_silu(float x) { return x / (1.0f + expf(-x)); }
 
+__device__ __forceinline__ float eq_pow2_lift(float mx) {
+    // 2^e such that mx 2^e in [2^14, 2^15); 1 for mx == 0 or non-finite
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(mx, &e);
+    e = 15 - e;
+    e = e > 120 ? 120 : (e < -120 ? -120 : e);
+    return ldexpf(1.0f, e);
+}
+
 __device__ __forceinline__ float eq_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -385,46 +395,75 @@ struct eq_ptrs { float* p[EQ_MAX_M + 1]; };
 template <int LT>
 __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __restrict__ rad, const float* __restrict__ wig,
                                     const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src,
-                                    const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb) {
+                                    const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb, eq_ptrs rs) {
+    __shared__ unsigned int smax[2 * EQ_MAX_M + 1];  // |.| maxima of the edge's operand rows (bit patterns order like floats)
     const long long ebase = eptr[n0];
     const long long e = ebase + blockIdx.x;
     if (e >= eptr[n1]) return;
     const int c = threadIdx.x, C2 = 2 * d.C;
-    if (c >= C2) return;
+    const bool on = c < C2;
+    if (threadIdx.x < 2 * EQ_MAX_M + 1) smax[threadIdx.x] = 0u;
+    __syncthreads();
     const long long el = e - ebase;
-    const int node = c < d.C ? e_src[e] : e_dst[e];
-    const float* yr = y + (size_t)node * d.S * d.C + (c < d.C ? c : c - d.C);
-    const float* D = wig + (size_t)e * d.DR;
-    const float* rr = rad + (size_t)el * d.RW * C2;
+    float rmx[2 * LT + 1];
 #pragma unroll
-    for (int l = 0; l <= LT; ++l) {
-        float v[2 * LT + 1];
+    for (int t = 0; t < 2 * LT + 1; ++t) rmx[t] = 0.f;
+    if (on) {
+        const int node = c < d.C ? e_src[e] : e_dst[e];
+        const float* yr = y + (size_t)node * d.S * d.C + (c < d.C ? c : c - d.C);
+        const float* D = wig + (size_t)e * d.DR;
+        const float* rr = rad + (size_t)el * d.RW * C2;
 #pragma unroll
-        for (int m = 0; m < 2 * l + 1; ++m) v[m] = yr[(size_t)(l * l + m) * d.C];
-        const int ml = l < d.M ? l : d.M;
-        const float* Dl = D + d.d_off[l];
-        for (int ri = 0; ri < 2 * ml + 1; ++ri) {
-            float a = 0.f;
+        for (int l = 0; l <= LT; ++l) {
+            float v[2 * LT + 1];
 #pragma unroll
-            for (int m = 0; m < 2 * l + 1; ++m) a += Dl[ri * (2 * l + 1) + m] * v[m];
-            const int mp = ri - ml, am = mp < 0 ? -mp : mp;
-            const int nm = LT - am + 1;
-            a *= rr[(size_t)(d.rad_off[am] + (l - am)) * C2 + c];
-            const long long row = am == 0 ? el : 2 * el + (mp < 0 ? 1 : 0);
-            mb.p[am][(size_t)row * nm * C2 + (size_t)(l - am) * C2 + c] = a;
+            for (int m = 0; m < 2 * l + 1; ++m) v[m] = yr[(size_t)(l * l + m) * d.C];
+            const int ml = l < d.M ? l : d.M;
+            const float* Dl = D + d.d_off[l];
+#pragma unroll
+            for (int mp = -l; mp <= l; ++mp) {  // compile-time order: the row-maximum slot is a constant
+                const int am = mp < 0 ? -mp : mp;
+                if (am > ml) continue;
+                const int ri = mp + ml;
+                float a = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2 * l + 1; ++m) a += Dl[ri * (2 * l + 1) + m] * v[m];
+                const int nm = LT - am + 1;
+                a *= rr[(size_t)(d.rad_off[am] + (l - am)) * C2 + c];
+                const long long row = am == 0 ? el : 2 * el + (mp < 0 ? 1 : 0);
+                mb.p[am][(size_t)row * nm * C2 + (size_t)(l - am) * C2 + c] = a;
+                rmx[am == 0 ? 0 : 2 * am - 1 + (mp < 0 ? 1 : 0)] = fmaxf(rmx[am == 0 ? 0 : 2 * am - 1 + (mp < 0 ? 1 : 0)], fabsf(a));
+            }
         }
+    }
+    if (rs.p[0]) {
+#pragma unroll
+        for (int t = 0; t < 2 * LT + 1; ++t) {
+            if (t >= 2 * d.M + 1) break;
+            float v = rmx[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+            if ((threadIdx.x & 63) == 0) atomicMax(&smax[t], __float_as_uint(v));
+        }
+    }
+    if (!rs.p[0]) return;
+    __syncthreads();
+    if (threadIdx.x < 2 * d.M + 1) {
+        const int t = threadIdx.x, m = (t + 1) >> 1;
+        const long long row = m == 0 ? el : 2 * el + ((t + 1) & 1);
+        rs.p[m][row] = eq_pow2_lift(__uint_as_float(smax[t]));
     }
 }
 
 int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, int n0, int n1, float* const* mbuf,
-                            hipStream_t s) {
+                            float* const* rsp, hipStream_t s) {
     const long long Eub = eq_edge_bound(h, n1 - n0);
     if (Eub <= 0) return ADF_OK;
-    eq_ptrs mb;
-    for (int m = 0; m <= h->d.M; ++m) mb.p[m] = mbuf[m];
+    eq_ptrs mb, rs;
+    for (int m = 0; m <= EQ_MAX_M; ++m) { mb.p[m] = m <= h->d.M ? mbuf[m] : nullptr; rs.p[m] = (rsp && m <= h->d.M) ? rsp[m] : nullptr; }
     const int bd = (2 * h->d.C + 63) / 64 * 64;
 #define EQ_RI(LT_) hipLaunchKernelGGL(eq_rotate_in_kernel<LT_>, dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
-                                      h->e_src, h->e_dst, n0, n1, h->d, mb)
+                                      h->e_src, h->e_dst, n0, n1, h->d, mb, rs)
     EQ_FOR_L(h->d.L, EQ_RI)
 #undef EQ_RI
     ADF_HIP_CHECK(hipGetLastError());
@@ -501,15 +540,6 @@ __global__ __launch_bounds__(256) void eq_s2act_kernel(const float* __restrict__
 typedef float eqf32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 eqhalf8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float eq_pow2_lift(float mx) {
-    // 2^e such that mx 2^e in [2^14, 2^15); 1 for mx == 0 or non-finite
-    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
-    int e;
-    (void)frexpf(mx, &e);
-    e = 15 - e;
-    e = e > 120 ? 120 : (e < -120 ? -120 : e);
-    return ldexpf(1.0f, e);
-}
 
 // where the m-major reduced coefficient r of an SO(2) convolution's output lives: value = base[o1] + sg * base[o2] with
 // base = the edge's first row in the order-m buffer (m = 0: y0 + el * ld0)
@@ -712,52 +742,62 @@ int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, in
 // transformer_block.py:312-345: per head LayerNorm over the alpha channels, smooth leaky ReLU, dot with alpha_dot,
 // softmax over the edges that share a target (torch_geometric.utils.softmax: exp(a - max) / (sum + 1e-16)).
 // One workgroup per target; thread = (edge of the segment, head).
-#define EQ_MAXDEG 128
-__global__ __launch_bounds__(256) void eq_alpha_kernel(const float* __restrict__ y0, int ldy, const int32_t* __restrict__ eptr,
-                                                       int n0, int n1, const float* __restrict__ lnw,
-                                                       const float* __restrict__ lnb, const float* __restrict__ adot,
-                                                       int NH, int A, float* __restrict__ alpha, int32_t* flags) {
-    __shared__ float lg[EQ_MAXDEG * 16];
-    const int n = n0 + blockIdx.x;
-    if (n >= n1) return;
-    const long long ebase = eptr[n0], e0 = eptr[n];
-    int deg = (int)(eptr[n + 1] - e0);
-    if (deg > EQ_MAXDEG) { if (threadIdx.x == 0) atomicExch(&flags[3], 1); deg = EQ_MAXDEG; }
-    for (int t = threadIdx.x; t < deg * NH; t += blockDim.x) {
-        const int k = t / NH, hd = t - k * NH;
-        const float* v = y0 + (size_t)(e0 + k - ebase) * ldy + hd * A;
+// Two kernels: (1) one wave per edge: lanes over the alpha channels of one head at a time (coalesced reads of the
+// convolution's extra scalars), wave reductions for mean / variance / dot -> logits [E, NH]; (2) one thread per
+// (target, head): softmax over the target's CSR segment, edges in order (run-to-run identical).
+__global__ __launch_bounds__(256) void eq_alpha_logit_kernel(const float* __restrict__ y0, int ldy,
+                                                             const int32_t* __restrict__ eptr, int n0, int n1,
+                                                             const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                             const float* __restrict__ adot, int NH, int A,
+                                                             float* __restrict__ logit) {
+    const long long ebase = eptr[n0];
+    const long long el = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (ebase + el >= eptr[n1]) return;
+    const float* row = y0 + (size_t)el * ldy;
+    for (int hd = 0; hd < NH; ++hd) {
+        const float* v = row + hd * A;
         float sum = 0.f;
-        for (int a = 0; a < A; ++a) sum += v[a];
-        const float mean = sum / A;
+        for (int a = lane; a < A; a += 64) sum += v[a];
+        const float mean = eq_wave_sum(sum) / A;
         float q = 0.f;
-        for (int a = 0; a < A; ++a) { const float u = v[a] - mean; q += u * u; }
-        const float rstd = rsqrtf(q / A + 1e-5f);
+        for (int a = lane; a < A; a += 64) { const float u = v[a] - mean; q += u * u; }
+        const float rstd = rsqrtf(eq_wave_sum(q) / A + 1e-5f);
         float acc = 0.f;
-        for (int a = 0; a < A; ++a) {
+        for (int a = lane; a < A; a += 64) {
             const float u = (v[a] - mean) * rstd * lnw[a] + lnb[a];
             // SmoothLeakyReLU(0.2): (1 + a)/2 x + (1 - a)/2 x (2 sigmoid(x) - 1)   (activation.py:30-45)
             const float sl = 0.6f * u + 0.4f * u * (2.0f / (1.0f + expf(-u)) - 1.0f);
             acc += sl * adot[hd * A + a];
         }
-        lg[t] = acc;
+        acc = eq_wave_sum(acc);
+        if (lane == 0) logit[(size_t)el * NH + hd] = acc;
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < deg * NH; t += blockDim.x) {
-        const int k = t / NH, hd = t - k * NH;
-        float mx = -3.0e38f;
-        for (int kk = 0; kk < deg; ++kk) mx = fmaxf(mx, lg[kk * NH + hd]);
-        float den = 0.f;
-        for (int kk = 0; kk < deg; ++kk) den += expf(lg[kk * NH + hd] - mx);
-        alpha[(size_t)(e0 + k - ebase) * NH + hd] = expf(lg[t] - mx) / (den + 1e-16f);
-    }
+}
+
+__global__ void eq_alpha_softmax_kernel(float* __restrict__ alpha, const int32_t* __restrict__ eptr, int n0, int n1, int NH) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = n0 + (int)(t / NH), hd = (int)(t % NH);
+    if (n >= n1) return;
+    const long long ebase = eptr[n0], e0 = eptr[n] - ebase, e1 = eptr[n + 1] - ebase;
+    float mx = -3.0e38f;
+    for (long long e = e0; e < e1; ++e) mx = fmaxf(mx, alpha[(size_t)e * NH + hd]);
+    float den = 0.f;
+    for (long long e = e0; e < e1; ++e) den += expf(alpha[(size_t)e * NH + hd] - mx);
+    const float inv = 1.0f / (den + 1e-16f);
+    for (long long e = e0; e < e1; ++e) alpha[(size_t)e * NH + hd] = expf(alpha[(size_t)e * NH + hd] - mx) * inv;
 }
 
 int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, int ldy, int n0, int n1, float* alpha,
                         hipStream_t s) {
     if (n1 <= n0) return ADF_OK;
     if (h->d.NH > 16) { adf_set_error("eqv2: more than 16 heads"); return ADF_EINVAL; }
-    hipLaunchKernelGGL(eq_alpha_kernel, dim3(n1 - n0), dim3(256), 0, s, y0, ldy, h->eptr, n0, n1, at->alpha_ln_w,
-                       at->alpha_ln_b, at->alpha_dot, h->d.NH, h->d.A, alpha, h->flags);
+    const long long Eub = eq_edge_bound(h, n1 - n0);
+    hipLaunchKernelGGL(eq_alpha_logit_kernel, dim3((unsigned)((Eub + 3) / 4)), dim3(256), 0, s, y0, ldy, h->eptr, n0, n1,
+                       at->alpha_ln_w, at->alpha_ln_b, at->alpha_dot, h->d.NH, h->d.A, alpha);
+    const long long nt = (long long)(n1 - n0) * h->d.NH;
+    hipLaunchKernelGGL(eq_alpha_softmax_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, alpha, h->eptr, n0, n1,
+                       h->d.NH);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
@@ -901,8 +941,135 @@ __global__ void eq_from_grid_kernel(const float* __restrict__ g, const float* __
     for (int s = 1; s < S; ++s) hr[(size_t)s * d.F] = acc[s];
 }
 
+// ---- matrix-core versions (f16x3 split, constant operands as fp16 hi/lo fragment images in LDS, one wave per
+// (node, block of 32 hidden channels), power-of-two lift from that item's own maximum).
+//   to grid:   G[p, f] = sum_s T[p, s] h1[s, f]      A = T (M = grid point, K = coefficient, 4 k-steps), B from memory
+//   from grid: out[s, f] = sum_p F[p, s] g[p, f]     A = F^T (M = coefficient, 2 blocks; K = grid point), B from memory
+__global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __restrict__ h1, const eqhalf8* __restrict__ tabs,
+                                                                  int npb, float inv_sT, int n0, int n1, int S, int F, int G,
+                                                                  float* __restrict__ g) {
+    extern __shared__ eqhalf8 tab[];  // [npb][4 ks][hi|lo][64]
+    const int ntab = npb * 4 * 2 * 64;
+    for (int t = threadIdx.x; t < ntab; t += 512) tab[t] = tabs[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, kh = lane >> 5;
+    const int nblk = F >> 5;
+    const long long items = (long long)(n1 - n0) * nblk;
+    for (long long item = (long long)blockIdx.x * 8 + wave; item < items; item += (long long)gridDim.x * 8) {
+        const int n = n0 + (int)(item / nblk), f = (int)(item % nblk) * 32 + cl;
+        const float* hr = h1 + (size_t)n * S * F + f;
+        float vin[4][8];
+        float mx = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sidx = 16 * ks + 8 * kh + j;
+                const float v = sidx < S ? hr[(size_t)sidx * F] : 0.f;
+                vin[ks][j] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float lift = eq_pow2_lift(mx);
+        eqhalf8 bh[4], bl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float sv = vin[ks][j] * lift;
+                const _Float16 hh = (_Float16)sv;
+                bh[ks][j] = hh;
+                bl[ks][j] = (_Float16)(sv - (float)hh);
+            }
+        const float sc = inv_sT / lift;
+        float* gr = g + (size_t)(n - n0) * G * F + f;
+        for (int pb = 0; pb < npb; ++pb) {
+            eqf32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const eqhalf8 ah = tab[((pb * 4 + ks) * 2 + 0) * 64 + lane];
+                const eqhalf8 al = tab[((pb * 4 + ks) * 2 + 1) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pp = 32 * pb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (pp < G) gr[(size_t)pp * F] = acc[r] * sc;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void eq_from_grid_mfma_kernel(const float* __restrict__ g, const eqhalf8* __restrict__ tabs,
+                                                                    int nkst, float inv_sF, const float* __restrict__ gate,
+                                                                    int n0, int n1, int S, int F, int G, float* __restrict__ h2) {
+    extern __shared__ eqhalf8 tab[];  // [nkst][2 sb][hi|lo][64]
+    const int ntab = nkst * 2 * 2 * 64;
+    for (int t = threadIdx.x; t < ntab; t += 512) tab[t] = tabs[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, kh = lane >> 5;
+    const int nblk = F >> 5;
+    const long long items = (long long)(n1 - n0) * nblk;
+    for (long long item = (long long)blockIdx.x * 8 + wave; item < items; item += (long long)gridDim.x * 8) {
+        const int n = n0 + (int)(item / nblk), f = (int)(item % nblk) * 32 + cl;
+        const float* gr = g + (size_t)(n - n0) * G * F + f;
+        float mx = 0.f;
+        for (int pp = kh; pp < G; pp += 2) mx = fmaxf(mx, fabsf(gr[(size_t)pp * F]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float lift = eq_pow2_lift(mx);
+        eqf32x16 acc[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
+        for (int kst = 0; kst < nkst; ++kst) {
+            eqhalf8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pp = 16 * kst + 8 * kh + j;
+                const float sv = (pp < G ? gr[(size_t)pp * F] : 0.f) * lift;
+                const _Float16 hh = (_Float16)sv;
+                bh[j] = hh;
+                bl[j] = (_Float16)(sv - (float)hh);
+            }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                const eqhalf8 ah = tab[((kst * 2 + sb) * 2 + 0) * 64 + lane];
+                const eqhalf8 al = tab[((kst * 2 + sb) * 2 + 1) * 64 + lane];
+                acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[sb], 0, 0, 0);
+                acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[sb], 0, 0, 0);
+                acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[sb], 0, 0, 0);
+            }
+        }
+        const float sc = inv_sF / lift;
+        float* hr = h2 + (size_t)n * S * F + f;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int sidx = 32 * sb + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (sidx < S) hr[(size_t)sidx * F] = sidx == 0 ? gate[(size_t)n * F + f] : acc[sb][r] * sc;
+            }
+    }
+}
+
 int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, hipStream_t s) {
     if (n1 <= n0) return ADF_OK;
+    if (!h->exact_f32 && h->gtab_to && h->d.S <= 64 && h->d.F % 32 == 0) {
+        const size_t dyn = (size_t)h->g_npb * 4 * 2 * 64 * 16;
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_to_grid_mfma_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(eq_to_grid_mfma_kernel, dim3(h->num_cus), dim3(512), dyn, s, h1, (const eqhalf8*)h->gtab_to, h->g_npb,
+                           h->g_inv_sT, n0, n1, h->d.S, h->d.F, h->d.G, g);
+        ADF_HIP_CHECK(hipGetLastError());
+        return ADF_OK;
+    }
     const int bd = (h->d.F + 63) / 64 * 64;
     const size_t dyn = sizeof(float) * h->d.G * h->d.S;
 #define EQ_TG(LT_) hipLaunchKernelGGL(eq_to_grid_kernel<LT_>, dim3(n1 - n0), dim3(bd), dyn, s, h1, h->to_full, n0, n1, h->d, g)
@@ -914,6 +1081,15 @@ int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, fl
 
 int32_t eq_launch_from_grid(const adf_eqv2* h, const float* g, const float* gate, int n0, int n1, float* h2, hipStream_t s) {
     if (n1 <= n0) return ADF_OK;
+    if (!h->exact_f32 && h->gtab_from && h->d.S <= 64 && h->d.F % 32 == 0) {
+        const size_t dyn = (size_t)h->g_nkst * 2 * 2 * 64 * 16;
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_from_grid_mfma_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(eq_from_grid_mfma_kernel, dim3(h->num_cus), dim3(512), dyn, s, g, (const eqhalf8*)h->gtab_from,
+                           h->g_nkst, h->g_inv_sF, gate, n0, n1, h->d.S, h->d.F, h->d.G, h2);
+        ADF_HIP_CHECK(hipGetLastError());
+        return ADF_OK;
+    }
     const int bd = (h->d.F + 63) / 64 * 64;
     const size_t dyn = sizeof(float) * h->d.G * h->d.S;
 #define EQ_FG(LT_) hipLaunchKernelGGL(eq_from_grid_kernel<LT_>, dim3(n1 - n0), dim3(bd), dyn, s, g, h->from_full, gate, n0, n1, h->d, h2)
