@@ -92,7 +92,7 @@ def check_graph(name, b, cutoff, K, ref_model, allow_tie_mismatch=False):
     return out
 
 
-def main():
+def main_painn():
     torch.set_num_threads(8)
 
     # ---------------------------------------------------------------- 0. known-answer vectors
@@ -441,6 +441,9 @@ def main():
     for k, v in tparams.items():
         fxt["tp_" + k] = v
     np.savez_compressed(GOLD / "train_small.npz", **npify(fxt))
+
+
+def main_eqv2():
     # ---------------------------------------------------------------- 7. EquiformerV2 denoiser
     # Groundwork only: the reference model runs on CPU under an e3nn STAND-IN (oracle/refshim/e3nn_standin.py:
     # parity UNPINNED for the S2-grid normalisation, see its docstring), checked for consistency with the vendored
@@ -469,15 +472,37 @@ def main():
     assert wdiff < 5e-6
     assert chk["equivariance_max_abs"] < 1e-12 and all(v < 1e-5 for k, v in chk.items() if k.startswith("roundtrip"))
     be = make_batch(2, n_slab=16, n_ads=3, seed=3)
-    for lmax_, mmax_ in ((4, 2), (6, 2)):
+    from adsorbdiff_amd.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos as MyEqV2
+
+    # (name, lmax, mmax, layers, C, hidden, heads, alpha, value, ffn, edge channels, scale of the atom edge embeddings)
+    # "w32": every contraction length of the dense products is a multiple of 32 (the shapes the f16x3 matrix-core
+    # kernels take); its edge embeddings are lifted from the 1e-3 initialisation to trained-like magnitudes
+    cases = (("eqv2_l4m2", 4, 2, 2, 8, 8, 2, 4, 4, 16, 8, 1.0), ("eqv2_l6m2", 6, 2, 2, 8, 8, 2, 4, 4, 16, 8, 1.0),
+             ("eqv2_l6m2_w32", 6, 2, 1, 16, 32, 2, 16, 16, 32, 32, 300.0))
+    for name_, lmax_, mmax_, nl_, C_, hid_, nh_, al_, va_, ffn_, ec_, emb_scale in cases:
+        kw = dict(max_neighbors=20, max_radius=6.0, max_num_elements=90, num_layers=nl_, sphere_channels=C_,
+                  attn_hidden_channels=hid_, num_heads=nh_, attn_alpha_channels=al_, attn_value_channels=va_,
+                  ffn_hidden_channels=ffn_, norm_type="layer_norm_sh", lmax_list=[lmax_], mmax_list=[mmax_],
+                  grid_resolution=18, edge_channels=ec_, num_distance_basis=16, attn_activation="silu",
+                  ffn_activation="silu", use_s2_act_attn=False, use_attn_renorm=True, use_gate_act=False,
+                  use_grid_mlp=True, use_sep_s2_act=True, alpha_drop=0.0, drop_path_rate=0.0, proj_drop=0.0,
+                  weight_init="uniform", FOR_denoising=True)
         torch.manual_seed(0)
-        eq = RefEqV2(None, None, None, max_neighbors=20, max_radius=6.0, max_num_elements=90, num_layers=2,
-                     sphere_channels=8, attn_hidden_channels=8, num_heads=2, attn_alpha_channels=4, attn_value_channels=4,
-                     ffn_hidden_channels=16, norm_type="layer_norm_sh", lmax_list=[lmax_], mmax_list=[mmax_],
-                     grid_resolution=18, edge_channels=8, num_distance_basis=16, attn_activation="silu",
-                     ffn_activation="silu", use_s2_act_attn=False, use_attn_renorm=True, use_gate_act=False,
-                     use_grid_mlp=True, use_sep_s2_act=True, alpha_drop=0.0, drop_path_rate=0.0, proj_drop=0.0,
-                     weight_init="uniform", FOR_denoising=True).eval()
+        eq = RefEqV2(None, None, None, **kw).eval()
+        if emb_scale != 1.0:
+            with torch.no_grad():
+                for n_, p_ in eq.named_parameters():
+                    if n_.endswith("source_embedding.weight") or n_.endswith("target_embedding.weight"):
+                        p_.mul_(emb_scale)
+        # the host mirror exposes the same parameters (names and shapes) and loads the reference's state_dict
+        mine = MyEqV2(None, None, None, **kw)
+        ref_params = {k: tuple(v.shape) for k, v in eq.named_parameters()}
+        my_params = {k: tuple(v.shape) for k, v in mine.named_parameters()}
+        assert ref_params == my_params, set(ref_params.items()) ^ set(my_params.items())
+        mine.load_state_dict(eq.state_dict())
+        assert all(torch.equal(v, dict(eq.named_parameters())[k]) or (k == "atom_radii") for k, v in mine.named_parameters())
+        rr, mr = eq.atom_radii.detach(), mine.atom_radii.detach()
+        assert torch.equal(torch.isnan(rr), torch.isnan(mr)) and torch.equal(torch.nan_to_num(rr), torch.nan_to_num(mr))
         bad = set(torch.nonzero(torch.isnan(eq.atom_radii)).flatten().tolist())
         safe = torch.tensor([z for z in range(20, 80) if z not in bad])
         bq = be.clone()
@@ -485,11 +510,22 @@ def main():
         zz = bq.atomic_numbers.clone()
         zz[bq.tags < 2] = safe[torch.randint(0, len(safe), (int((bq.tags < 2).sum()),), generator=gz)].float()
         bq.atomic_numbers = zz
+        # node embeddings after the edge-degree embedding and after every block, recorded on the reference's own modules
+        rec = {}
+        hooks = [eq.edge_degree_embedding.register_forward_hook(lambda m_, i_, o_: rec.__setitem__("ed", o_.embedding.detach().clone()))]
+        for bi_, blk_ in enumerate(eq.blocks):
+            hooks.append(blk_.register_forward_hook(lambda m_, i_, o_, bi_=bi_: rec.__setitem__(bi_, o_.embedding.detach().clone())))
         outs = []
         for gauge_seed in (1, 2):
             torch.manual_seed(gauge_seed)
             with torch.no_grad():
                 outs.append(eq(bq.clone()))
+            if gauge_seed == 1:
+                x0 = rec["ed"].clone()
+                x0[:, 0] = x0[:, 0] + eq.sphere_embedding(bq.atomic_numbers.long()).detach()
+                xb = torch.stack([x0] + [rec[i] for i in range(nl_)])
+        for h_ in hooks:
+            h_.remove()
         f1e, f2e = outs[0]
         gauge = float((outs[0][0] - outs[1][0]).abs().max() / f1e.abs().max())
         assert bool(torch.isfinite(f1e).all()) and gauge < 1e-5, gauge
@@ -497,8 +533,8 @@ def main():
         # oracle restatement (oracle/eqv2_oracle.py) on the reference's own edge list: in this small cell the +a / -a
         # images of an atom tie exactly at the K-th place and the reference's pick is implementation-defined
         gq = eq.generate_graph(bq.clone(), enforce_max_neighbors_strictly=True)
-        hp_q = dict(lmax=lmax_, mmax=mmax_, num_layers=2, sphere_channels=8, attn_hidden_channels=8, num_heads=2,
-                    attn_alpha_channels=4, attn_value_channels=4, ffn_hidden_channels=16, grid_resolution=18,
+        hp_q = dict(lmax=lmax_, mmax=mmax_, num_layers=nl_, sphere_channels=C_, attn_hidden_channels=hid_, num_heads=nh_,
+                    attn_alpha_channels=al_, attn_value_channels=va_, ffn_hidden_channels=ffn_, grid_resolution=18,
                     max_radius=6.0, max_neighbors=20)
         sd_q = {k: v.detach().clone() for k, v in eq.state_dict().items()}
         with torch.no_grad():
@@ -507,25 +543,44 @@ def main():
                                     atom_radii=eq.atom_radii.detach())
         eq1 = float((q1 - f1e).norm() / f1e.norm())
         eq2 = float((q2 - f2e).norm() / f2e.norm())
-        print(f"[eqv2] L={lmax_} M={mmax_}: oracle vs reference rel err {eq1:.2e} / {eq2:.2e} "
+        print(f"[eqv2] {name_}: oracle vs reference rel err {eq1:.2e} / {eq2:.2e} "
               f"(with the tabulated radii: {float((r1 - f1e).norm() / f1e.norm()):.2e})")
         assert eq1 < 1e-5 and eq2 < 1e-5 and float((r1 - f1e).norm() / f1e.norm()) < 1e-5
         own = Q.radius_graph_pbc(bq.pos, bq.cell, bq.natoms, 6.0, 20)
         own_ei, own_d, _, _ = Q.pbc_distances(bq.pos, own[0], bq.cell, own[1], own[2])
         key = lambda ei_, d_: sorted((int(a_), int(b_), round(float(c_), 4)) for a_, b_, c_ in zip(ei_[0], ei_[1], d_))
         assert key(own_ei, own_d) == key(gq[0], gq[1])  # same edges up to the sign of tied self-images
-        fxe = dict(f1=f1e, f2=f2e, gauge_dependence=gauge, lmax=lmax_, mmax=mmax_, to_grid_mat=grid.to_grid_mat,
+        fxe = dict(f1=f1e, f2=f2e, x_blocks=xb, gauge_dependence=gauge, lmax=lmax_, mmax=mmax_, to_grid_mat=grid.to_grid_mat,
                    from_grid_mat=grid.from_grid_mat, nan_radius_elements=np.array(sorted(bad)), edge_index=gq[0],
                    edge_vec=gq[2], **batch_inputs(bq))
         pnames = {k for k, _ in eq.named_parameters()}
         fxe.update({"sd::" + k: v for k, v in eq.state_dict().items() if k in pnames and k != "atom_radii"})  # parameters only
-        fxe["hp"] = np.array("num_layers=2 sphere_channels=8 attn_hidden_channels=8 num_heads=2 attn_alpha_channels=4 "
-                             "attn_value_channels=4 ffn_hidden_channels=16 norm_type=layer_norm_sh grid_resolution=18 "
-                             "edge_channels=8 num_distance_basis=16 max_num_elements=90 max_radius=6.0 max_neighbors=20 "
-                             "attn_activation=silu ffn_activation=silu use_grid_mlp=True use_sep_s2_act=True FOR_denoising=True")
-        np.savez_compressed(GOLD / f"eqv2_l{lmax_}m{mmax_}.npz", **npify(fxe))
-        print(f"[eqv2] L={lmax_} M={mmax_}: params={sum(p.numel() for p in eq.parameters())} |f1|max={f1e.abs().max():.4f} "
+        fxe["hp"] = np.array(f"num_layers={nl_} sphere_channels={C_} attn_hidden_channels={hid_} num_heads={nh_} "
+                             f"attn_alpha_channels={al_} attn_value_channels={va_} ffn_hidden_channels={ffn_} "
+                             f"norm_type=layer_norm_sh grid_resolution=18 edge_channels={ec_} num_distance_basis=16 "
+                             "max_num_elements=90 max_radius=6.0 max_neighbors=20 attn_activation=silu ffn_activation=silu "
+                             "use_grid_mlp=True use_sep_s2_act=True FOR_denoising=True")
+        np.savez_compressed(GOLD / f"{name_}.npz", **npify(fxe))
+        print(f"[eqv2] {name_}: params={sum(p.numel() for p in eq.parameters())} |f1|max={f1e.abs().max():.4f} "
               f"gauge dependence={gauge:.2e}")
+    # the J matrices the product derives (adsorbdiff_amd/so3_math.py) against the reference's vendored table
+    from adsorbdiff.models.equiformer_v2.wigner import _Jd as ref_Jd
+
+    from adsorbdiff_amd import so3_math
+
+    for l_, j_ in enumerate(so3_math.j_matrices(6)):
+        assert float(np.abs(j_ - ref_Jd[l_].double().numpy()).max()) < 1e-12, l_
+    np.savez_compressed(GOLD / "eqv2_jd.npz", **{f"J{l_}": ref_Jd[l_].double().numpy() for l_ in range(7)})
+    print("EquiformerV2 goldens written to", GOLD)
+
+
+def main():
+    """ADF_GOLDEN_ONLY=eqv2 / painn regenerates one family (both are deterministic)."""
+    only = os.environ.get("ADF_GOLDEN_ONLY")
+    if only in (None, "", "painn"):
+        main_painn()
+    if only in (None, "", "eqv2"):
+        main_eqv2()
     print("all goldens written to", GOLD)
 
 

@@ -42,18 +42,27 @@ def model_from_fixture(fx):
     return m.to(DEV).eval()
 
 
-@pytest.mark.parametrize("name", ["eqv2_l4m2.npz", "eqv2_l6m2.npz"])
-def test_eqv2_forward_vs_reference_fixture(name):
-    """(f1, f2) of the reference model (its own edge list: exact K-th-neighbour ties in this small cell), 1e-4."""
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("name", ["eqv2_l4m2.npz", "eqv2_l6m2.npz", "eqv2_l6m2_w32.npz"])
+def test_eqv2_forward_vs_reference_fixture(name, exact):
+    """(f1, f2) and the node embeddings after the edge-degree embedding and after every block, against the reference
+    model's own recordings (its edge list: exact K-th-neighbour ties in this small cell), 1e-4.  `w32`: every
+    contraction length is a multiple of 32, the shapes the f16x3 matrix-core kernels take; `exact`: f32 arithmetic."""
     fx = load_npz(name)
     m = model_from_fixture(fx)
     b = batch_from_fixture(fx, device=DEV)
     eng = m.engine()
+    eng.set_arithmetic(exact)
     eng.set_edges(torch.from_numpy(fx["edge_index"]), torch.from_numpy(fx["edge_vec"]))
-    f1, f2 = m(b)
+    f1, f2, xb = eng.forward(b, return_blocks=True)
     e1, e2 = rel_err(f1.cpu(), fx["f1"]), rel_err(f2.cpu(), fx["f2"])
-    print(name, "rel err", e1, e2)
+    print(name, "exact" if exact else "f16x3", "rel err", e1, e2)
     assert e1 < REL_TOL and e2 < REL_TOL
+    L = int(fx["lmax"])
+    for k in range(xb.shape[0]):
+        for l in range(L + 1):
+            got, ref = xb[k, :, l * l:(l + 1) ** 2].cpu(), torch.from_numpy(fx["x_blocks"][k, :, l * l:(l + 1) ** 2])
+            assert rel_err(got, ref) < REL_TOL, (k, l, rel_err(got, ref))
     # per-atom bound: every row within 1e-4 of the largest row norm
     for got, ref in ((f1.cpu().numpy(), fx["f1"]), (f2.cpu().numpy(), fx["f2"])):
         scale = np.linalg.norm(ref, axis=1).max()
