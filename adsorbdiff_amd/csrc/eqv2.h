@@ -20,6 +20,7 @@ struct eq_radial {      // RadialFunction: Linear, LayerNorm, SiLU, Linear, Laye
     eq_lin l0, l3, l6;
     const float *ln1_w, *ln1_b, *ln4_w, *ln4_b;
     float* w0t;         // library-owned transpose of l0.w: [in, out]
+    float* table;       // [NE*NE, l6.out] radial weights per element pair (static-radial mode), else null
 };
 struct eq_norm {        // EquivariantLayerNormArraySphericalHarmonics (layer_norm.py:129-250)
     const float *affine, *l0_w, *l0_b;
@@ -81,6 +82,7 @@ struct adf_eqv2 {
     eq_attn force[2];
     unsigned char* w16_arena; size_t w16_bytes; float* w16_scales; unsigned int* w16_scratch;
     float* wt_arena; size_t wt_bytes;   // transposed first radial layers
+    float* rtab_arena; size_t rtab_floats; bool rad_static;   // per-element-pair radial tables (see eq_radial_static)
     // graph
     int64_t capN, capB, capE;
     int32_t *nbr_cnt, *nbr_src, *nbr_shift, *img_cnt, *eptr, *e_src, *e_dst, *flags;
@@ -118,14 +120,19 @@ enum { EQ_PROF_GRAPH = 0, EQ_PROF_RADIAL, EQ_PROF_ROTATE, EQ_PROF_CONV, EQ_PROF_
 int32_t eq_launch_edges_from_topk(adf_eqv2* h, const adf_batch* b, hipStream_t s);
 int32_t eq_launch_eptr_from_dst(adf_eqv2* h, int N, int64_t E, hipStream_t s);
 int32_t eq_launch_wigner(adf_eqv2* h, int N, hipStream_t s);
+int32_t eq_launch_check_z(const adf_eqv2* h, const int32_t* Z, int N, hipStream_t s);
 int32_t eq_launch_norm(const adf_eqv2* h, const eq_norm* nm, const float* x, float* y, int N, hipStream_t s);
 int32_t eq_launch_radial_pre(const adf_eqv2* h, const eq_radial* r, const float* src_emb, const float* dst_emb,
                              const int32_t* Z, int n0, int n1, float* out, int N, hipStream_t s);
 int32_t eq_launch_ln_silu(float* x, const float* w, const float* b, long long rows, int width, hipStream_t s);
-int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int n0, int n1, float* x, hipStream_t s);
+// pair_ne > 0: m0 / rad are tables with one row per element pair (Z_src * pair_ne + Z_tgt) instead of one row per edge
+int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int pair_ne, int n0, int n1, float* x,
+                              hipStream_t s);
+int32_t eq_launch_radial_pre_pairs(const adf_eqv2* h, const eq_radial* r, const float* src_emb, const float* dst_emb,
+                                   float* out, hipStream_t s);
 // rsp (optional): per-order arrays that receive the power-of-two lifts of the operand rows it writes
-int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, int n0, int n1, float* const* mbuf,
-                            float* const* rsp, hipStream_t s);
+int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, const int32_t* Z, int pair_ne, int n0, int n1,
+                            float* const* mbuf, float* const* rsp, hipStream_t s);
 // rsp (optional): per-order arrays that receive the power-of-two lifts of the output rows (matrix-core version only;
 // *rs_written tells whether they were filled)
 int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,

@@ -151,7 +151,7 @@ extern "C" int32_t adf_eqv2_destroy(adf_eqv2_t h) {
     { unsigned char* t = (unsigned char*)h->gtab_to; eq_free(t); h->gtab_to = nullptr; }
     { unsigned char* t = (unsigned char*)h->gtab_from; eq_free(t); h->gtab_from = nullptr; }
     eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
-    eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena);
+    eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena); eq_free(h->rtab_arena);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
     delete h->prof_cat;
     delete h;
@@ -352,6 +352,66 @@ static int32_t eq_split_weights(adf_eqv2* h, hipStream_t s) {
     return ADF_OK;
 }
 
+// Static-radial mode.  The Gaussian basis of an edge is exp(coeff (d - r_s - r_t - mu_k)^2) with d in (0.01, rc]; if for
+// EVERY pair of elements with finite radii the window of non-vanishing terms (|d - r_s - r_t - mu_k| < tmax,
+// eq_radial_pre_kernel) is empty for every possible d, the radial MLP of an edge depends on (Z_s, Z_t) only and is
+// tabulated once per weight binding (NE^2 rows per radial function).  With the reference's radii (pm subtracted from
+// Angstrom, equiformer_v2_denoising.py:165-213) this always holds; with radii in Angstrom it would not and every edge
+// is evaluated.  ADF_EQV2_RADIAL=edge forces the per-edge evaluation (parity tests compare both).
+static int32_t eq_radial_static(adf_eqv2* h, eq_radial** rads, int nrad, hipStream_t s) {
+    const eq_dims& d = h->d;
+    const int NE = h->hp.max_num_elements;
+    h->rad_static = false;
+    for (int i = 0; i < nrad; ++i) rads[i]->table = nullptr;
+    const char* env = getenv("ADF_EQV2_RADIAL");
+    if (env && !strcmp(env, "edge")) return ADF_OK;
+    float radii[101];
+    ADF_HIP_CHECK(hipMemcpyAsync(radii, h->atom_radii, sizeof(radii), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    const float rc = h->hp.max_radius, delta = rc / (float)(d.NB - 1);
+    const float coeff = -0.5f / ((2.0f * delta) * (2.0f * delta)), tmax = sqrtf(104.0f / -coeff);
+    for (int a = 0; a < NE && a <= 100; ++a)
+        for (int b = a; b < NE && b <= 100; ++b) {
+            const float rr = radii[a] + radii[b];
+            if (!(rr == rr)) continue;  // NaN output either way
+            const float lo = 0.0f - rr, hi = rc - rr;  // range of dd = d - r_a - r_b
+            if (hi + tmax >= 0.f && lo - tmax <= rc) return ADF_OK;  // some d reaches a basis function: per-edge mode
+        }
+    size_t total = 0;
+    for (int i = 0; i < nrad; ++i) total += (size_t)NE * NE * rads[i]->l6.out;
+    if (h->rtab_floats < total) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        eq_free(h->rtab_arena);
+        if (eq_alloc(&h->rtab_arena, total) != ADF_OK) { h->rtab_floats = 0; return ADF_OK; }  // no room: per-edge mode
+        h->rtab_floats = total;
+    }
+    float *t1 = nullptr, *t2 = nullptr, *rs = nullptr;
+    const long long rows = (long long)NE * NE;
+    ADF_TRY(eq_alloc(&t1, (size_t)rows * d.EC)); ADF_TRY(eq_alloc(&t2, (size_t)rows * d.EC)); ADF_TRY(eq_alloc(&rs, (size_t)rows));
+    float* keep_rs = h->rs; const int64_t keep_cap = h->rs_cap;
+    h->rs = rs; h->rs_cap = rows;
+    float* p = h->rtab_arena;
+    int32_t st = ADF_OK;
+    for (int i = 0; i < nrad && st == ADF_OK; ++i) {
+        eq_radial* r = rads[i];
+        const float* semb = i == 0 ? h->ed_src_emb : (i <= h->hp.num_layers ? h->blk[i - 1].ga.src_emb : h->force[i - 1 - h->hp.num_layers].src_emb);
+        const float* temb = i == 0 ? h->ed_dst_emb : (i <= h->hp.num_layers ? h->blk[i - 1].ga.dst_emb : h->force[i - 1 - h->hp.num_layers].dst_emb);
+        st = eq_launch_radial_pre_pairs(h, r, semb, temb, t1, s);
+        if (st == ADF_OK) st = eq_launch_ln_silu(t1, r->ln1_w, r->ln1_b, rows, d.EC, s);
+        if (st == ADF_OK) st = eq_gemm(h, t1, d.EC, nullptr, &r->l3, true, t2, d.EC, nullptr, rows, 0, false, s);
+        if (st == ADF_OK) st = eq_launch_ln_silu(t2, r->ln4_w, r->ln4_b, rows, d.EC, s);
+        if (st == ADF_OK) st = eq_gemm(h, t2, d.EC, nullptr, &r->l6, true, p, r->l6.out, nullptr, rows, 0, false, s);
+        r->table = p;
+        p += (size_t)rows * r->l6.out;
+    }
+    (void)hipStreamSynchronize(s);
+    h->rs = keep_rs; h->rs_cap = keep_cap;
+    eq_free(t1); eq_free(t2); eq_free(rs);
+    if (st != ADF_OK) { for (int i = 0; i < nrad; ++i) rads[i]->table = nullptr; return st; }
+    h->rad_static = true;
+    return ADF_OK;
+}
+
 extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const void* const* weights, void* stream) {
     if (!h || !weights) { adf_set_error("eqv2_set_weights: null argument"); return ADF_EINVAL; }
     const eq_dims& d = h->d;
@@ -402,6 +462,7 @@ extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const v
         ADF_TRY(eq_launch_transpose(rads[i]->l0.w, rads[i]->w0t, d.EC, d.NB + 2 * d.EC, s));
     }
     ADF_TRY(eq_split_weights(h, s));
+    ADF_TRY(eq_radial_static(h, rads, k, s));
     h->weights_set = true;
     return ADF_OK;
 }
@@ -572,9 +633,14 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
         const long long Eub = (long long)(n1 - n0) * (h->ext_graph ? h->maxdeg : h->hp.max_neighbors);
         eq_chunk_bufs b;
         eq_carve(h, Eub, &b);
-        ADF_TRY(eq_radial(h, &at->rad, at->src_emb, at->dst_emb, Z, n0, n1, Eub, &b, b.rad, N, s));
+        const bool tab = h->rad_static && at->rad.table;
+        if (!tab) ADF_TRY(eq_radial(h, &at->rad, at->src_emb, at->dst_emb, Z, n0, n1, Eub, &b, b.rad, N, s));
         const bool lifts = !h->exact_f32;
-        { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_in(h, y, b.rad, n0, n1, b.m, lifts ? b.rsb : nullptr, s)); }
+        {
+            eq_prof_scope ps(h, EQ_PROF_ROTATE, s);
+            ADF_TRY(eq_launch_rotate_in(h, y, tab ? at->rad.table : b.rad, Z, tab ? h->hp.max_num_elements : 0, n0, n1, b.m,
+                                        lifts ? b.rsb : nullptr, s));
+        }
         {
             eq_prof_scope ps(h, EQ_PROF_CONV, s);
             ADF_TRY(eq_gemm(h, b.m[0], at->c1_m0.in, nullptr, &at->c1_m0, true, b.y[0], at->c1_m0.out, nullptr, Eub, 0, false, s,
@@ -638,6 +704,7 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
             ADF_TRY(eq_launch_edges_from_topk(h, b, s));
         }
         ADF_TRY(eq_launch_wigner(h, N, s));
+        ADF_TRY(eq_launch_check_z(h, Z, N, s));
     }
     h->lastN = N;
     const size_t xs = (size_t)N * d.S * d.C;
@@ -647,9 +714,10 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
         const long long Eub = (long long)(n1 - n0) * (h->ext_graph ? h->maxdeg : h->hp.max_neighbors);
         eq_chunk_bufs cb;
         eq_carve(h, Eub, &cb);
-        ADF_TRY(eq_radial(h, &h->ed_rad, h->ed_src_emb, h->ed_dst_emb, Z, n0, n1, Eub, &cb, cb.rad, N, s));
+        const bool tab = h->rad_static && h->ed_rad.table;
+        if (!tab) ADF_TRY(eq_radial(h, &h->ed_rad, h->ed_src_emb, h->ed_dst_emb, Z, n0, n1, Eub, &cb, cb.rad, N, s));
         eq_prof_scope ps(h, EQ_PROF_ROTATE, s);
-        ADF_TRY(eq_launch_edge_degree(h, cb.rad, Z, n0, n1, h->x, s));
+        ADF_TRY(eq_launch_edge_degree(h, tab ? h->ed_rad.table : cb.rad, Z, tab ? h->hp.max_num_elements : 0, n0, n1, h->x, s));
     }
     if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks, h->x, xs * 4, hipMemcpyDeviceToDevice, s));
     for (int i = 0; i < h->hp.num_layers; ++i) {

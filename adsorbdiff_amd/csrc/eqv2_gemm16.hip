@@ -11,6 +11,8 @@
 //   * accumulate-into-C (residual connections) and plain SiLU.
 // Tiling as gemm16.hip: 128 x (64 NJ) x 32 per 256-thread workgroup, 4 waves as 2 x 2, fp32 A split while staged, weights
 // pre-split at set_weights, one K-tile of global loads in flight, XCD-aware tile order, 16-byte stores through LDS.
+#include <stdlib.h>
+
 #include "eqv2.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -221,6 +223,170 @@ __global__ __launch_bounds__(256, 2) void eq_gemm16_kernel(const float* __restri
     }
 }
 
+// 256 x 256 x 32 tile, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 (4 x 2 MFMA blocks): per k-tile the workgroup
+// stages 32 KB of A and 32 KB of W for 384 MFMAs — a third of the operand bytes per MFMA of the 128 x 256 kernel above
+// (whose two co-resident workgroups ask the L2 for ~60 B/clk/CU at the matrix pipe's pace).  One workgroup per CU,
+// two waves per SIMD.
+template <int ACT, bool ACCUM>
+__global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __restrict__ A, eq_rowmap am,
+                                                               const float* __restrict__ rscale,
+                                                               const _Float16* __restrict__ Whi,
+                                                               const _Float16* __restrict__ Wlo,
+                                                               const float* __restrict__ inv_scale,
+                                                               const float* __restrict__ bias, float* __restrict__ Cm,
+                                                               eq_rowmap cm, long long M, int N, int K, int tiles_n) {
+    constexpr int MI = 4, NJ = 2, TM = 256, TN = 256, NA = 4, NW = 2;
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * GLD];
+    __shared__ float rinv[TM];
+    _Float16* Ahi = lds;
+    _Float16* Alo = Ahi + TM * GLD;
+    _Float16* Bhi = Alo + TM * GLD;
+    _Float16* Blo = Bhi + TN * GLD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int id = blockIdx.x, xcd = id & 7, qd = id >> 3;
+    const long long tile_m = (long long)(qd / tiles_n) * 8 + xcd;
+    const int tile_n = qd % tiles_n;
+    const long long m0 = tile_m * TM;
+    const int n0 = tile_n * TN;
+    if (m0 >= M) return;
+
+    const float* a_ptr[NA];
+    float a_rs[NA];
+    int a_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + 512 * i;
+        const int row = f >> 3, kq = f & 7;
+        long long grow = m0 + row;
+        if (grow > M - 1) grow = M - 1;
+        a_ptr[i] = A + (grow / am.period) * am.outer + (grow % am.period) * (long long)am.inner + kq * 4;
+        a_rs[i] = rscale ? rscale[grow] : 1.0f;
+        a_off[i] = row * GLD + kq * 4;
+    }
+    if (tid < TM) {
+        long long grow = m0 + tid;
+        if (grow > M - 1) grow = M - 1;
+        rinv[tid] = rscale ? 1.0f / rscale[grow] : 1.0f;
+    }
+    int w_src[NW], w_off[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int f = tid + 512 * i;
+        const int row = f >> 2, part = f & 3;
+        w_src[i] = min(n0 + row, N - 1) * K + part * 8;
+        w_off[i] = row * GLD + part * 8;
+    }
+    float4 ra[NA];
+    half8 rwh[NW], rwl[NW];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i]);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i]);
+        rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i]);
+    }
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / GK;
+    const int fa = (wm + (lane & 31)) * GLD + (lane >> 5) * 8;
+    const int fb = (wn + (lane & 31)) * GLD + (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const float sx = ra[i].x * a_rs[i], sy = ra[i].y * a_rs[i], sz = ra[i].z * a_rs[i], sw = ra[i].w * a_rs[i];
+            half4 h, l;
+            h[0] = (_Float16)sx; h[1] = (_Float16)sy; h[2] = (_Float16)sz; h[3] = (_Float16)sw;
+            l[0] = (_Float16)(sx - (float)h[0]); l[1] = (_Float16)(sy - (float)h[1]);
+            l[2] = (_Float16)(sz - (float)h[2]); l[3] = (_Float16)(sw - (float)h[3]);
+            *reinterpret_cast<half4*>(Ahi + a_off[i]) = h;
+            *reinterpret_cast<half4*>(Alo + a_off[i]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            *reinterpret_cast<half8*>(Bhi + w_off[i]) = rwh[i];
+            *reinterpret_cast<half8*>(Blo + w_off[i]) = rwl[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int k1 = (kt + 1) * GK;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(a_ptr[i] + k1);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + k1);
+                rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + k1);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 bh[NJ], bl[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                bh[j] = *reinterpret_cast<const half8*>(Bhi + fb + j * 32 * GLD + ks * 16);
+                bl[j] = *reinterpret_cast<const half8*>(Blo + fb + j * 32 * GLD + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const half8 ah = *reinterpret_cast<const half8*>(Ahi + fa + i * 32 * GLD + ks * 16);
+                const half8 al = *reinterpret_cast<const half8*>(Alo + fa + i * 32 * GLD + ks * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const float isc = *inv_scale;
+    const int q = lane & 31;
+    __syncthreads();  // all waves are done reading the operand tiles
+    float* T = reinterpret_cast<float*>(lds) + wave * (32 * GTLD);  // [32 rows][64] floats per wave (8 x 8 KB <= 80 KB)
+    const int cb = n0 + wn;
+    const float bv0 = (bias && cb + q < N) ? bias[cb + q] : 0.f;
+    const float bv1 = (bias && cb + 32 + q < N) ? bias[cb + 32 + q] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sc = isc * rinv[wm + 32 * i + lr];
+            float v0 = acc[i][0][r] * sc + bv0, v1 = acc[i][1][r] * sc + bv1;
+            if (ACT == 2) { v0 = eq16_silu(v0); v1 = eq16_silu(v1); }
+            T[lr * GTLD + q] = v0;
+            T[lr * GTLD + 32 + q] = v1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = lane + 64 * it;
+            const int lr = item >> 4, c4 = item & 15;
+            const long long row = m0 + wm + 32 * i + lr;
+            const int col = cb + 4 * c4;
+            if (row < M && col < N) {
+                float* cp = Cm + (row / cm.period) * cm.outer + (row % cm.period) * (long long)cm.inner + col;
+                float4 v = *reinterpret_cast<const float4*>(T + lr * GTLD + 4 * c4);
+                if (ACCUM) {
+                    const float4 o = *reinterpret_cast<const float4*>(cp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4*>(cp) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // shapes the kernel takes: K % 32 == 0, N % 4 == 0, 16-byte aligned rows of A and C
 bool eq_gemm16_ok(const float* A, const eq_rowmap* am, const float* Cm, const eq_rowmap* cm, int N, int K) {
     if (K % GK != 0 || (N & 3)) return false;
@@ -233,6 +399,22 @@ int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscal
                          float* Cm, const eq_rowmap* cm, long long M, int N, int K, int act, bool accumulate,
                          hipStream_t s) {
     if (M <= 0 || N <= 0) return ADF_OK;
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("ADF_EQV2_GEMM_TILE"); big = (e && atoi(e) == 128) ? 0 : 1; }
+    if (big && N >= 256 && M >= 8192) {
+        const int tiles_n = (N + 255) / 256;
+        const long long tiles_m8 = ((M + 255) / 256 + 7) / 8 * 8;
+        const long long nb = tiles_m8 * tiles_n;
+        if (nb > 0x7fffffffLL) { adf_set_error("eq_gemm16: grid too large"); return ADF_EINVAL; }
+#define EQ_L256(ACT_, ACC_)                                                                                          \
+    hipLaunchKernelGGL((eq_gemm16_256_kernel<ACT_, ACC_>), dim3((unsigned)nb), dim3(512), 0, s, A, *am, rscale,      \
+                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n)
+        if (act == 2) { if (accumulate) EQ_L256(2, true); else EQ_L256(2, false); }
+        else { if (accumulate) EQ_L256(0, true); else EQ_L256(0, false); }
+#undef EQ_L256
+        ADF_HIP_CHECK(hipGetLastError());
+        return ADF_OK;
+    }
     const int NJ = N <= 128 ? 2 : 4;
     const int TN = 64 * NJ;
     const int tiles_n = (N + TN - 1) / TN;

@@ -114,6 +114,18 @@ int32_t eq_launch_edges_from_topk(adf_eqv2* h, const adf_batch* b, hipStream_t s
     return ADF_OK;
 }
 
+// atomic numbers must index the embedding tables [0, max_num_elements) and the radius table [0, 100]
+__global__ void eq_check_z_kernel(const int32_t* __restrict__ Z, int N, int max_elem, int32_t* flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && (Z[i] < 0 || Z[i] >= max_elem || Z[i] > 100)) atomicExch(&flags[4], 1);
+}
+
+int32_t eq_launch_check_z(const adf_eqv2* h, const int32_t* Z, int N, hipStream_t s) {
+    hipLaunchKernelGGL(eq_check_z_kernel, dim3((N + 255) / 256), dim3(256), 0, s, Z, N, h->hp.max_num_elements, h->flags);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
 // eptr from a target-sorted edge list: eptr[i] = first edge with dst >= i
 __global__ void eq_eptr_kernel(const int32_t* __restrict__ dst, long long E, int N, int32_t* __restrict__ eptr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,6 +318,37 @@ __global__ void eq_radial_pre_kernel(const float* __restrict__ e_vec, const int3
     out[(size_t)(e - e0) * EC + j] = acc;
 }
 
+// The same first layer on a TABLE of element pairs instead of edges, for models whose Gaussian window is empty for
+// every pair whatever the distance (decided from the radii table alone at set_weights: with the reference's pm-valued
+// radii it always is): the radial MLP is then a function of (Z_src, Z_tgt) only and is evaluated once per weight
+// binding; row = Z_src * NE + Z_tgt.  A pair with a non-finite radius gives NaN, as the per-edge evaluation does.
+__global__ void eq_radial_pre_pairs_kernel(const float* __restrict__ radii, const float* __restrict__ w0t,
+                                           const float* __restrict__ b0, const float* __restrict__ semb,
+                                           const float* __restrict__ temb, int EC, int NB, int NE, float* __restrict__ out) {
+    const int pair = blockIdx.x, j = threadIdx.x;
+    const int zs = pair / NE, zt = pair - zs * NE;
+    if (j >= EC) return;
+    const float rr = (zs <= 100 ? radii[zs] : 0.f) + (zt <= 100 ? radii[zt] : 0.f);
+    float acc = b0[j];
+    if (!(rr == rr)) acc = rr;
+    const float* se = semb + (size_t)zs * EC;
+    const float* te = temb + (size_t)zt * EC;
+    const float* ws = w0t + (size_t)NB * EC;
+    const float* wt = ws + (size_t)EC * EC;
+    for (int q = 0; q < EC; ++q) acc += se[q] * ws[(size_t)q * EC + j];
+    for (int q = 0; q < EC; ++q) acc += te[q] * wt[(size_t)q * EC + j];
+    out[(size_t)pair * EC + j] = acc;
+}
+
+int32_t eq_launch_radial_pre_pairs(const adf_eqv2* h, const eq_radial* r, const float* src_emb, const float* dst_emb,
+                                   float* out, hipStream_t s) {
+    const int NE = h->hp.max_num_elements, EC = h->d.EC;
+    hipLaunchKernelGGL(eq_radial_pre_pairs_kernel, dim3(NE * NE), dim3((EC + 63) / 64 * 64), 0, s, h->atom_radii, r->w0t,
+                       r->l0.b, src_emb, dst_emb, EC, h->d.NB, NE, out);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
 int32_t eq_launch_radial_pre(const adf_eqv2* h, const eq_radial* r, const float* src_emb, const float* dst_emb,
                              const int32_t* Z, int n0, int n1, float* out, int N, hipStream_t s) {
     const long long Eub = eq_edge_bound(h, n1 - n0);
@@ -349,7 +392,8 @@ template <int LT>
 __global__ void eq_edge_degree_kernel(const float* __restrict__ m0, const float* __restrict__ wig,
                                       const int32_t* __restrict__ eptr, const int32_t* __restrict__ Z,
                                       const float* __restrict__ emb, int n0, int n1, eq_dims d, float inv_avg,
-                                      int max_elem, float* __restrict__ x, int32_t* flags) {
+                                      int max_elem, float* __restrict__ x, int32_t* flags,
+                                      const int32_t* __restrict__ e_src, int pair_ne) {
     const int n = n0 + blockIdx.x, c = threadIdx.x;
     if (n >= n1 || c >= d.C) return;
     const long long ebase = eptr[n0];
@@ -358,7 +402,9 @@ __global__ void eq_edge_degree_kernel(const float* __restrict__ m0, const float*
     for (int s = 0; s < (LT + 1) * (LT + 1); ++s) acc[s] = 0.f;
     for (long long e = eptr[n]; e < eptr[n + 1]; ++e) {
         const float* D = wig + (size_t)e * d.DR;
-        const float* mr = m0 + (size_t)(e - ebase) * ((LT + 1) * d.C);
+        long long mrow = e - ebase;
+        if (pair_ne > 0) mrow = (long long)min(max(Z[e_src[e]], 0), pair_ne - 1) * pair_ne + min(max(Z[n], 0), pair_ne - 1);
+        const float* mr = m0 + (size_t)mrow * ((LT + 1) * d.C);
 #pragma unroll
         for (int l = 0; l <= LT; ++l) {
             const int ml = l < d.M ? l : d.M;
@@ -375,11 +421,13 @@ __global__ void eq_edge_degree_kernel(const float* __restrict__ m0, const float*
     for (int s = 0; s < (LT + 1) * (LT + 1); ++s) xr[(size_t)s * d.C + c] = acc[s] * inv_avg + (s == 0 ? emb[(size_t)z * d.C + c] : 0.f);
 }
 
-int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int n0, int n1, float* x, hipStream_t s) {
+int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t* Z, int pair_ne, int n0, int n1, float* x,
+                              hipStream_t s) {
     if (n1 <= n0) return ADF_OK;
     const int bd = (h->d.C + 63) / 64 * 64;
 #define EQ_ED(LT_) hipLaunchKernelGGL(eq_edge_degree_kernel<LT_>, dim3(n1 - n0), dim3(bd), 0, s, m0, h->wig, h->eptr, Z, \
-                                      h->sphere_emb, n0, n1, h->d, 1.0f / h->hp.avg_degree, h->hp.max_num_elements, x, h->flags)
+                                      h->sphere_emb, n0, n1, h->d, 1.0f / h->hp.avg_degree, h->hp.max_num_elements, x, h->flags, \
+                                      h->e_src, pair_ne)
     EQ_FOR_L(h->d.L, EQ_ED)
 #undef EQ_ED
     ADF_HIP_CHECK(hipGetLastError());
@@ -395,7 +443,8 @@ struct eq_ptrs { float* p[EQ_MAX_M + 1]; };
 template <int LT>
 __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __restrict__ rad, const float* __restrict__ wig,
                                     const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src,
-                                    const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb, eq_ptrs rs) {
+                                    const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb, eq_ptrs rs,
+                                    const int32_t* __restrict__ Z, int pair_ne) {
     __shared__ unsigned int smax[2 * EQ_MAX_M + 1];  // |.| maxima of the edge's operand rows (bit patterns order like floats)
     const long long ebase = eptr[n0];
     const long long e = ebase + blockIdx.x;
@@ -412,7 +461,13 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
         const int node = c < d.C ? e_src[e] : e_dst[e];
         const float* yr = y + (size_t)node * d.S * d.C + (c < d.C ? c : c - d.C);
         const float* D = wig + (size_t)e * d.DR;
-        const float* rr = rad + (size_t)el * d.RW * C2;
+        // radial weights: per edge, or (pair_ne > 0) one row per element pair (Z_src, Z_tgt)
+        long long rrow = el;
+        if (pair_ne > 0) {  // atomic numbers are range-checked by eq_check_z_kernel; clamped here against stray reads
+            const int zs = min(max(Z[e_src[e]], 0), pair_ne - 1), zt = min(max(Z[e_dst[e]], 0), pair_ne - 1);
+            rrow = (long long)zs * pair_ne + zt;
+        }
+        const float* rr = rad + (size_t)rrow * d.RW * C2;
 #pragma unroll
         for (int l = 0; l <= LT; ++l) {
             float v[2 * LT + 1];
@@ -455,15 +510,15 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
     }
 }
 
-int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, int n0, int n1, float* const* mbuf,
-                            float* const* rsp, hipStream_t s) {
+int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, const int32_t* Z, int pair_ne, int n0, int n1,
+                            float* const* mbuf, float* const* rsp, hipStream_t s) {
     const long long Eub = eq_edge_bound(h, n1 - n0);
     if (Eub <= 0) return ADF_OK;
     eq_ptrs mb, rs;
     for (int m = 0; m <= EQ_MAX_M; ++m) { mb.p[m] = m <= h->d.M ? mbuf[m] : nullptr; rs.p[m] = (rsp && m <= h->d.M) ? rsp[m] : nullptr; }
     const int bd = (2 * h->d.C + 63) / 64 * 64;
 #define EQ_RI(LT_) hipLaunchKernelGGL(eq_rotate_in_kernel<LT_>, dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
-                                      h->e_src, h->e_dst, n0, n1, h->d, mb, rs)
+                                      h->e_src, h->e_dst, n0, n1, h->d, mb, rs, Z, pair_ne)
     EQ_FOR_L(h->d.L, EQ_RI)
 #undef EQ_RI
     ADF_HIP_CHECK(hipGetLastError());

@@ -179,3 +179,46 @@ def test_eqv2_sampling_vs_oracle_stepper():
     print(f"eqv2 sampling: max |dpos| {diff:.2e} A (adsorbate moved up to {moved:.2f} A)")
     assert diff < 1e-4
     assert torch.equal(out.pos.cpu()[~ads], b.pos[~ads])
+
+
+def test_eqv2_static_radial_tables_equal_per_edge_evaluation(monkeypatch):
+    """With the reference's radii the distance basis vanishes on every edge and the radial MLPs are tabulated per element
+    pair at weight binding; ADF_EQV2_RADIAL=edge evaluates them per edge instead: same outputs."""
+    m = make_model(4, 2, C=32, hidden=32, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=1, cutoff=12.0).to(DEV)
+    b = safe_batch(2, 36, seed=9).to(DEV)
+    f1, f2 = m(b)
+    monkeypatch.setenv("ADF_EQV2_RADIAL", "edge")
+    m._engine.close()
+    m._engine = None
+    g1, g2 = m(b)
+    assert rel_err(f1.cpu(), g1.cpu()) < 2e-6 and rel_err(f2.cpu(), g2.cpu()) < 2e-6
+
+
+def test_eqv2_distance_basis_path_vs_oracle():
+    """Radii small enough for the Gaussian distance basis to be non-zero (the table divided by 100: what the
+    reference's discarded `/ 100` would have produced, equiformer_v2_denoising.py:168-169): the per-edge radial path
+    with its basis window, against the oracle given the same radii."""
+    from oracle import eqv2_oracle as Q
+
+    m = make_model(4, 2, C=8, hidden=8, heads=2, alpha=4, value=4, ffn=16, ec=8, layers=1, cutoff=12.0)
+    with torch.no_grad():
+        m.atom_radii.div_(100.0)
+        for n, p in m.named_parameters():  # let the basis part of the first radial layer matter
+            if n.endswith("rad_func.net.0.weight"):
+                p[:, :600].mul_(3.0)
+    b = safe_batch(2, 36, seed=13)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ei, sh, nb = Q.radius_graph_pbc(b.pos, b.cell, b.natoms, 12.0, 20)
+    ei, d, v, _ = Q.pbc_distances(b.pos, ei, b.cell, sh, nb)
+    with torch.no_grad():
+        r1, r2 = Q.eqv2_forward(sd, oracle_hp(m), b.pos, b.atomic_numbers, b.cell, b.natoms, graph=(ei, v),
+                                atom_radii=m.atom_radii.detach())
+        z1, _ = Q.eqv2_forward(sd, oracle_hp(m), b.pos, b.atomic_numbers, b.cell, b.natoms, graph=(ei, v))
+    assert rel_err(z1, r1) > 1e-3, "the distance basis does not reach the outputs of this test model"
+    m = m.to(DEV)
+    eng = m.engine()
+    eng.set_edges(ei, v)
+    f1, f2 = m(b.to(DEV))
+    e1, e2 = rel_err(f1.cpu(), r1), rel_err(f2.cpu(), r2)
+    print(f"distance basis: rel err {e1:.2e} {e2:.2e}")
+    assert e1 < REL_TOL and e2 < REL_TOL
