@@ -69,7 +69,7 @@ struct adf_eqv2 {
     eq_dims d;
     eq_dims* d_dev;   // device copy (kernels that index its tables per lane)
     int device, num_cus;
-    bool weights_set, consts_set, exact_f32;
+    bool weights_set, consts_set, exact_f32, s2_emit_mag;
     // constants (device)
     float *jd, *to_red, *from_red, *to_full, *from_full;
     // weights
@@ -104,7 +104,7 @@ struct adf_eqv2 {
     float* sys;
     void* s2tab; int s2_npb; float s2_inv_sT, s2_inv_sF, s2_gain_shift;  // fragment-order fp16 hi/lo images of to_red / from_red
     void *gtab_to, *gtab_from; int g_npb, g_nkst; float g_inv_sT, g_inv_sF;  // likewise for to_full / from_full
-    float* rs; int64_t rs_cap;   // per-row lifts of the A operand of an f16x3 product
+    float* rs; int64_t rs_cap;   // per-row magnitudes max|a| of the A operand of an f16x3 product (-> power-of-two lift)
     int64_t lastN;
     // HIP-event timing per kernel group (bench.py roofline)
     bool prof_on;
@@ -150,4 +150,4 @@ int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hip
 // C (+)= act(A . W^T + b): exact f32 for any shape; act: 0 none, 2 SiLU
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
                 float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s,
-                const float* rs_pre = nullptr);
+                const float* rs_pre = nullptr, float* out_mag = nullptr);

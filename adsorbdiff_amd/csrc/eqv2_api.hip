@@ -18,7 +18,7 @@ bool eq_gemm16_ok(const float* A, const eq_rowmap* am, const float* Cm, const eq
 int32_t eq_launch_rowscale(const float* A, const eq_rowmap* am, long long M, int K, float* rs, hipStream_t s);
 int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscale, const adf_w16* W, const float* bias,
                          float* Cm, const eq_rowmap* cm, long long M, int N, int K, int act, bool accumulate,
-                         hipStream_t s);
+                         hipStream_t s, float* out_mag);
 
 template <typename T>
 static int32_t eq_alloc(T** p, size_t count) {
@@ -118,6 +118,9 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     h->num_cus = prop.multiProcessorCount;
     const char* env = getenv("ADF_GEMM");
     h->exact_f32 = env && !strcmp(env, "f32");
+    // the S2 activation can hand the magnitudes of its output rows to the second convolution (atomics in its epilogue)
+    // instead of a separate pass over them: measured slower on MI355X (+8 ms vs -3 ms per forward at 256 k edges): off
+    { const char* e2 = getenv("ADF_EQV2_S2_EMIT"); h->s2_emit_mag = e2 && atoi(e2) != 0; }
     h->prof_ev = new std::vector<hipEvent_t>();
     h->prof_cat = new std::vector<int>();
     int32_t st = eq_alloc(&h->flags, EQ_NFLAGS);
@@ -527,7 +530,7 @@ static int32_t eq_ensure_capacity(adf_eqv2* h, int64_t N, int64_t B, int64_t Ene
         h->garena_floats = 2 * (size_t)cn * d.G * d.F;
         ADF_TRY(eq_alloc(&h->garena, h->garena_floats));
         int64_t rc = 2 * cn * kk;
-        if (cn * d.G > rc) rc = cn * d.G;
+        if (3 * cn * d.G > rc) rc = 3 * cn * d.G;
         if (cN * (2 * d.L + 1) > rc) rc = cN * (2 * d.L + 1);
         ADF_TRY(eq_alloc(&h->rs, (size_t)rc));
         h->rs_cap = rc;
@@ -568,17 +571,26 @@ extern "C" int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, cons
 // ---------------------------------------------------------------------------------------------- dense product dispatch
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
                 float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s,
-                const float* rs_pre) {
+                const float* rs_pre, float* out_mag) {
     const eq_rowmap a1 = {lda, 1, 0}, c1 = {ldc, 1, 0};
     const eq_rowmap* am = amap ? amap : &a1;
     const eq_rowmap* cm = cmap ? cmap : &c1;
     if (!h->exact_f32 && W->has16 && (rs_pre || M <= h->rs_cap) && eq_gemm16_ok(A, am, Cm, cm, W->out, W->in)) {
         // per-row power-of-two lift of A (eqv2_gemm16.hip; rs_pre: already written by the producer of A), then the product
         if (!rs_pre) ADF_TRY(eq_launch_rowscale(A, am, M, W->in, h->rs, s));
+        if (out_mag) ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));
         return eq_launch_gemm16(A, am, rs_pre ? rs_pre : h->rs, &W->w16, use_bias ? W->b : nullptr, Cm, cm, M, W->out, W->in,
-                                act, accumulate, s);
+                                act, accumulate, s, out_mag);
     }
+    // exact-f32 product: no lifts needed downstream either (out_mag stays untouched; callers only pass it on when the
+    // matrix-core path runs, see eq_uses_mfma)
     return eq_gemm_f32(A, lda, amap, W->w, use_bias ? W->b : nullptr, Cm, ldc, cmap, M, W->out, W->in, act, accumulate, s);
+}
+
+// whether eq_gemm will take the f16x3 kernel for this product (then row magnitudes can be handed from producer to consumer)
+static bool eq_uses_mfma(const adf_eqv2* h, const float* A, int lda, const eq_lin* W, const float* Cm, int ldc) {
+    const eq_rowmap a1 = {lda, 1, 0}, c1 = {ldc, 1, 0};
+    return !h->exact_f32 && W->has16 && eq_gemm16_ok(A, &a1, Cm, &c1, W->out, W->in);
 }
 
 // ---------------------------------------------------------------------------------------------- forward
@@ -651,7 +663,7 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
         }
         { eq_prof_scope ps(h, EQ_PROF_ATTN, s); ADF_TRY(eq_launch_alpha(h, at, b.y[0], at->c1_m0.out, n0, n1, b.alpha, s)); }
         bool rs_ok = false;
-        { eq_prof_scope ps(h, EQ_PROF_S2ACT, s); ADF_TRY(eq_launch_s2act(h, b.y[0], b.y, extra, d.NH * d.A, n0, n1, b.mb, b.rsb, &rs_ok, s)); }
+        { eq_prof_scope ps(h, EQ_PROF_S2ACT, s); ADF_TRY(eq_launch_s2act(h, b.y[0], b.y, extra, d.NH * d.A, n0, n1, b.mb, h->s2_emit_mag ? b.rsb : nullptr, &rs_ok, s)); }
         {
             eq_prof_scope ps(h, EQ_PROF_CONV, s);
             ADF_TRY(eq_gemm(h, b.mb[0], at->c2_m0.in, nullptr, &at->c2_m0, true, b.z[0], at->c2_m0.out, nullptr, Eub, 0, false, s,
@@ -740,9 +752,14 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
                 float* ga = h->garena;
                 float* gb = h->garena + (size_t)h->chunk_nodes * d.G * d.F;
                 ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, s));
-                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g0, false, gb, d.F, nullptr, rows, 2, false, s));
-                ADF_TRY(eq_gemm(h, gb, d.F, nullptr, &f.g2, false, ga, d.F, nullptr, rows, 2, false, s));
-                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g4, false, gb, d.F, nullptr, rows, 0, false, s));
+                // the first product measures its operand rows itself; the next two get them from the producer's epilogue
+                const bool chain = eq_uses_mfma(h, ga, d.F, &f.g0, gb, d.F) && eq_uses_mfma(h, gb, d.F, &f.g2, ga, d.F) &&
+                                   eq_uses_mfma(h, ga, d.F, &f.g4, gb, d.F) && 3 * rows <= h->rs_cap;
+                float* m1 = chain ? h->rs + rows : nullptr;
+                float* m2 = chain ? h->rs + 2 * rows : nullptr;
+                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g0, false, gb, d.F, nullptr, rows, 2, false, s, nullptr, m1));
+                ADF_TRY(eq_gemm(h, gb, d.F, nullptr, &f.g2, false, ga, d.F, nullptr, rows, 2, false, s, m1, m2));
+                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g4, false, gb, d.F, nullptr, rows, 0, false, s, m2, nullptr));
                 ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
             }
             ADF_TRY(eq_so3_linear(h, f.l2, h->h2, d.F, h->x, d.C, N, true, s));

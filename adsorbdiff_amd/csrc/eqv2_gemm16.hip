@@ -25,7 +25,17 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float eq16_silu(float x) { return x / (1.0f + expf(-x)); }
 
-// rs[r] = 2^(14 - exponent(max_k |A[r, k]|)), 1 for an all-zero row; one wave per row
+__device__ __forceinline__ float eq16_lift(float mx) {
+    // 2^e with mx 2^e in [2^14, 2^15); 1 for mx == 0 or non-finite
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(mx, &e);
+    e = 15 - e;
+    e = e > 120 ? 120 : (e < -120 ? -120 : e);
+    return ldexpf(1.0f, e);
+}
+
+// rs[r] = max_k |A[r, k]| (the product kernels turn it into the row's power-of-two lift); one wave per row
 __global__ __launch_bounds__(256) void eq_rowscale_kernel(const float* __restrict__ A, eq_rowmap am, long long M, int K,
                                                           float* __restrict__ rs) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -39,17 +49,7 @@ __global__ __launch_bounds__(256) void eq_rowscale_kernel(const float* __restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if (lane == 0) {
-        float s = 1.0f;
-        if (mx > 0.f && mx < 3.0e38f) {
-            int e;
-            (void)frexpf(mx, &e);  // mx = m 2^e, m in [0.5, 1)
-            e = 15 - e;
-            e = e > 120 ? 120 : (e < -120 ? -120 : e);
-            s = ldexpf(1.0f, e);
-        }
-        rs[r] = s;
-    }
+    if (lane == 0) rs[r] = mx;
 }
 
 int32_t eq_launch_rowscale(const float* A, const eq_rowmap* am, long long M, int K, float* rs, hipStream_t s) {
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void eq_gemm16_kernel(const float* __restri
                                                            const _Float16* __restrict__ Wlo,
                                                            const float* __restrict__ inv_scale,
                                                            const float* __restrict__ bias, float* __restrict__ Cm,
-                                                           eq_rowmap cm, long long M, int N, int K, int tiles_n) {
+                                                           eq_rowmap cm, long long M, int N, int K, int tiles_n,
+                                                           unsigned int* __restrict__ out_mag) {
     constexpr int MI = 2;
     constexpr int TM = 64 * MI, TN = 64 * NJ, NA = TM / 32;
     __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * GLD];
@@ -94,13 +95,13 @@ __global__ __launch_bounds__(256, 2) void eq_gemm16_kernel(const float* __restri
         long long grow = m0 + row;
         if (grow > M - 1) grow = M - 1;
         a_ptr[i] = A + (grow / am.period) * am.outer + (grow % am.period) * (long long)am.inner + kq * 4;
-        a_rs[i] = rscale ? rscale[grow] : 1.0f;
+        a_rs[i] = rscale ? eq16_lift(rscale[grow]) : 1.0f;
         a_off[i] = row * GLD + kq * 4;
     }
     if (tid < TM) {
         long long grow = m0 + tid;
         if (grow > M - 1) grow = M - 1;
-        rinv[tid] = rscale ? 1.0f / rscale[grow] : 1.0f;
+        rinv[tid] = rscale ? 1.0f / eq16_lift(rscale[grow]) : 1.0f;
     }
     int w_src[NJ], w_off[NJ];
 #pragma unroll
@@ -199,6 +200,13 @@ __global__ __launch_bounds__(256, 2) void eq_gemm16_kernel(const float* __restri
                 if (ACT == 2) { v0 = eq16_silu(v0); v1 = eq16_silu(v1); }
                 T[lr * GTLD + q] = v0;
                 T[lr * GTLD + 32 + q] = v1;
+                if (out_mag) {  // magnitude of the output row (all lanes of a half-wave hold the same row)
+                    float mg = fmaxf(cb + q < N ? fabsf(v0) : 0.f, cb + 32 + q < N ? fabsf(v1) : 0.f);
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
+                    const long long orow = m0 + wm + 32 * i + lr;
+                    if (q == 0 && orow < M) atomicMax(out_mag + orow, __float_as_uint(mg));
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -234,7 +242,8 @@ __global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __re
                                                                const _Float16* __restrict__ Wlo,
                                                                const float* __restrict__ inv_scale,
                                                                const float* __restrict__ bias, float* __restrict__ Cm,
-                                                               eq_rowmap cm, long long M, int N, int K, int tiles_n) {
+                                                               eq_rowmap cm, long long M, int N, int K, int tiles_n,
+                                                           unsigned int* __restrict__ out_mag) {
     constexpr int MI = 4, NJ = 2, TM = 256, TN = 256, NA = 4, NW = 2;
     __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * GLD];
     __shared__ float rinv[TM];
@@ -261,13 +270,13 @@ __global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __re
         long long grow = m0 + row;
         if (grow > M - 1) grow = M - 1;
         a_ptr[i] = A + (grow / am.period) * am.outer + (grow % am.period) * (long long)am.inner + kq * 4;
-        a_rs[i] = rscale ? rscale[grow] : 1.0f;
+        a_rs[i] = rscale ? eq16_lift(rscale[grow]) : 1.0f;
         a_off[i] = row * GLD + kq * 4;
     }
     if (tid < TM) {
         long long grow = m0 + tid;
         if (grow > M - 1) grow = M - 1;
-        rinv[tid] = rscale ? 1.0f / rscale[grow] : 1.0f;
+        rinv[tid] = rscale ? 1.0f / eq16_lift(rscale[grow]) : 1.0f;
     }
     int w_src[NW], w_off[NW];
 #pragma unroll
@@ -364,6 +373,13 @@ __global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __re
             if (ACT == 2) { v0 = eq16_silu(v0); v1 = eq16_silu(v1); }
             T[lr * GTLD + q] = v0;
             T[lr * GTLD + 32 + q] = v1;
+            if (out_mag) {
+                float mg = fmaxf(cb + q < N ? fabsf(v0) : 0.f, cb + 32 + q < N ? fabsf(v1) : 0.f);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
+                const long long orow = m0 + wm + 32 * i + lr;
+                if (q == 0 && orow < M) atomicMax(out_mag + orow, __float_as_uint(mg));
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -397,7 +413,7 @@ bool eq_gemm16_ok(const float* A, const eq_rowmap* am, const float* Cm, const eq
 
 int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscale, const adf_w16* W, const float* bias,
                          float* Cm, const eq_rowmap* cm, long long M, int N, int K, int act, bool accumulate,
-                         hipStream_t s) {
+                         hipStream_t s, float* out_mag) {
     if (M <= 0 || N <= 0) return ADF_OK;
     static int big = -1;
     if (big < 0) { const char* e = getenv("ADF_EQV2_GEMM_TILE"); big = (e && atoi(e) == 128) ? 0 : 1; }
@@ -408,7 +424,8 @@ int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscal
         if (nb > 0x7fffffffLL) { adf_set_error("eq_gemm16: grid too large"); return ADF_EINVAL; }
 #define EQ_L256(ACT_, ACC_)                                                                                          \
     hipLaunchKernelGGL((eq_gemm16_256_kernel<ACT_, ACC_>), dim3((unsigned)nb), dim3(512), 0, s, A, *am, rscale,      \
-                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n)
+                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n, \
+                       reinterpret_cast<unsigned int*>(out_mag))
         if (act == 2) { if (accumulate) EQ_L256(2, true); else EQ_L256(2, false); }
         else { if (accumulate) EQ_L256(0, true); else EQ_L256(0, false); }
 #undef EQ_L256
@@ -425,7 +442,8 @@ int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscal
     dim3 grid((unsigned)nblocks);
 #define EQ_L16(ACT_, NJ_, ACC_)                                                                                       \
     hipLaunchKernelGGL((eq_gemm16_kernel<ACT_, NJ_, ACC_>), grid, dim3(256), 0, s, A, *am, rscale,                    \
-                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n)
+                       (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n, \
+                       reinterpret_cast<unsigned int*>(out_mag))
     if (NJ == 2) {
         if (act == 2) { if (accumulate) EQ_L16(2, 2, true); else EQ_L16(2, 2, false); }
         else { if (accumulate) EQ_L16(0, 2, true); else EQ_L16(0, 2, false); }

@@ -506,7 +506,7 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
     if (threadIdx.x < 2 * d.M + 1) {
         const int t = threadIdx.x, m = (t + 1) >> 1;
         const long long row = m == 0 ? el : 2 * el + ((t + 1) & 1);
-        rs.p[m][row] = eq_pow2_lift(__uint_as_float(smax[t]));
+        rs.p[m][row] = __uint_as_float(smax[t]);
     }
 }
 
@@ -605,18 +605,21 @@ __global__ __launch_bounds__(512, 2) void eq_s2act_mfma_kernel(const float* __re
                                                                eq_ptrs ym, const int32_t* __restrict__ eptr, int n0, int n1,
                                                                const eq_dims* __restrict__ dg, int Sr, int L, int M, int Hd,
                                                                const eqhalf8* __restrict__ tabs, int npb, float inv_sT,
-                                                               float inv_sF, float gain_shift, eq_ptrs mb) {
+                                                               float inv_sF, float gain_shift, eq_ptrs mb, eq_ptrs rs) {
     extern __shared__ eqhalf8 tab[];  // TA [npb][2 ks][hi|lo][64], then FA likewise
     __shared__ eq_rdesc rdesc[32];    // input side, by coefficient r
     __shared__ int4 odesc[32];        // output side, by coefficient r': (m, row sign, column base, -)
     __shared__ const float* in_ptr[EQ_MAX_M + 1];
     __shared__ float* out_ptr[EQ_MAX_M + 1];
+    __shared__ unsigned int* mag_ptr[EQ_MAX_M + 1];
+    __shared__ unsigned int wmag[8][2 * EQ_MAX_M + 2];  // per wave: magnitudes of the item's destination rows
     const int ntab = npb * 2 * 2 * 64;
     for (int t = threadIdx.x; t < 2 * ntab; t += 512) tab[t] = tabs[t];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + EQ_MAX_M + 1) {
         const int m = threadIdx.x - 64;
         in_ptr[m] = m == 0 ? y0 : ym.p[m <= M ? m : 0];
         out_ptr[m] = mb.p[m <= M ? m : 0];
+        mag_ptr[m] = reinterpret_cast<unsigned int*>(rs.p[m <= M ? m : 0]);
     }
     if (threadIdx.x < 32) {
         const int r = threadIdx.x;
@@ -731,6 +734,7 @@ __global__ __launch_bounds__(512, 2) void eq_s2act_mfma_kernel(const float* __re
         }
         const float sc2 = inv_sF / lift2;
         // outputs (row r' = (reg & 3) + 8 (reg >> 2) + 4 kh), the l = 0 row replaced by SiLU of the scalar gate
+        if (lane < 2 * EQ_MAX_M + 2) wmag[wave][lane] = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int4 o = odesc[(r & 3) + 8 * (r >> 2) + 4 * kh];
@@ -738,13 +742,31 @@ __global__ __launch_bounds__(512, 2) void eq_s2act_mfma_kernel(const float* __re
             const int nm = L - o.x + 1;
             const long long row = o.x == 0 ? el : 2 * el + o.y;
             float* dst = out_ptr[o.x] + (size_t)row * nm * Hd + o.z;
+            float mg = 0.f;
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) {
                 const int c = cb + 32 * nb + cl;
                 float v = acc2[nb][r] * sc2;
                 if (r == 0 && kh == 0) v = eq_silu(base0[gate_off + c]);
                 dst[c] = v;
+                mg = fmaxf(mg, fabsf(v));
             }
+            // magnitude of the destination row (zeroed by the launcher): the next product's power-of-two lift comes from it
+            if (mag_ptr[0]) {
+#pragma unroll
+                for (int sh = 16; sh > 0; sh >>= 1) mg = fmaxf(mg, __shfl_xor(mg, sh));
+                if (cl == 0) atomicMax(&wmag[wave][o.x == 0 ? 0 : 2 * o.x - 1 + o.y], __float_as_uint(mg));
+            }
+        }
+        if (mag_ptr[0]) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 2 * M + 1) {
+                const int m = (lane + 1) >> 1;
+                const long long row = m == 0 ? el : 2 * el + ((lane + 1) & 1);
+                atomicMax(mag_ptr[m] + row, wmag[wave][lane]);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -758,16 +780,20 @@ int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, in
     eq_ptrs a, b;
     for (int m = 0; m <= d.M; ++m) { a.p[m] = ym[m]; b.p[m] = mbp[m]; }
     const int ld0 = extra + (d.L + 1) * d.Hd;
-    (void)rsp;
     if (!h->exact_f32 && h->s2tab && d.Sr <= 32 && d.Hd % 32 == 0) {
+        eq_ptrs r;
+        for (int m = 0; m <= EQ_MAX_M; ++m) r.p[m] = (rsp && m <= d.M) ? rsp[m] : nullptr;
+        if (rsp)
+            for (int m = 0; m <= d.M; ++m)
+                ADF_HIP_CHECK(hipMemsetAsync(rsp[m], 0, sizeof(float) * (size_t)(m == 0 ? Eub : 2 * Eub), s));
         const size_t dyn = (size_t)h->s2_npb * 2 * 2 * 64 * 16 * 2;
         ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_s2act_mfma_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(eq_s2act_mfma_kernel<1>, dim3(h->num_cus), dim3(512), dyn, s, y0, ld0, extra, gate_off, a, h->eptr,
                            n0, n1, h->d_dev, d.Sr, d.L, d.M, d.Hd, (const eqhalf8*)h->s2tab, h->s2_npb, h->s2_inv_sT,
-                           h->s2_inv_sF, h->s2_gain_shift, b);
+                           h->s2_inv_sF, h->s2_gain_shift, b, r);
         ADF_HIP_CHECK(hipGetLastError());
-        *rs_written = false;
+        *rs_written = rsp != nullptr;
         return ADF_OK;
     }
     *rs_written = false;
