@@ -855,6 +855,12 @@ __global__ void tr_adamw_kernel(float* __restrict__ p, const float* __restrict__
                                 float* __restrict__ ema, long long n, const float* __restrict__ sqnorm, float max_norm,
                                 float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
                                 float ema_decay) {
+    // A non-finite global gradient norm (NaN / Inf anywhere in the gradients, e.g. an fp16-range overflow in the f16x3
+    // forward) makes the whole update a no-op: parameters, moments and the EMA shadow keep their values.  The host also
+    // skips the step on a non-finite loss like the reference (sde_denoising_trainer.py:425-431); this is the guard that
+    // needs no host round trip and that holds on every rank after the gradient all-reduce.
+    const float sq = *sqnorm;
+    if (!(sq == sq) || sq > 3.0e38f) return;
     float clip = 1.0f;
     if (max_norm > 0.f) {  // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
         const float c = max_norm / (sqrtf(*sqnorm) + 1e-6f);

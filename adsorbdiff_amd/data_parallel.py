@@ -20,7 +20,24 @@ import numpy as np
 import torch
 
 from .data import Batch, Data, data_list_collater
-from .sampler import balanced_partition
+
+
+def balanced_partition_ref(sizes, num_parts: int) -> List[List[int]]:
+    """The reference's partition with the reference's OUTPUT ORDER (datasets/data_parallel.py:32-48): descending sizes by
+    ``np.argsort(-sizes)``, a heap of (load, members) entries — ties between equal loads are broken by comparing the
+    member lists — and the parts returned in heap-array order, members in insertion order; rank r takes entry r.
+    (``sampler.balanced_partition`` deals sampling shards with a deterministic index tie-break and sorted members; which
+    rank gets which shard does not change any result there.)"""
+    import heapq
+
+    sizes = np.asarray(sizes)
+    order = np.argsort(-sizes)
+    heap = [(sizes[i], [i]) for i in order[:num_parts]]
+    heapq.heapify(heap)
+    for i in order[num_parts:]:
+        load, members = heapq.heappop(heap)
+        heapq.heappush(heap, (load + sizes[i], members + [i]))
+    return [[int(j) for j in members] for _, members in heap]
 
 
 class OCPCollater:
@@ -92,7 +109,7 @@ class BalancedBatchSampler:
         per_rank = [self._rank_batches(r) for r in range(self.num_replicas)]
         for step in range(len(mine)):
             idx_all = [i for r in range(self.num_replicas) for i in per_rank[r][step]]
-            parts = balanced_partition([int(self.sizes[i]) for i in idx_all], self.num_replicas)
+            parts = balanced_partition_ref(np.array([int(self.sizes[i]) for i in idx_all]), self.num_replicas)
             yield [idx_all[j] for j in parts[self.rank]]
 
 

@@ -66,6 +66,18 @@ def write_final_frames(batch, path, fid: int = 0, start_index: int = 0, apply_li
         env.close()
         return path
     out = path.with_suffix(".npz")
-    np.savez(out, **{f"{start_index + i}/{k}": v for i, r in enumerate(records) for k, v in r.items()},
-             length=start_index + len(records))
+    entries = {}
+    if start_index > 0:
+        # per-batch calls append: keep the records already in the file (np.savez rewrites the whole archive)
+        if not out.exists():
+            raise FileNotFoundError(f"{out}: start_index={start_index} but the records of the earlier batches are missing")
+        with np.load(out, allow_pickle=False) as old:
+            have = int(old["length"])
+            if have != start_index:
+                raise ValueError(f"{out} holds {have} records, start_index={start_index} would leave a gap or overwrite")
+            entries.update({k: old[k] for k in old.files if k != "length"})
+    entries.update({f"{start_index + i}/{k}": v for i, r in enumerate(records) for k, v in r.items()})
+    tmp = out.with_suffix(".tmp.npz")
+    np.savez(tmp, **entries, length=start_index + len(records))
+    tmp.replace(out)
     return out

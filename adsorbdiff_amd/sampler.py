@@ -105,9 +105,23 @@ class RcclGather:
             self.handle = None
 
 
-def gather_sites(batch, world: int, via: str = "torch", system_ids=None) -> torch.Tensor:
+def shard_bounds(batch, world: int):
+    """(B_max, A_max) over all shards of ``shard_batch(batch, r, world)``: the largest number of systems on a rank and the
+    largest adsorbate.  Every rank computes it locally from the global batch (the partition is deterministic), so the
+    exchange buffer of ``gather_sites`` can be sized without a collective."""
+    parts = balanced_partition(batch.natoms.tolist(), world)
+    B = int(batch.natoms.shape[0])
+    counts = torch.bincount(batch.batch[batch.tags == 2], minlength=B)
+    return max(len(p) for p in parts), max(int(counts.max().item()), 1)
+
+
+def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=None) -> torch.Tensor:
     """All ranks' adsorbate sites: [sum_r B_r, A_max, 3] (NaN padded), rank-major — or, when every rank passes the
     global ids of its systems (``system_ids``, what ``shard_batch`` returns), in global system order.
+
+    ONE collective when ``bounds = (B_max, A_max)`` is given (``shard_bounds``: every rank derives it locally): each rank
+    packs [B_max, 1 + 3 A_max] floats — the system id (bit pattern of an int32; -1 = padding row) and the NaN-padded
+    sites — and one all_gather moves them.  Without bounds the shapes are agreed on first (one more small all_gather).
 
     via="torch": ``torch.distributed.all_gather`` (backend nccl = RCCL over xGMI; gloo in the CPU tests);
     via="rccl":  the library's C-ABI entry ``adf_allgather_sites`` (one GPU per rank)."""
@@ -116,43 +130,35 @@ def gather_sites(batch, world: int, via: str = "torch", system_ids=None) -> torc
         return local
     import torch.distributed as dist
 
-    ids = torch.as_tensor(system_ids if system_ids is not None else [], dtype=torch.int64)
-    if via == "rccl":
-        g = RcclGather.get(local.device)
-        meta = torch.tensor([local.shape[0], local.shape[1]], dtype=torch.int64, device=local.device)
-        metas = g.all_gather(meta).cpu()
-        Bmax, Amax = int(metas[:, 0].max()), int(metas[:, 1].max())
-        padded = torch.full((Bmax, Amax, 3), float("nan"), dtype=local.dtype, device=local.device)
-        padded[: local.shape[0], : local.shape[1]] = local
-        outs = g.all_gather(padded)
-        id_pad = torch.full((Bmax,), -1, dtype=torch.int64, device=local.device)
-        id_pad[: ids.numel()] = ids.to(local.device)
-        all_ids = g.all_gather(id_pad) if system_ids is not None else None
-        counts = [int(m[0]) for m in metas]
-    else:
-        if dist.get_backend() == "gloo" and local.is_cuda:  # test configuration: several ranks on one GPU
-            local = local.cpu()
-        dev = local.device
-        meta = torch.tensor([local.shape[0], local.shape[1]], dtype=torch.int64, device=dev)
-        metas = [torch.zeros_like(meta) for _ in range(world)]
-        dist.all_gather(metas, meta)
-        Bmax = int(max(int(m[0]) for m in metas))
-        Amax = int(max(int(m[1]) for m in metas))
-        padded = torch.full((Bmax, Amax, 3), float("nan"), dtype=local.dtype, device=dev)
-        padded[: local.shape[0], : local.shape[1]] = local
-        outs = [torch.empty_like(padded) for _ in range(world)]
-        dist.all_gather(outs, padded)
-        all_ids = None
-        if system_ids is not None:
-            id_pad = torch.full((Bmax,), -1, dtype=torch.int64, device=dev)
-            id_pad[: ids.numel()] = ids.to(dev)
-            all_ids = [torch.empty_like(id_pad) for _ in range(world)]
-            dist.all_gather(all_ids, id_pad)
-        counts = [int(m[0]) for m in metas]
-    sites = torch.cat([outs[r][: counts[r]] for r in range(world)], dim=0)
-    if all_ids is None:
-        return sites
-    gid = torch.cat([all_ids[r][: counts[r]] for r in range(world)], dim=0)
-    assert bool((gid >= 0).all()), "every rank must pass one id per local system"
-    order = torch.argsort(gid)
-    return sites[order]
+    host_bounce = via != "rccl" and dist.get_backend() == "gloo" and local.is_cuda  # test configuration
+    if host_bounce:
+        local = local.cpu()
+    dev = local.device
+
+    def all_gather(t):
+        if via == "rccl":
+            return RcclGather.get(dev).all_gather(t)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return torch.stack(outs)
+
+    if bounds is None:
+        meta = all_gather(torch.tensor([local.shape[0], local.shape[1]], dtype=torch.int64, device=dev)).cpu()
+        bounds = (int(meta[:, 0].max()), int(meta[:, 1].max()))
+    Bmax, Amax = int(bounds[0]), int(bounds[1])
+    if local.shape[0] > Bmax or local.shape[1] > Amax:
+        raise ValueError(f"gather_sites: local sites {tuple(local.shape)} exceed the bounds {(Bmax, Amax)}")
+    ids = torch.arange(local.shape[0], dtype=torch.int32) if system_ids is None else torch.as_tensor(system_ids, dtype=torch.int32)
+    if ids.numel() != local.shape[0]:
+        raise ValueError("every rank must pass one id per local system")
+    packed = torch.full((Bmax, 1 + 3 * Amax), float("nan"), dtype=torch.float32, device=dev)
+    packed[:, 0] = torch.full((Bmax,), -1, dtype=torch.int32, device=dev).view(torch.float32)
+    packed[: local.shape[0], 0] = ids.to(dev).view(torch.float32)
+    packed[: local.shape[0], 1 : 1 + 3 * local.shape[1]] = local.reshape(local.shape[0], -1).to(torch.float32)
+    everything = all_gather(packed.contiguous())                       # the one exchange: [world, B_max, 1 + 3 A_max]
+    gid = everything[:, :, 0].contiguous().view(torch.int32)
+    keep = gid >= 0
+    sites = everything[:, :, 1:].reshape(world, Bmax, Amax, 3)[keep].to(local.dtype)
+    if system_ids is None:
+        return sites                                                   # rank-major
+    return sites[torch.argsort(gid[keep].to(torch.int64))]

@@ -114,10 +114,29 @@ class DenoisingTrainer:
         self.train_engine.zero_grad()
         loss = self.train_engine.loss_and_grad(batch, targets)
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # NaN policy of the reference loop (sde_denoising_trainer.py:425-440): a step with a NaN loss is skipped (counted;
+        # more than 10 in a row stop the training), a loss above 1e6 stops it.  All ranks must take the same branch, so
+        # the flag is reduced over the ranks first (one scalar); the fused optimizer additionally turns an update with
+        # a non-finite gradient norm into a no-op on the device (csrc/train.hip: tr_adamw_kernel).
+        bad = (~torch.isfinite(loss.detach()).all()).to(torch.float32).reshape(1)
+        if world > 1:
+            bad_r = bad if dist.get_backend() != "gloo" else bad.cpu()
+            dist.all_reduce(bad_r, op=dist.ReduceOp.MAX)
+            bad = bad_r.to(bad.device)
+        if bool(bad.item()):
+            logging.warning("NaN loss detected, skipping step")
+            self.nan_count = getattr(self, "nan_count", 0) + 1
+            self.train_engine.zero_grad()
+            if self.nan_count > 10:
+                raise FloatingPointError("Too many NaN losses, stopping training")
+            return {"loss": loss, "grad_norm": None, "skipped": True}
+        self.nan_count = 0
+        if float(loss.detach().reshape(-1)[0]) > 1e6:
+            raise FloatingPointError(f"Loss too high: {float(loss.detach().reshape(-1)[0])}")
         allreduce_gradients(self._unwrapped_model, world)
         grad_norm = self.optimizer.step()
         self.step += 1
-        return {"loss": loss, "grad_norm": grad_norm}
+        return {"loss": loss, "grad_norm": grad_norm, "skipped": False}
 
     # ---------------------------------------------------------------- checkpoint ingest
     def load_checkpoint(self, checkpoint_path: str) -> None:

@@ -169,7 +169,7 @@ def main():
 
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.painn_denoising import PaiNN
-    from adsorbdiff_amd.sampler import gather_sites, shard_batch
+    from adsorbdiff_amd.sampler import gather_sites, shard_batch, shard_bounds
     from adsorbdiff_amd.scaling import PAINN_NB6_SCALE_FACTORS
     from adsorbdiff_amd.synthetic import make_batch
     from adsorbdiff_amd.trainer import DenoisingTrainer
@@ -182,15 +182,18 @@ def main():
     scale_factors = model.scale_factors()
     trainer = DenoisingTrainer(model, device=dev)
 
+    bounds = None
     if args.scaling == "weak":
         n_local = args.systems
         batch0 = make_batch(n_local, seed=1000 + rank, sid_offset=rank * args.systems).to(dev)
         my_ids = [rank * args.systems + i for i in range(n_local)]
+        bounds = (n_local, 4)  # every rank: the same number of systems, 4-atom adsorbates
     else:
         # the SAME synthetic batch on every rank count (seed 1000), dealt by atom count like the reference does
         full = make_batch(args.systems, seed=1000)
         if world > 1:
             batch0, my_ids = shard_batch(full, rank, world)
+            bounds = shard_bounds(full, world)  # every rank derives the exchange buffer's shape locally: ONE all_gather
         else:
             batch0, my_ids = full, list(range(args.systems))
         n_local = len(my_ids)
@@ -211,7 +214,7 @@ def main():
                        device=str(dev))
         out = den.run()
         assert den.steps_applied == args.num_steps, den.steps_applied
-        return gather_sites(out, world, via=args.gather, system_ids=my_ids)
+        return gather_sites(out, world, via=args.gather, system_ids=my_ids, bounds=bounds)
 
     def fence():
         if world > 1:
@@ -453,18 +456,21 @@ def main_eqv2(args, rank, world, dev):
 
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos
-    from adsorbdiff_amd.sampler import gather_sites, shard_batch
+    from adsorbdiff_amd.sampler import gather_sites, shard_batch, shard_bounds
     from adsorbdiff_amd.trainer import DenoisingTrainer
 
     torch.manual_seed(0)
     model = EquiformerV2S_OC20_DenoisingPos(None, None, None, **EQV2_HP).eval()
     trainer = DenoisingTrainer(model, device=dev)
+    bounds = None
     if args.scaling == "weak":
         batch0 = eqv2_batch(args.systems, seed=1000 + rank, sid_offset=rank * args.systems).to(dev)
         my_ids = [rank * args.systems + i for i in range(args.systems)]
+        bounds = (args.systems, 4)
     else:
         full = eqv2_batch(args.systems, seed=1000)
         batch0, my_ids = shard_batch(full, rank, world) if world > 1 else (full, list(range(args.systems)))
+        bounds = shard_bounds(full, world) if world > 1 else None
         batch0 = batch0.to(dev)
     n_local = len(my_ids)
     total_systems = args.systems * world if args.scaling == "weak" else args.systems
@@ -480,7 +486,7 @@ def main_eqv2(args, rank, world, dev):
         den = Denoiser(b, DiffTorchCalc(trainer), dict(params, placement_noise=placement), device=str(dev))
         out = den.run()
         assert den.steps_applied == args.num_steps, den.steps_applied
-        return gather_sites(out, world, via=args.gather, system_ids=my_ids)
+        return gather_sites(out, world, via=args.gather, system_ids=my_ids, bounds=bounds)
 
     def fence():
         if world > 1:

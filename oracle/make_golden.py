@@ -574,13 +574,110 @@ def main_eqv2():
     print("EquiformerV2 goldens written to", GOLD)
 
 
+def main_handoff():
+    # ---------------------------------------------------------------- 8. hand-off lift rule and input-side balancing
+    # (SURVEY 8f-3 / 8f-4).  The lift block of scripts/create_lmdbs/pred_traj_to_lmdb.py (a script with module-level
+    # ase / lmdb imports) is extracted from its source by line anchors and EXECUTED on seeded systems; balanced_partition
+    # and BalancedBatchSampler.__iter__ of datasets/data_parallel.py are imported and driven with a stand-in all_gather.
+    import ast
+    import textwrap
+    from types import SimpleNamespace
+
+    src = Path("/root/reference/scripts/create_lmdbs/pred_traj_to_lmdb.py").read_text().splitlines()
+    a = next(i for i, l in enumerate(src) if "ads_idx = tags_map[sid] == 2" in l)
+    z = next(i for i, l in enumerate(src) if "image.pos[ads_idx] = ads_pos" in l)
+    block = textwrap.dedent("\n".join(src[a:z + 1]))
+    ast.parse(block)
+    code = compile(block, "pred_traj_to_lmdb.py[lift block]", "exec")
+    b = make_batch(6, n_slab=36, n_ads=4, seed=77)
+    ads = b.tags == 2
+    for k, dz in enumerate((2.0, 0.05, 0.1, -0.3, -4.0, 0.0999)):
+        m = b.batch == k
+        top = float(b.pos[m & (b.tags == 1), 2].max())
+        zmin = float(b.pos[m & ads, 2].min())
+        b.pos[m & ads, 2] += top + dz - zmin
+    want = b.pos.clone()
+    for k in range(6):
+        m = b.batch == k
+        image = SimpleNamespace(pos=want[m].clone())
+        env = {"tags_map": {"s": b.tags[m].numpy()}, "sid": "s", "image": image, "abs": abs}
+        exec(code, env)
+        want[m] = image.pos
+    np.savez_compressed(GOLD / "handoff_lift.npz", pos_after=want.numpy(), **npify(batch_inputs(b)))
+    print(f"[handoff] lift rule: shifts {[(float((want - b.pos)[b.batch == k].abs().max())) for k in range(6)]}")
+
+    from adsorbdiff.datasets import data_parallel as RDP
+
+    from adsorbdiff_amd.data_parallel import BalancedBatchSampler as MySampler
+    from adsorbdiff_amd.data_parallel import balanced_partition_ref
+
+    rng = np.random.default_rng(4)
+    cases = {}
+    for name, sizes, parts in (("rand8", rng.integers(20, 230, 64), 8), ("ties4", np.array([50] * 6 + [30] * 5 + [70, 70, 10]), 4),
+                               ("two", rng.integers(1, 9, 11), 2), ("more_parts", np.array([5, 3, 9]), 3)):
+        ref = RDP.balanced_partition(np.asarray(sizes), parts)
+        mine = balanced_partition_ref(np.asarray(sizes), parts)
+        assert [list(map(int, p)) for p in ref] == mine, (name, ref, mine)
+        cases[f"{name}/sizes"] = np.asarray(sizes)
+        cases[f"{name}/parts"] = np.array(parts)
+        for r, p in enumerate(ref):
+            cases[f"{name}/part{r}"] = np.asarray(p, dtype=np.int64)
+    # the sampler's per-step balancing, all ranks: drive the reference __iter__ with an all_gather that returns what the
+    # other ranks' DistributedSamplers would contribute (no process group here)
+    sizes = rng.integers(20, 230, 53)
+    world, bs, seed, epoch = 4, 3, 0, 2
+
+    class _DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(sizes)
+
+        def __getitem__(self, i):
+            return i
+
+    def rank_batches(rank):
+        smp = torch.utils.data.DistributedSampler(_DS(), num_replicas=world, rank=rank, shuffle=True, seed=seed)
+        smp.set_epoch(epoch)
+        return list(torch.utils.data.BatchSampler(smp, bs, drop_last=False))
+
+    per_rank = [rank_batches(r) for r in range(world)]
+    for rank in range(world):
+        step = {"i": 0}
+
+        def fake_all_gather(t, device=None, _step=step):
+            out = [torch.stack([torch.tensor(per_rank[r][_step["i"]]), torch.tensor([int(sizes[j]) for j in per_rank[r][_step["i"]]])])
+                   for r in range(world)]
+            _step["i"] += 1
+            return out
+
+        ref_s = RDP.BalancedBatchSampler.__new__(RDP.BalancedBatchSampler)
+        ref_s.balance_batches, ref_s.batch_sampler, ref_s.sizes = True, per_rank[rank], sizes
+        ref_s.mode, ref_s.num_replicas, ref_s.rank, ref_s.device = "atoms", world, rank, "cpu"
+        orig = RDP.distutils.all_gather
+        RDP.distutils.all_gather = fake_all_gather
+        try:
+            ref_batches = [list(map(int, bidx)) for bidx in ref_s]
+        finally:
+            RDP.distutils.all_gather = orig
+        mine_s = MySampler(sizes, bs, world, rank, mode="atoms", shuffle=True, seed=seed)
+        mine_s.set_epoch(epoch)
+        assert [list(x) for x in mine_s] == ref_batches, (rank, ref_batches[:2])
+        for i, bb in enumerate(ref_batches):
+            cases[f"sampler/rank{rank}/step{i}"] = np.asarray(bb, dtype=np.int64)
+    cases["sampler/sizes"] = sizes
+    cases["sampler/meta"] = np.array([world, bs, seed, epoch, len(per_rank[0])])
+    np.savez_compressed(GOLD / "balanced_partition.npz", **cases)
+    print("[input side] balanced_partition and BalancedBatchSampler.__iter__ match the reference on", len(cases), "arrays")
+
+
 def main():
-    """ADF_GOLDEN_ONLY=eqv2 / painn regenerates one family (both are deterministic)."""
+    """ADF_GOLDEN_ONLY=eqv2 / painn / handoff regenerates one family (all are deterministic)."""
     only = os.environ.get("ADF_GOLDEN_ONLY")
     if only in (None, "", "painn"):
         main_painn()
     if only in (None, "", "eqv2"):
         main_eqv2()
+    if only in (None, "", "handoff"):
+        main_handoff()
     print("all goldens written to", GOLD)
 
 

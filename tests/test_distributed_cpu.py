@@ -7,7 +7,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from adsorbdiff_amd.data import Batch
-from adsorbdiff_amd.sampler import adsorbate_sites, gather_sites, shard_batch
+from adsorbdiff_amd.sampler import adsorbate_sites, gather_sites, shard_batch, shard_bounds
 from adsorbdiff_amd.synthetic import make_batch
 
 
@@ -26,8 +26,20 @@ def _worker(rank, world, port, out_dir):
     )
     mine, ids = shard_batch(full, rank, world)
     mine.pos = mine.pos + float(rank + 1)  # stand-in for "sampled" positions
-    sites = gather_sites(mine, world)
-    torch.save({"sites": sites, "ids": ids}, os.path.join(out_dir, f"r{rank}.pt"))
+    calls = {"n": 0}
+    real = dist.all_gather
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    dist.all_gather = counting
+    sites = gather_sites(mine, world)                                      # shapes agreed on first: 2 collectives
+    n_plain = calls["n"]
+    ordered = gather_sites(mine, world, system_ids=ids, bounds=shard_bounds(full, world))  # ONE collective
+    dist.all_gather = real
+    torch.save({"sites": sites, "ids": ids, "ordered": ordered, "collectives": (n_plain, calls["n"] - n_plain)},
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -40,6 +52,11 @@ def test_two_rank_shard_and_gather(tmp_path):
     r1 = torch.load(tmp_path / "r1.pt")
     # every rank holds the same gathered tensor: all 5 systems, rank-major, NaN-padded to 4 atoms
     assert r0["sites"].shape == (5, 4, 3)
+    assert r0["collectives"] == (2, 1) and r1["collectives"] == (2, 1)  # with locally derived bounds: one all_gather
+    # global system order when ids are passed: row g = system g
+    assert r0["ordered"].shape == (5, 4, 3) and torch.equal(torch.nan_to_num(r0["ordered"]), torch.nan_to_num(r1["ordered"]))
+    gid = torch.tensor(r0["ids"] + r1["ids"])
+    assert torch.equal(torch.nan_to_num(r0["ordered"]), torch.nan_to_num(r0["sites"][torch.argsort(gid)]))
     assert torch.equal(torch.nan_to_num(r0["sites"]), torch.nan_to_num(r1["sites"]))
     assert sorted(r0["ids"] + r1["ids"]) == [0, 1, 2, 3, 4]
     # atom-count balanced: the two 40-atom systems land on different ranks

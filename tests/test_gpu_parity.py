@@ -441,6 +441,20 @@ def test_lift_rule_and_final_frame_records(tmp_path):
     np.testing.assert_allclose(z["1/pos"], want[40:80], atol=2e-6)
 
 
+def test_lift_rule_vs_reference_fixture():
+    """adf_lift_adsorbates against positions produced by EXECUTING the lift block of the reference's converter
+    (scripts/create_lmdbs/pred_traj_to_lmdb.py:81-90, oracle/make_golden.py section 8) on six seeded systems: adsorbate far
+    above, 0.05 / 0.1 / 0.0999 A above, below and deep inside the surface."""
+    from adsorbdiff_amd.handoff import lift_adsorbates
+
+    fx = load_npz("handoff_lift.npz")
+    g = batch_from_fixture(fx, device=DEV)
+    lifted = lift_adsorbates(g)
+    np.testing.assert_allclose(g.pos.cpu().numpy(), fx["pos_after"], rtol=0, atol=2e-6)
+    moved = np.abs(fx["pos_after"] - fx["pos"]).reshape(6, -1).max(axis=1)
+    np.testing.assert_allclose(lifted.cpu().numpy(), moved, rtol=0, atol=2e-6)
+
+
 def test_graph_replay_matches_eager():
     """denoising_pos_params["use_graph"]: one captured hipGraph per step gives bit-identical positions."""
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
