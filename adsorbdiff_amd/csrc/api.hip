@@ -57,9 +57,6 @@ extern "C" int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, in
         ADF_HIP_CHECK(hipMemcpy(k, h->kcount, sizeof(k), hipMemcpyDeviceToHost));
         ADF_HIP_CHECK(hipMemset(h->kcount, 0, sizeof(k)));
         *message_ksteps = (int64_t)k[0];
-        if (k[1])  // development builds of message32.hip (-DM32_STAMP): wave cycles per segment of the block body
-            fprintf(stderr, "m32 stamps: S0 %llu  S1 %llu  finish %llu  S2 %llu  S3 %llu  S4 %llu  rotate %llu\n", k[1], k[2], k[3], k[4],
-                    k[5], k[6], k[7]);
     }
     for (int c = 0; c < ADF_PROF_NCAT; ++c) { ms[c] = 0.f; count[c] = 0; }
     const size_t pairs = h->prof_used / 2;
@@ -150,8 +147,6 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         h->gemm_f32 = e && strcmp(e, "f32") == 0;
         const char* e2 = getenv("ADF_MSG");
         h->msg_f32 = e2 ? strcmp(e2, "f32") == 0 : h->gemm_f32;
-        const char* e3 = getenv("ADF_MSG_KERNEL");
-        h->msg_v1 = !(e3 && strcmp(e3, "v2") == 0);  // v2 = message32.hip (experimental; measured slower: DESIGN.md 4)
     }
     if (st == ADF_OK) st = dev_alloc(&h->kcount, 8);
     if (st == ADF_OK && hipMemset(h->kcount, 0, 8 * sizeof(unsigned long long)) != hipSuccess) st = ADF_EHIP;
@@ -179,7 +174,7 @@ static void inc_free(adf_painn* h) {
 static void free_workspaces(adf_painn* h) {
     void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
                     h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec,
-                    h->cache_d2, h->cache_cid, h->cache_cnt, h->atab, h->prev_nptr, h->prev_src, h->prev_geom};
+                    h->cache_d2, h->cache_cid, h->cache_cnt, h->prev_nptr, h->prev_src, h->prev_geom};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->prev_nptr = h->prev_src = nullptr; h->prev_geom = nullptr; h->inc_valid = false;
@@ -188,7 +183,6 @@ static void free_workspaces(adf_painn* h) {
     h->e_geom = nullptr;
     h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = h->rec = nullptr;
     h->cache_d2 = nullptr; h->cache_cid = nullptr; h->cache_cnt = nullptr; h->cache_valid = false;
-    h->atab = nullptr; h->atab_valid = false;
     h->capN = h->capB = h->capE = 0;
 }
 
@@ -247,7 +241,6 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
             bw.un2_b = f(k++);
         }
     ADF_TRY(adf_pack_rbf(h, (hipStream_t)stream));
-    ADF_TRY(adf_message32_prepare());
     {   // split every GEMM weight into fp16 hi/lo (gemm16.hip)
         hipStream_t s = (hipStream_t)stream;
         const long long H = h->hp.hidden_channels, HH = H * H;
@@ -327,10 +320,6 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
         ALLOC(prev_nptr, capN + 1);
         ALLOC(prev_src, capE);
         ALLOC(prev_geom, capE);
-    }
-    if (!h->msg_f32 && !h->msg_v1) {
-        ALLOC(atab, capE * 96 + 64);
-        if (st == ADF_OK && hipMemsetAsync(h->atab, 0, 64, 0) != hipSuccess) st = ADF_EHIP;
     }
     if (st == ADF_OK) {
         h->scan_tmp_bytes = adf_scan_temp_bytes(capN + 1);
@@ -496,9 +485,7 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
                              int n_targets = 0, float* rec = nullptr, bool records_ready = false) {
     if (!records_ready) ADF_TRY(make_records(h, l, N, x, vec, vec_is_zero, rec, nullptr, s));
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
-    const int32_t st = (h->msg_f32 || h->msg_v1)
-        ? adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec)
-        : adf_message32_impl(h, l, N, x, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec);
+    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec);
     adf_prof_end(h, s);
     return st;
 }
@@ -578,7 +565,7 @@ extern "C" int32_t adf_painn_forward_subset(adf_painn_t h, const adf_batch* b, c
 // launch failure) must not leave rows behind that a later forward would trust.
 static int inc_prepare(adf_painn* h, int N) {
     const int L = h->hp.num_layers, H = h->hp.hidden_channels;
-    if (!h->inc_on || !h->moving || h->gemm_f32 || h->msg_f32 || !h->msg_v1 || L > ADF_MAX_LAYERS || !h->prev_nptr)
+    if (!h->inc_on || !h->moving || h->gemm_f32 || h->msg_f32 || L > ADF_MAX_LAYERS || !h->prev_nptr)
         return 0;
     if (N > h->inc_capN) {
         (void)hipDeviceSynchronize();

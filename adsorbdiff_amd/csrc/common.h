@@ -121,12 +121,8 @@ struct adf_painn {
     //  range, 5 non-finite or fp16-range-exceeding activation (gemm16.hip), 6-7 unused}
     int32_t* flags;
     float *x, *vecA, *vecB, *y, *xh, *vv, *cat, *dot;  // node buffers
-    float* rec;          // [(N+1)][H/32][160] gather records of the message kernels (message32.hip)
-    // radial-basis MFMA operand per edge, fp16 hi/lo (message32.hip): 64 zero bytes, then [capE][96 B]
-    unsigned char* atab;
-    bool atab_valid;     // built for the handle's current graph
+    float* rec;          // [(N+1)][H/32][160] gather records of the message kernel (message.hip)
     bool rbf_uniform;    // Gaussian centres are k/(R-1): the message kernel may use its recurrence (ADF_MSG_RBF=direct: never)
-    bool msg_v1;         // default; ADF_MSG_KERNEL=v2 selects message32.hip (experimental)
     // Layer-0 gather records depend on the atomic numbers only (x0 = emb(Z), vec0 = 0).  While a static-atom
     // promise is in force (adf_graph_set_moving: same batch, only flagged atoms move) they are computed once.
     float* rec0;
@@ -199,11 +195,6 @@ size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s,
                          const int32_t* tlist = nullptr, int n_targets = 0, const float* rec = nullptr);
-int32_t adf_message32_impl(adf_painn* h, int layer, int N, const float* x, const float* vec, float* x_out,
-                           float* vec_out, bool vec_is_zero, hipStream_t s, const int32_t* tlist = nullptr,
-                           int n_targets = 0, const float* rec = nullptr);
-int32_t adf_message32_prepare();
-int32_t adf_build_atab(adf_painn* h, int N, hipStream_t s);
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
 int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s,
                          float* rec = nullptr);

@@ -53,6 +53,7 @@ struct eq_dims {
     int rbase[EQ_MAX_M + 1];   // first m-major reduced index of order m (m = 0: 0)
     int rad_off[EQ_MAX_M + 1]; // column offset of order m in a radial row, in units of the input channel count
     int RW;                    // sum_m (L - m + 1)
+    int presplit_rows;         // rotate-in with fp16 hi/lo output: rows of the order-0 operand buffer (set per launch)
     int j_off[EQ_MAX_L + 2];   // offset of J_l in the concatenated table
     short r_m[64], r_sgn[64], r_l[64];  // m-major reduced index -> (order m, 0: +m or m = 0 / 1: -m, degree l)
     float resc[EQ_MAX_L + 1];  // m-truncation rescale sqrt((2l+1)/(2M+1)) for l > M (so3.py:160-186)
@@ -69,7 +70,7 @@ struct adf_eqv2 {
     eq_dims d;
     eq_dims* d_dev;   // device copy (kernels that index its tables per lane)
     int device, num_cus;
-    bool weights_set, consts_set, exact_f32, s2_emit_mag;
+    bool weights_set, consts_set, exact_f32, s2_emit_mag, presplit;
     // constants (device)
     float *jd, *to_red, *from_red, *to_full, *from_full;
     // weights
@@ -131,8 +132,11 @@ int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t*
 int32_t eq_launch_radial_pre_pairs(const adf_eqv2* h, const eq_radial* r, const float* src_emb, const float* dst_emb,
                                    float* out, hipStream_t s);
 // rsp (optional): per-order arrays that receive the power-of-two lifts of the operand rows it writes
+// presplit: write the operand rows as lifted fp16 hi / lo images (for eq_launch_gemm16p) instead of fp32
 int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, const int32_t* Z, int pair_ne, int n0, int n1,
-                            float* const* mbuf, float* const* rsp, hipStream_t s);
+                            float* const* mbuf, float* const* rsp, bool presplit, hipStream_t s);
+int32_t eq_launch_gemm16p(const void* Ahi, const void* Alo, const float* mag, const adf_w16* W, const float* bias, float* Cm,
+                          int ldc, long long M, int N, int K, int act, hipStream_t s);
 // rsp (optional): per-order arrays that receive the power-of-two lifts of the output rows (matrix-core version only;
 // *rs_written tells whether they were filled)
 int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,

@@ -121,6 +121,7 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     // the S2 activation can hand the magnitudes of its output rows to the second convolution (atomics in its epilogue)
     // instead of a separate pass over them: measured slower on MI355X (+8 ms vs -3 ms per forward at 256 k edges): off
     { const char* e2 = getenv("ADF_EQV2_S2_EMIT"); h->s2_emit_mag = e2 && atoi(e2) != 0; }
+    { const char* e3 = getenv("ADF_EQV2_PRESPLIT"); h->presplit = !(e3 && atoi(e3) == 0); }
     h->prof_ev = new std::vector<hipEvent_t>();
     h->prof_cat = new std::vector<int>();
     int32_t st = eq_alloc(&h->flags, EQ_NFLAGS);
@@ -648,18 +649,32 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
         const bool tab = h->rad_static && at->rad.table;
         if (!tab) ADF_TRY(eq_radial(h, &at->rad, at->src_emb, at->dst_emb, Z, n0, n1, Eub, &b, b.rad, N, s));
         const bool lifts = !h->exact_f32;
+        // first convolution on pre-split operands (rotate-in writes lifted fp16 hi / lo rows, the product kernel copies
+        // them): every order's weight must have its fp16 image and a contraction length that is a multiple of 32
+        bool pre = lifts && h->presplit && at->c1_m0.has16 && at->c1_m0.in % 32 == 0 && (at->c1_m0.out & 3) == 0;
+        for (int m = 1; m <= d.M; ++m) pre = pre && at->c1_m[m - 1].has16 && at->c1_m[m - 1].in % 32 == 0 && (at->c1_m[m - 1].out & 3) == 0;
         {
             eq_prof_scope ps(h, EQ_PROF_ROTATE, s);
             ADF_TRY(eq_launch_rotate_in(h, y, tab ? at->rad.table : b.rad, Z, tab ? h->hp.max_num_elements : 0, n0, n1, b.m,
-                                        lifts ? b.rsb : nullptr, s));
+                                        lifts ? b.rsb : nullptr, pre, s));
         }
         {
             eq_prof_scope ps(h, EQ_PROF_CONV, s);
-            ADF_TRY(eq_gemm(h, b.m[0], at->c1_m0.in, nullptr, &at->c1_m0, true, b.y[0], at->c1_m0.out, nullptr, Eub, 0, false, s,
-                            lifts ? b.rsb[0] : nullptr));
-            for (int m = 1; m <= d.M; ++m)
-                ADF_TRY(eq_gemm(h, b.m[m], at->c1_m[m - 1].in, nullptr, &at->c1_m[m - 1], false, b.y[m], at->c1_m[m - 1].out,
-                                nullptr, 2 * Eub, 0, false, s, lifts ? b.rsb[m] : nullptr));
+            if (pre) {
+                for (int m = 0; m <= d.M; ++m) {
+                    const eq_lin* W = m == 0 ? &at->c1_m0 : &at->c1_m[m - 1];
+                    const long long rows = m == 0 ? Eub : 2 * Eub;
+                    const _Float16* hi = reinterpret_cast<const _Float16*>(b.m[m]);
+                    ADF_TRY(eq_launch_gemm16p(hi, hi + (size_t)rows * W->in, b.rsb[m], &W->w16, m == 0 ? W->b : nullptr, b.y[m],
+                                              W->out, rows, W->out, W->in, 0, s));
+                }
+            } else {
+                ADF_TRY(eq_gemm(h, b.m[0], at->c1_m0.in, nullptr, &at->c1_m0, true, b.y[0], at->c1_m0.out, nullptr, Eub, 0, false, s,
+                                lifts ? b.rsb[0] : nullptr));
+                for (int m = 1; m <= d.M; ++m)
+                    ADF_TRY(eq_gemm(h, b.m[m], at->c1_m[m - 1].in, nullptr, &at->c1_m[m - 1], false, b.y[m], at->c1_m[m - 1].out,
+                                    nullptr, 2 * Eub, 0, false, s, lifts ? b.rsb[m] : nullptr));
+            }
         }
         { eq_prof_scope ps(h, EQ_PROF_ATTN, s); ADF_TRY(eq_launch_alpha(h, at, b.y[0], at->c1_m0.out, n0, n1, b.alpha, s)); }
         bool rs_ok = false;
@@ -843,6 +858,38 @@ extern "C" int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos,
         }
     }
     return ADF_OK;
+}
+
+// Stand-alone C = act(A . W^T + b) through the dense-product kernels of this path (unit tests, micro-benchmarks).
+// mode 0: exact f32 (any shape); 1: f16x3 with per-row lifts, fp32 A staged and split in the kernel; 2: f16x3 on
+// pre-split fp16 hi / lo rows (eq_gemm16p_kernel).  `repeat` > 1 re-runs the product kernel alone (timing).
+int32_t eq_launch_presplit(const float* A, const float* mag, long long M, int K, void* hi, void* lo, hipStream_t s);
+
+extern "C" int32_t adf_eqv2_linear_forward(const float* A, const float* W, const float* bias, float* Cm, int64_t M, int32_t N,
+                                           int32_t K, int32_t act, int32_t mode, int32_t repeat, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!A || !W || !Cm || M <= 0 || N <= 0 || K <= 0) { adf_set_error("bad argument"); return ADF_EINVAL; }
+    if (mode == 0) return eq_gemm_f32(A, K, nullptr, W, bias, Cm, N, nullptr, M, N, K, act, false, s);
+    const eq_rowmap am = {K, 1, 0}, cm = {N, 1, 0};
+    if (!eq_gemm16_ok(A, &am, Cm, &cm, N, K)) { adf_set_error("shape not taken by the f16x3 kernels"); return ADF_EINVAL; }
+    unsigned char* buf = nullptr;
+    const size_t n = (size_t)N * K, ma = (size_t)M * K;
+    ADF_TRY(eq_alloc(&buf, n * 4 + 64 + (size_t)M * 4 + (mode == 2 ? ma * 4 : 0) + 64));
+    adf_w16 w16;
+    w16.hi = buf; w16.lo = buf + n * 2; w16.inv_scale = reinterpret_cast<float*>(buf + n * 4); w16.bias_perm = nullptr;
+    unsigned int* scratch = reinterpret_cast<unsigned int*>(buf + n * 4 + 16);
+    float* mag = reinterpret_cast<float*>(buf + n * 4 + 64);
+    unsigned char* split = buf + n * 4 + 64 + (((size_t)M * 4 + 63) / 64) * 64;
+    int32_t st = adf_split_weight(W, (long long)n, &w16, scratch, s);
+    if (st == ADF_OK) st = eq_launch_rowscale(A, &am, M, K, mag, s);
+    if (st == ADF_OK && mode == 2) st = eq_launch_presplit(A, mag, M, K, split, split + ma * 2, s);
+    for (int r = 0; r < (repeat > 0 ? repeat : 1) && st == ADF_OK; ++r) {
+        if (mode == 2) st = eq_launch_gemm16p(split, split + ma * 2, mag, &w16, bias, Cm, N, M, N, K, act, s);
+        else st = eq_launch_gemm16(A, &am, mag, &w16, bias, Cm, &cm, M, N, K, act, false, s, nullptr);
+    }
+    (void)hipStreamSynchronize(s);
+    eq_free(buf);
+    return st;
 }
 
 // ---------------------------------------------------------------------------------------------- counters / profile

@@ -334,25 +334,39 @@ __global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __re
                 rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + k1);
             }
         }
+        // Fragment reads run one row block ahead of the MFMAs that consume them (the compiler's own order waits on a read
+        // right after issuing it, ~14 exposed LDS round trips per k-tile): the 6 MFMAs of block i cover the reads of i + 1.
+        half8 bh[2][NJ], bl[2][NJ], ah[2], al[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 bh[NJ], bl[NJ];
+        for (int j = 0; j < NJ; ++j) {
+            bh[0][j] = *reinterpret_cast<const half8*>(Bhi + fb + j * 32 * GLD);
+            bl[0][j] = *reinterpret_cast<const half8*>(Blo + fb + j * 32 * GLD);
+        }
+        ah[0] = *reinterpret_cast<const half8*>(Ahi + fa);
+        al[0] = *reinterpret_cast<const half8*>(Alo + fa);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                bh[j] = *reinterpret_cast<const half8*>(Bhi + fb + j * 32 * GLD + ks * 16);
-                bl[j] = *reinterpret_cast<const half8*>(Blo + fb + j * 32 * GLD + ks * 16);
-            }
+        for (int step = 0; step < 2 * MI; ++step) {
+            const int ks = step / MI, i = step % MI, cur = step & 1, nxt = cur ^ 1;
+            if (step + 1 < 2 * MI) {
+                const int ks2 = (step + 1) / MI, i2 = (step + 1) % MI;
+                ah[nxt] = *reinterpret_cast<const half8*>(Ahi + fa + i2 * 32 * GLD + ks2 * 16);
+                al[nxt] = *reinterpret_cast<const half8*>(Alo + fa + i2 * 32 * GLD + ks2 * 16);
+                if (i2 == 0) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const half8 ah = *reinterpret_cast<const half8*>(Ahi + fa + i * 32 * GLD + ks * 16);
-                const half8 al = *reinterpret_cast<const half8*>(Alo + fa + i * 32 * GLD + ks * 16);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) {
+                        bh[ks2][j] = *reinterpret_cast<const half8*>(Bhi + fb + j * 32 * GLD + ks2 * 16);
+                        bl[ks2][j] = *reinterpret_cast<const half8*>(Blo + fb + j * 32 * GLD + ks2 * 16);
+                    }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[ks][j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -401,6 +415,207 @@ __global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __re
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Pre-split A operand: the producer (rotate-in) already wrote fp16 hi / lo images of the rows, lifted by the row's own
+// power of two (mag[row] = the row's max |a| before the lift), so staging is a pure 16-byte copy — the fp32 kernel above
+// spends ~4 VALU instructions per MFMA on the conversion (SQ counters, profiles/).  256 x 256 x 32 tile, 8 waves; LDS rows
+// are 64 bytes, unpadded, with the 16-byte chunk index XOR-ed by (row >> 2) & 3 (conflict-free ds_write_b128 and
+// ds_read_b128); TWO LDS buffers: tile t+1 is written and tile t+2 requested while tile t is multiplied, one barrier
+// per k-tile; fragment reads run one row block ahead of their MFMAs.
+template <int ACT>
+__global__ __launch_bounds__(512, 2) void eq_gemm16p_kernel(const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo,
+                                                            const float* __restrict__ mag, const _Float16* __restrict__ Whi,
+                                                            const _Float16* __restrict__ Wlo, const float* __restrict__ inv_scale,
+                                                            const float* __restrict__ bias, float* __restrict__ Cm, int ldc,
+                                                            long long M, int N, int K, int tiles_n) {
+    constexpr int MI = 4, NJ = 2, TM = 256, TN = 256, RB = 32;  // RB halves (64 B) per LDS row
+    constexpr int BUF = (2 * TM + 2 * TN) * RB;                  // halves per buffer (64 KB)
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsp[];
+    __shared__ float rinv[TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int id = blockIdx.x, xcd = id & 7, qd = id >> 3;
+    const long long tile_m = (long long)(qd / tiles_n) * 8 + xcd;
+    const int tile_n = qd % tiles_n;
+    const long long m0 = tile_m * TM;
+    const int n0 = tile_n * TN;
+    if (m0 >= M) return;
+
+    // staging: 2 chunks of 16 B per thread and image: f = tid + 512 i -> row f >> 2, chunk f & 3
+    size_t a_src[2];
+    int w_src[2], st_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + 512 * i;
+        const int row = f >> 2, part = f & 3;
+        long long grow = m0 + row;
+        if (grow > M - 1) grow = M - 1;
+        a_src[i] = (size_t)grow * K + part * 8;
+        w_src[i] = min(n0 + row, N - 1) * K + part * 8;
+        st_off[i] = row * RB + ((part ^ ((row >> 2) & 3)) * 8);
+    }
+    if (tid < TM) {
+        long long grow = m0 + tid;
+        if (grow > M - 1) grow = M - 1;
+        rinv[tid] = 1.0f / eq16_lift(mag[grow]);
+    }
+    half8 rah[2], ral[2], rwh[2], rwl[2];
+    auto load_tile = [&](int k1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rah[i] = *reinterpret_cast<const half8*>(Ahi + a_src[i] + k1);
+            ral[i] = *reinterpret_cast<const half8*>(Alo + a_src[i] + k1);
+            rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + k1);
+            rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i] + k1);
+        }
+    };
+    auto store_tile = [&](_Float16* buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<half8*>(buf + st_off[i]) = rah[i];
+            *reinterpret_cast<half8*>(buf + TM * RB + st_off[i]) = ral[i];
+            *reinterpret_cast<half8*>(buf + 2 * TM * RB + st_off[i]) = rwh[i];
+            *reinterpret_cast<half8*>(buf + (2 * TM + TN) * RB + st_off[i]) = rwl[i];
+        }
+    };
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / GK;
+    // fragment addresses: row (lane & 31) of a 32-row block, chunk c = 2 ks + (lane >> 5), swizzled by (row >> 2) & 3
+    // (the 32-row blocks start at multiples of 32, so the swizzle depends on lane only)
+    const int frow = lane & 31, fsw = (frow >> 2) & 3, fkh = lane >> 5;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = frow * RB + (((2 * ks + fkh) ^ fsw) * 8);
+    load_tile(0);
+    store_tile(ldsp);
+    if (nk > 1) load_tile(GK);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        _Float16* cur = ldsp + (kt & 1) * BUF;
+        _Float16* nxt = ldsp + ((kt + 1) & 1) * BUF;
+        if (kt + 1 < nk) store_tile(nxt);          // tile kt+1 (in registers since the previous iteration)
+        if (kt + 2 < nk) load_tile((kt + 2) * GK);  // tile kt+2: its latency hides under this tile's MFMAs
+        const _Float16* Ah = cur + wm * RB;
+        const _Float16* Al = cur + TM * RB + wm * RB;
+        const _Float16* Bh = cur + 2 * TM * RB + wn * RB;
+        const _Float16* Bl = cur + (2 * TM + TN) * RB + wn * RB;
+        half8 bh[2][NJ], bl[2][NJ], ah[2], al[2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bh[0][j] = *reinterpret_cast<const half8*>(Bh + j * 32 * RB + foff[0]);
+            bl[0][j] = *reinterpret_cast<const half8*>(Bl + j * 32 * RB + foff[0]);
+        }
+        ah[0] = *reinterpret_cast<const half8*>(Ah + foff[0]);
+        al[0] = *reinterpret_cast<const half8*>(Al + foff[0]);
+#pragma unroll
+        for (int step = 0; step < 2 * MI; ++step) {
+            const int ks = step / MI, i = step % MI, c = step & 1, nx = c ^ 1;
+            if (step + 1 < 2 * MI) {
+                const int ks2 = (step + 1) / MI, i2 = (step + 1) % MI;
+                ah[nx] = *reinterpret_cast<const half8*>(Ah + i2 * 32 * RB + foff[ks2]);
+                al[nx] = *reinterpret_cast<const half8*>(Al + i2 * 32 * RB + foff[ks2]);
+                if (i2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        bh[ks2][j] = *reinterpret_cast<const half8*>(Bh + j * 32 * RB + foff[ks2]);
+                        bl[ks2][j] = *reinterpret_cast<const half8*>(Bl + j * 32 * RB + foff[ks2]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[c], bh[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bl[ks][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[c], bh[ks][j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    const float isc = *inv_scale;
+    const int q = lane & 31;
+    float* T = reinterpret_cast<float*>(ldsp) + wave * (32 * GTLD);  // [32 rows][64] floats per wave
+    const int cb = n0 + wn;
+    const float bv0 = (bias && cb + q < N) ? bias[cb + q] : 0.f;
+    const float bv1 = (bias && cb + 32 + q < N) ? bias[cb + 32 + q] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sc = isc * rinv[wm + 32 * i + lr];
+            float v0 = acc[i][0][r] * sc + bv0, v1 = acc[i][1][r] * sc + bv1;
+            if (ACT == 2) { v0 = eq16_silu(v0); v1 = eq16_silu(v1); }
+            T[lr * GTLD + q] = v0;
+            T[lr * GTLD + 32 + q] = v1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = lane + 64 * it;
+            const int lr = item >> 4, c4 = item & 15;
+            const long long row = m0 + wm + 32 * i + lr;
+            const int col = cb + 4 * c4;
+            if (row < M && col < N)
+                *reinterpret_cast<float4*>(Cm + row * (long long)ldc + col) = *reinterpret_cast<const float4*>(T + lr * GTLD + 4 * c4);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int32_t eq_launch_gemm16p(const void* Ahi, const void* Alo, const float* mag, const adf_w16* W, const float* bias, float* Cm,
+                          int ldc, long long M, int N, int K, int act, hipStream_t s) {
+    if (M <= 0 || N <= 0) return ADF_OK;
+    if (K % GK != 0 || (N & 3) || (ldc & 3)) { adf_set_error("eq_gemm16p: bad shape"); return ADF_EINVAL; }
+    const int tiles_n = (N + 255) / 256;
+    const long long tiles_m8 = ((M + 255) / 256 + 7) / 8 * 8;
+    const long long nb = tiles_m8 * tiles_n;
+    if (nb > 0x7fffffffLL) { adf_set_error("eq_gemm16p: grid too large"); return ADF_EINVAL; }
+    const size_t dyn = 2 * (size_t)(2 * 256 + 2 * 256) * 32 * sizeof(_Float16);  // 128 KB
+    if (act == 2) {
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_gemm16p_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(eq_gemm16p_kernel<2>, dim3((unsigned)nb), dim3(512), dyn, s, (const _Float16*)Ahi, (const _Float16*)Alo,
+                           mag, (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, ldc, M, N, K, tiles_n);
+    } else {
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_gemm16p_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(eq_gemm16p_kernel<0>, dim3((unsigned)nb), dim3(512), dyn, s, (const _Float16*)Ahi, (const _Float16*)Alo,
+                           mag, (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, ldc, M, N, K, tiles_n);
+    }
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// A [M, K] fp32 + row magnitudes -> lifted fp16 hi / lo images (unit-test / benchmark path of eq_gemm16p_kernel; in the
+// model the producer kernel writes them directly)
+__global__ void eq_presplit_kernel(const float* __restrict__ A, const float* __restrict__ mag, long long M, int K,
+                                   _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * K) return;
+    const float sv = A[t] * eq16_lift(mag[t / K]);
+    const _Float16 h = (_Float16)sv;
+    hi[t] = h;
+    lo[t] = (_Float16)(sv - (float)h);
+}
+
+int32_t eq_launch_presplit(const float* A, const float* mag, long long M, int K, void* hi, void* lo, hipStream_t s) {
+    const long long n = M * K;
+    hipLaunchKernelGGL(eq_presplit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, mag, M, K, (_Float16*)hi,
+                       (_Float16*)lo);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
 }
 
 // shapes the kernel takes: K % 32 == 0, N % 4 == 0, 16-byte aligned rows of A and C

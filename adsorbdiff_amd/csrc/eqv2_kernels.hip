@@ -440,11 +440,13 @@ int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t*
 // thread = one of the 2C input channels.
 struct eq_ptrs { float* p[EQ_MAX_M + 1]; };
 
-template <int LT>
+template <int LT, bool PRESPLIT>
 __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __restrict__ rad, const float* __restrict__ wig,
                                     const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src,
                                     const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb, eq_ptrs rs,
                                     const int32_t* __restrict__ Z, int pair_ne) {
+    // PRESPLIT: the operand rows are written as fp16 hi / lo images lifted by the row's own power of two (what
+    // eq_gemm16p_kernel stages by plain copies): mb.p[m] holds [rows][nm 2C] halves of hi followed by the same of lo
     __shared__ unsigned int smax[2 * EQ_MAX_M + 1];  // |.| maxima of the edge's operand rows (bit patterns order like floats)
     const long long ebase = eptr[n0];
     const long long e = ebase + blockIdx.x;
@@ -454,14 +456,15 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
     if (threadIdx.x < 2 * EQ_MAX_M + 1) smax[threadIdx.x] = 0u;
     __syncthreads();
     const long long el = e - ebase;
+    const long long Erows = eptr[n1] - ebase;
     float rmx[2 * LT + 1];
 #pragma unroll
     for (int t = 0; t < 2 * LT + 1; ++t) rmx[t] = 0.f;
+    float vals[PRESPLIT ? (LT + 1) * (LT + 1) : 1];
     if (on) {
         const int node = c < d.C ? e_src[e] : e_dst[e];
         const float* yr = y + (size_t)node * d.S * d.C + (c < d.C ? c : c - d.C);
         const float* D = wig + (size_t)e * d.DR;
-        // radial weights: per edge, or (pair_ne > 0) one row per element pair (Z_src, Z_tgt)
         long long rrow = el;
         if (pair_ne > 0) {  // atomic numbers are range-checked by eq_check_z_kernel; clamped here against stray reads
             const int zs = min(max(Z[e_src[e]], 0), pair_ne - 1), zt = min(max(Z[e_dst[e]], 0), pair_ne - 1);
@@ -485,8 +488,12 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
                 for (int m = 0; m < 2 * l + 1; ++m) a += Dl[ri * (2 * l + 1) + m] * v[m];
                 const int nm = LT - am + 1;
                 a *= rr[(size_t)(d.rad_off[am] + (l - am)) * C2 + c];
-                const long long row = am == 0 ? el : 2 * el + (mp < 0 ? 1 : 0);
-                mb.p[am][(size_t)row * nm * C2 + (size_t)(l - am) * C2 + c] = a;
+                if (PRESPLIT) {
+                    vals[l * l + l + mp] = a;
+                } else {
+                    const long long row = am == 0 ? el : 2 * el + (mp < 0 ? 1 : 0);
+                    mb.p[am][(size_t)row * nm * C2 + (size_t)(l - am) * C2 + c] = a;
+                }
                 rmx[am == 0 ? 0 : 2 * am - 1 + (mp < 0 ? 1 : 0)] = fmaxf(rmx[am == 0 ? 0 : 2 * am - 1 + (mp < 0 ? 1 : 0)], fabsf(a));
             }
         }
@@ -508,17 +515,47 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
         const long long row = m == 0 ? el : 2 * el + ((t + 1) & 1);
         rs.p[m][row] = __uint_as_float(smax[t]);
     }
+    if (PRESPLIT && on) {
+        (void)Erows;
+#pragma unroll
+        for (int l = 0; l <= LT; ++l) {
+            const int ml = l < d.M ? l : d.M;
+#pragma unroll
+            for (int mp = -l; mp <= l; ++mp) {
+                const int am = mp < 0 ? -mp : mp;
+                if (am > ml) continue;
+                const int nm = LT - am + 1, sg = mp < 0 ? 1 : 0;
+                const float lift = eq_pow2_lift(__uint_as_float(smax[am == 0 ? 0 : 2 * am - 1 + sg]));
+                const float sv = vals[l * l + l + mp] * lift;
+                const _Float16 hh = (_Float16)sv;
+                const long long row = am == 0 ? el : 2 * el + sg;
+                const size_t rows_total = (size_t)(am == 0 ? 1 : 2) * (size_t)d.presplit_rows;
+                _Float16* hi = reinterpret_cast<_Float16*>(mb.p[am]);
+                const size_t off = (size_t)row * nm * C2 + (size_t)(l - am) * C2 + c;
+                hi[off] = hh;
+                hi[rows_total * nm * C2 + off] = (_Float16)(sv - (float)hh);
+            }
+        }
+    }
 }
 
 int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad, const int32_t* Z, int pair_ne, int n0, int n1,
-                            float* const* mbuf, float* const* rsp, hipStream_t s) {
+                            float* const* mbuf, float* const* rsp, bool presplit, hipStream_t s) {
     const long long Eub = eq_edge_bound(h, n1 - n0);
     if (Eub <= 0) return ADF_OK;
+    if (presplit && !rsp) { adf_set_error("rotate_in: pre-split output needs the row magnitudes"); return ADF_EINVAL; }
+    eq_dims dd = h->d;
+    dd.presplit_rows = (int)Eub;  // rows of the order-0 operand buffer: the lo image starts after rows * width halves
     eq_ptrs mb, rs;
     for (int m = 0; m <= EQ_MAX_M; ++m) { mb.p[m] = m <= h->d.M ? mbuf[m] : nullptr; rs.p[m] = (rsp && m <= h->d.M) ? rsp[m] : nullptr; }
     const int bd = (2 * h->d.C + 63) / 64 * 64;
-#define EQ_RI(LT_) hipLaunchKernelGGL(eq_rotate_in_kernel<LT_>, dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
-                                      h->e_src, h->e_dst, n0, n1, h->d, mb, rs, Z, pair_ne)
+#define EQ_RI(LT_)                                                                                                     \
+    if (presplit)                                                                                                      \
+        hipLaunchKernelGGL((eq_rotate_in_kernel<LT_, true>), dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
+                           h->e_src, h->e_dst, n0, n1, dd, mb, rs, Z, pair_ne);                                       \
+    else                                                                                                               \
+        hipLaunchKernelGGL((eq_rotate_in_kernel<LT_, false>), dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
+                           h->e_src, h->e_dst, n0, n1, dd, mb, rs, Z, pair_ne)
     EQ_FOR_L(h->d.L, EQ_RI)
 #undef EQ_RI
     ADF_HIP_CHECK(hipGetLastError());

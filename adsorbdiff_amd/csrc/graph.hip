@@ -391,7 +391,6 @@ int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
                        h->flags);
     ADF_HIP_CHECK(hipGetLastError());
     h->lastN = N; h->lastB = B;
-    h->atab_valid = false;
     h->last_reps[0] = p.r0; h->last_reps[1] = p.r1; h->last_reps[2] = p.r2;
     return ADF_OK;
 }

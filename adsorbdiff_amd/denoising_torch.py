@@ -220,7 +220,9 @@ class Denoiser:
 
                 # Nothing to hand to the host between steps (no per-step frames, no host noise hook, no graph replay):
                 # the whole loop is one library call (adf_sample), polling the early-stop flag every `check_every` steps.
-                fused_loop = (not use_graph) and self.noise_fn is None and (frames is None or not self.save_full)
+                step_hook = params.get("step_hook")  # extension: callable(t) after every applied step (diagnostics)
+                fused_loop = ((not use_graph) and self.noise_fn is None and step_hook is None
+                              and (frames is None or not self.save_full))
                 if fused_loop:
                     zt = zr = None
                     if not ode:  # device generator, drawn in the reference's order (:274-289): z_tr then z_rot, per step
@@ -255,6 +257,8 @@ class Denoiser:
                             assert torch.equal(state, snapshot[1])
                     if frames is not None and (self.save_full or t_idx == T - 1):
                         frames.append(pos.clone())
+                    if step_hook is not None:
+                        step_hook(t_idx)
                     if early and (t_idx % check_every == check_every - 1):
                         if int(state[1].item()):
                             break

@@ -51,6 +51,9 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", choices=("painn", "eqv2"), default="painn",
                     help="painn = BASELINE config 2/3 (the headline); eqv2 = config 4 (EquiformerV2 denoiser, L_max = 6)")
+    ap.add_argument("--mode", choices=("sample", "train"), default="sample",
+                    help="sample = the headline (reverse-diffusion sampling); train = BASELINE config 5: one score-matching "
+                         "training step (PaiNN, --systems graphs per GPU, weak scaling, gradient all-reduce over RCCL)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
@@ -69,7 +72,12 @@ def parse():
                                                       "testing the N>1 path with several ranks on one GPU)")
     a = ap.parse_args()
     if a.systems is None:
-        a.systems = 1000 if a.model == "painn" else 128
+        a.systems = 256 if a.mode == "train" else (1000 if a.model == "painn" else 128)
+    if a.mode == "train":
+        if a.model != "painn":
+            raise SystemExit("bench.py --mode train: the training step exists for the PaiNN denoiser (config 5)")
+        if a.steps == 2 and a.warmup == 1:
+            a.steps, a.warmup = 10, 3
     return a
 
 
@@ -119,8 +127,8 @@ def cpu_baseline(model_sd, scale_factors, params, full=False):
         return {"systems": n_sys, "reverse_steps": n_steps, "seconds": round(dt, 2),
                 "system_steps_per_s": n_sys * n_steps / dt}
 
-    wide = run(64, 1) if full else run(12, 1)
-    loop = run(8, params["num_steps"]) if full else run(2, 4)
+    wide = run(64, 1) if full else run(32, 1)
+    loop = run(8, params["num_steps"]) if full else run(4, 10)
     best = max(wide["system_steps_per_s"], loop["system_steps_per_s"])
     return {
         "value": best / params["num_steps"],
@@ -164,6 +172,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.mode == "train":
+        return main_train(args, rank, world, dev)
     if args.model == "eqv2":
         return main_eqv2(args, rank, world, dev)
 
@@ -240,8 +250,53 @@ def main():
 
     # Secondary measurement, N = 1 only, never `value`: the same pass with the model outputs evaluated on the
     # adsorbate atoms only (the stepper reads nothing else; sampled positions are bit-identical, checked here).
-    ads_only = exact_f32 = all_rows = None
+    ads_only = exact_f32 = all_rows = moving = None
     if world == 1 and not args.no_secondary:
+        # Stall-free secondary.  With the seed-0 random-init weights the scores are small and, as sigma shrinks along the
+        # schedule, most adsorbates stop moving by a representable amount after step ~30: the incremental layers then
+        # recompute nothing for those systems, which a trained model would not allow.  Same workload with the last linear
+        # map of both heads scaled by 100 so that every system keeps moving through step 49 (checked: the per-step
+        # fraction of recomputed rows is printed).
+        import copy
+
+        model_mv = copy.deepcopy(model).to(dev).eval()
+        with torch.no_grad():
+            for hname in ("out_forces", "out_forces2"):
+                getattr(model_mv, hname).output_network[1].vec2_proj.weight.mul_(100.0)
+        model_mv._engine = None
+        trainer_mv = DenoisingTrainer(model_mv, device=dev)
+        eng_mv = model_mv.engine(dev)
+        rows_log = []
+
+        def hook(t):
+            c_ = eng_mv.counters()
+            rows_log.append((int(c_.inc_rows), int(c_.inc_rows_full)))
+
+        def pass_mv(extra):
+            b = batch0.clone()
+            torch.manual_seed(0)
+            den = Denoiser(b, DiffTorchCalc(trainer_mv), dict(params, placement_noise=placement, **extra), device=str(dev))
+            return gather_sites(den.run(), 1)
+
+        pass_mv({"step_hook": hook})  # diagnostic pass (per-step host reads; also warms this engine up)
+        frac = []
+        for i, (r, f) in enumerate(rows_log):
+            r0, f0 = rows_log[i - 1] if i and rows_log[i - 1][0] <= r else (0, 0)
+            frac.append(round((r - r0) / max(f - f0, 1), 3))
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        sites_mv = pass_mv({})
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        moved_last = None
+        moving = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
+                  "recomputed_row_fraction_per_step": frac,
+                  "note": "value_moving: the same pass with both heads' last linear map x100 so that no system freezes "
+                          "before step 49; recomputed_row_fraction_per_step = layer x atom rows the incremental layers "
+                          "recomputed at each reverse step / all rows (1.0 = everything); one pass, not part of `value`"}
+        del moved_last, sites_mv
+        eng_mv.close()
+        del model_mv, trainer_mv
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         sites_full = one_pass({"incremental_layers": False})
@@ -397,6 +452,7 @@ def main():
                         "pattern alone sustains ~28 TB/s) - see DESIGN.md 4.",
             },
             "measured_peaks": measured,
+            "value_moving": moving,
             "incremental_layers_off": all_rows,
             "scores_on_adsorbate_only": ads_only,
             "exact_f32": exact_f32,
@@ -404,6 +460,94 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cpu_sd, scale_factors, params, full=args.cpu_full)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_train(args, rank, world, dev):
+    """BASELINE config 5: conditional-training step of the PaiNN denoiser (score-matching loss, forward + backward) on
+    OC20-IS2RE-shaped graphs, one process per GPU (weak scaling: `--systems` ~200-atom graphs per GPU and step), gradients
+    averaged by a bucketed all-reduce (backend nccl = RCCL over xGMI).  A "step" = noising + forward + loss + backward +
+    all-reduce + clip + AdamW + EMA on one synthetic batch resident in HBM."""
+    import torch
+    import torch.distributed as dist
+
+    import adsorbdiff_amd.train_step as TS
+    from adsorbdiff_amd.painn_denoising import PaiNN
+    from adsorbdiff_amd.scaling import PAINN_NB6_SCALE_FACTORS
+    from adsorbdiff_amd.so3_tables import Igso3Tables
+    from adsorbdiff_amd.synthetic import make_batch
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    torch.manual_seed(0)
+    model = PaiNN(None, 50, 1, hidden_channels=512, num_layers=6, num_rbf=128, cutoff=10.0, max_neighbors=50,
+                  scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True)
+    tr = DenoisingTrainer(model, device=dev)
+    tr.setup_training(dict(ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55), lr=1e-4,
+                      tables=Igso3Tables.shared())
+    batch = make_batch(args.systems, seed=2000 + rank).to(dev)
+    ar_events = []
+    real_allreduce = TS.allreduce_gradients
+
+    def timed_allreduce(m, w, *a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_allreduce(m, w, *a, **k)
+        e1.record()
+        ar_events.append((e0, e1))
+
+    TS.allreduce_gradients = timed_allreduce
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = tr.train_step(batch.clone())
+    ar_events.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.train_step(batch.clone())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(len(ar_events), 1)
+    if rank == 0:
+        H, R, L, n, E = 512, 128, 6, 200, 10100  # per graph: 200 atoms, ~10.1 k symmetrised edges
+        fwd = L * (30 * H * H * n + 2 * R * 3 * H * E) + 2 * 1.6e9 / 2  # SURVEY 8d: 34.6 GFLOP per graph forward
+        step_flops = 3.0 * fwd * args.systems  # forward + data-gradient + weight-gradient products
+        graphs = args.systems * world * args.steps
+        grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
+        out_line = {
+            "metric": "score-matching training graphs/sec (PaiNN H=512 x 6, ~200-atom OC20-shaped graphs, forward + backward + "
+                      "all-reduce + AdamW + EMA)",
+            "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (forward products f16x3-split MFMA, gradient products exact-f32 MFMA)", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5: PaiNN score-matching step, %d graphs x 200 atoms per GPU and step"
+                                   % args.systems,
+                       "graphs_per_gpu_and_step": args.systems,
+                       "parallelism": "one process per GPU, bucketed gradient all-reduce (%s), %d ranks" % (args.backend, world)},
+            "loss": float(out["loss"].reshape(-1)[0]),
+            "grad_norm": float(out["grad_norm"]) if out.get("grad_norm") is not None else None,
+            "allreduce_ms_per_step": ar_ms if world > 1 else 0.0,
+            "gradient_bytes": grad_bytes,
+            "roofline": {"kernel": "whole step: dense products of forward + backward (weight-gradient and data-gradient "
+                                   "GEMMs in exact-f32 MFMA dominate: profiles/r02_train_step_kernel_stats.csv)",
+                         "bound": "mfma", "achieved": step_flops * world * args.steps / elapsed / 1e12 / world,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": step_flops * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "note": "achieved = 3 x the forward's dense flops (SURVEY 8d: 34.6 GFLOP per graph) per graph and "
+                                 "step / wall time per step, per GPU; priced against the f32 matrix peak because the "
+                                 "gradient products run in exact f32"},
+        }
+        print(json.dumps(out_line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -411,6 +411,14 @@ int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int3
                         const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
                         int32_t early_stop_count, int32_t poll_every, int32_t* state, float* f1, float* f2, void* stream);
 
+/* Stand-alone torch.nn.functional.linear (+ optional SiLU, act = 2) through this path's dense-product kernels (unit tests
+ * and micro-benchmarks of so2_ops.py:12-79,158-238 / so3.py:694-745 shapes).  A [M,K], W [N,K], bias [N] or NULL, C [M,N],
+ * device pointers.  mode 0: exact f32; 1: f16x3 split with per-row power-of-two lifts (fp32 rows split in the kernel;
+ * K % 32 == 0, N % 4 == 0); 2: the same product on rows pre-split into fp16 hi / lo images.  repeat > 1 re-runs the
+ * product kernel alone.  Synchronises. */
+int32_t adf_eqv2_linear_forward(const float* A, const float* W, const float* bias, float* C, int64_t M, int32_t N, int32_t K,
+                                int32_t act, int32_t mode, int32_t repeat, void* stream);
+
 /* Work of the last forward and HIP-event time per kernel group (bench.py roofline).  Categories: 0 graph + Wigner,
  * 1 radial MLPs, 2 rotate in / out, 3 SO(2) convolution products, 4 S2 activation, 5 attention weights, 6 node-side
  * norms / SO(3) linears, 7 feed-forward grid MLP, 8 stepper. */

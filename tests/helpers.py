@@ -42,3 +42,17 @@ def canon_edges(src, dst, dist, vec):
 def rel_err(a, b):
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def row_rel_err(a, b, floor=1e-7):
+    """max over rows of |a_i - b_i| / max(|b_i|, floor): every system / atom bounded against its OWN magnitude (the
+    Frobenius ratio of rel_err lets large rows hide small ones)."""
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    return float(((a - b).norm(dim=1) / b.norm(dim=1).clamp(min=floor)).max())
+
+
+def max_abs_err_rel_to_max(a, b):
+    """max |a - b| / max row norm of b: the per-atom heads bounded element-wise against the largest atom."""
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).abs().max() / b.reshape(b.shape[0], -1).norm(dim=1).max().clamp(min=1e-30))

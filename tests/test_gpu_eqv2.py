@@ -222,3 +222,33 @@ def test_eqv2_distance_basis_path_vs_oracle():
     e1, e2 = rel_err(f1.cpu(), r1), rel_err(f2.cpu(), r2)
     print(f"distance basis: rel err {e1:.2e} {e2:.2e}")
     assert e1 < REL_TOL and e2 < REL_TOL
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("scale", [1e-4, 1e-2, 1.0, 1e3])
+def test_eqv2_linear_f16x3_row_lifts_cover_the_activation_range(mode, scale):
+    """The f16x3 dense products of this path lift every A row by its own power of two before the fp16 hi / lo split, so
+    the result does not depend on the overall magnitude of the activations (the unscaled split of gemm16.hip loses the
+    a_lo term below ~0.1: 4e-4 at 1e-2).  Rows of very different magnitude inside one launch included.  <= 5e-6."""
+    import ctypes as C
+
+    from adsorbdiff_amd import lib as L
+
+    lib = L.load()
+    torch.manual_seed(0)
+    M, N, K = 9000, 640, 448   # spans the 256-row tile kernels (M >= 8192) and a partially filled column tile
+    A = torch.randn(M, K, device=DEV) * scale
+    A[::7] *= 1e-3             # rows far below their neighbours: the lift is per row
+    A[5] = 0.0
+    W = torch.randn(N, K, device=DEV) * 0.05
+    b = torch.randn(N, device=DEV) * scale
+    out = torch.empty(M, N, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.adf_eqv2_linear_forward(A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, 0, mode, 1, st))
+    ref = A.double() @ W.double().T + b.double()
+    err = ((out.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp(min=1e-30))
+    assert float(err.max()) < 5e-6, float(err.max())   # every row against its own norm
+    # SiLU epilogue, small shape (128-row tile kernel)
+    L.check(lib.adf_eqv2_linear_forward(A.data_ptr(), W.data_ptr(), b.data_ptr(), out.data_ptr(), 300, N, K, 2, mode, 1, st))
+    ref2 = torch.nn.functional.silu(ref[:300])
+    assert rel_err(out[:300].cpu(), ref2.cpu()) < 5e-6

@@ -9,7 +9,8 @@ import torch
 from adsorbdiff_amd.painn_denoising import PaiNN
 from adsorbdiff_amd.scaling import PAINN_NB6_SCALE_FACTORS
 from adsorbdiff_amd.synthetic import make_batch
-from tests.helpers import batch_from_fixture, canon_edges, load_npz, rel_err, state_dict_from_fixture
+from tests.helpers import (batch_from_fixture, canon_edges, load_npz, max_abs_err_rel_to_max, rel_err, row_rel_err,
+                           state_dict_from_fixture)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -189,6 +190,7 @@ def test_painn_small_layers_and_output():
     f1, f2 = m(b)
     assert rel_err(f1.cpu(), fx["f1"]) < REL_TOL
     assert rel_err(f2.cpu(), fx["f2"]) < REL_TOL
+    assert max_abs_err_rel_to_max(f1.cpu(), fx["f1"]) < REL_TOL and max_abs_err_rel_to_max(f2.cpu(), fx["f2"]) < REL_TOL
     # per-layer: message block then update block, against the reference's captured activations
     eng = m.engine()
     eng.build_graph(b)
@@ -242,6 +244,7 @@ def test_painn_full_h512_vs_reference_fixture():
     f1, f2 = m(b)
     assert rel_err(f1.cpu(), fx["f1"]) < REL_TOL
     assert rel_err(f2.cpu(), fx["f2"]) < REL_TOL
+    assert max_abs_err_rel_to_max(f1.cpu(), fx["f1"]) < REL_TOL and max_abs_err_rel_to_max(f2.cpu(), fx["f2"]) < REL_TOL
 
 
 def test_painn_vs_oracle_bench_shape():
@@ -264,6 +267,8 @@ def test_painn_vs_oracle_bench_shape():
         s = O.ads_mean(f, b.tags, b.batch, 3)
         so = O.ads_mean(fo, b.tags, b.batch, 3)
         assert rel_err(s, so) < REL_TOL
+        assert row_rel_err(s, so) < REL_TOL, row_rel_err(s, so)  # every system against its own score norm
+        assert max_abs_err_rel_to_max(f, fo) < REL_TOL
 
 
 STEP_HP = dict(hidden_channels=128, num_layers=2, num_rbf=128, cutoff=6.0, max_neighbors=20)
@@ -343,6 +348,9 @@ def test_stepper_each_step_vs_reference_fixture(name):
         s_rot = torch.zeros(B, 3, device=DEV).index_add_(0, b.batch[ads], (f2 * keep)[ads]) / cnt
         assert rel_err(s_tr.cpu(), fx["ref_score_tr"][t]) < REL_TOL, (name, t, rel_err(s_tr.cpu(), fx["ref_score_tr"][t]))
         assert rel_err(s_rot.cpu(), fx["ref_score_rot"][t]) < REL_TOL, (name, t)
+        # each system against its own score norm (floor 1e-7)
+        assert row_rel_err(s_tr.cpu(), fx["ref_score_tr"][t]) < REL_TOL, (name, t, row_rel_err(s_tr.cpu(), fx["ref_score_tr"][t]))
+        assert row_rel_err(s_rot.cpu(), fx["ref_score_rot"][t]) < REL_TOL, (name, t, row_rel_err(s_rot.cpu(), fx["ref_score_rot"][t]))
         eng.sde_step(prep, pos, f1, f2, coefs[t], state, z_tr, z_rot, early_stop_count=0, dcom=dcom, drot=drot)
         # (2) the update the stepper derives from them.  drot is linear in the score: 1e-4 relative.  dcom is the
         # wrapped displacement cell.frac - com: its error is 1e-4 of the unwrapped step (tens of A at sigma = 10)
@@ -392,6 +400,47 @@ def test_sampling_1000_systems_5_steps_spot_check_vs_oracle():
         sl = slice(200 * k, 200 * (k + 1))
         # random-init scores are small (|dcom| << 1 A per step): the 5-step trajectory is well conditioned
         assert float((got[sl] - want).abs().max()) < 1e-4, (k, float((got[sl] - want).abs().max()))
+
+
+def test_sampling_50_steps_teacher_forced_vs_oracle(tmp_path):
+    """The full 50-step schedule of the benchmark (H = 512, 200-atom systems, 10 A, K = 50) on one system of a 4-system
+    batch, step by step: the oracle starts every step from the HIP sampler's own previous frame (teacher forcing, so the
+    chaos of the free-running trajectory does not enter) and must land on the sampler's next frame."""
+    from adsorbdiff_amd.data import Batch
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc, schedule_coefs
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+    from oracle import painn_oracle as O
+
+    torch.manual_seed(0)
+    m = PaiNN(None, 50, 1, cutoff=10.0, max_neighbors=50, scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True).eval()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    B, T, k = 4, 50, 2
+    b = make_batch(B, seed=1000)
+    torch.manual_seed(11)
+    noise = torch.rand(B, 3)
+    params = dict(num_steps=T, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+                  early_stop=False)
+    den = Denoiser(b.clone(), DiffTorchCalc(DenoisingTrainer(m, device=DEV)), dict(params, placement_noise=noise), device=DEV,
+                   save_full_traj=True, traj_dir=tmp_path, traj_names=[str(i) for i in range(B)])
+    den.run()
+    assert den.steps_applied == T
+    frames = torch.from_numpy(np.load(tmp_path / f"{k}.npz")["positions"])  # [T, 200, 3]: after every step
+    assert frames.shape[0] == T
+    one = Batch.from_data_list([b.to_data_list()[k]])
+    start = O.initial_placement(one.pos.clone(), one.cell, one.tags, one.batch, noise[k : k + 1])
+    coefs = schedule_coefs(params)
+    worst = 0.0
+    for t in range(T):
+        p_in = start if t == 0 else frames[t - 1]
+        f1, f2 = O.painn_forward(sd, p_in, one.atomic_numbers, one.cell, one.natoms, cutoff=10.0, max_neighbors=50,
+                                 scale_factors=m.scale_factors())
+        want, dcom, _, _ = O.reverse_step(p_in, one.cell, one.tags, one.batch, f1, f2, one.fixed, t, params)
+        s_tr = O.ads_mean(f1, one.tags, one.batch, 1)
+        tol = 1e-4 * abs(coefs[t].coef_tr) * float(s_tr.abs().max()) + 2e-5  # 1e-4 of the raw step + rounding of O(10 A) sums
+        err = float((frames[t] - want).abs().max())
+        worst = max(worst, err / tol)
+        assert err < tol, (t, err, tol)
+    print(f"50-step teacher-forced check: worst error / tolerance = {worst:.3f}")
 
 
 def test_denoiser_end_to_end_vs_reference_fixture(tmp_path):
