@@ -145,6 +145,8 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         if (st == ADF_OK) st = dev_alloc(&h->w16_scratch, 1);
         const char* e = getenv("ADF_GEMM");
         h->gemm_f32 = e && strcmp(e, "f32") == 0;
+        const char* el = getenv("ADF_LIFT");
+        h->lift_on = !(el && strcmp(el, "0") == 0);
         const char* e2 = getenv("ADF_MSG");
         h->msg_f32 = e2 ? strcmp(e2, "f32") == 0 : h->gemm_f32;
     }
@@ -173,7 +175,7 @@ static void inc_free(adf_painn* h) {
 
 static void free_workspaces(adf_painn* h) {
     void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
-                    h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec,
+                    h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec, h->lift.buf, h->mag_a, h->mag_b, h->mag_v3,
                     h->cache_d2, h->cache_cid, h->cache_cnt, h->prev_nptr, h->prev_src, h->prev_geom};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -182,6 +184,7 @@ static void free_workspaces(adf_painn* h) {
     h->scan_tmp = nullptr; h->scan_tmp_bytes = 0;
     h->e_geom = nullptr;
     h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = h->rec = nullptr;
+    h->lift.buf = h->mag_a = h->mag_b = h->mag_v3 = nullptr; h->lift.cap = 0; h->mag_v3_valid = false;
     h->cache_d2 = nullptr; h->cache_cid = nullptr; h->cache_cnt = nullptr; h->cache_valid = false;
     h->capN = h->capB = h->capE = 0;
 }
@@ -337,7 +340,12 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
     ALLOC(cat, capN * 2 * H);
     ALLOC(dot, capN * H);
     ALLOC(sys, capB * 16);
+    ALLOC(lift.buf, capN * 3);
+    ALLOC(mag_a, capN);
+    ALLOC(mag_b, capN);
+    ALLOC(mag_v3, capN * 3);
 #undef ALLOC
+    h->lift.cap = st == ADF_OK ? capN * 3 : 0;
     if (st != ADF_OK) { free_workspaces(h); return st; }
     h->capN = capN; h->capB = capB; h->capE = capE;
     return ADF_OK;
@@ -462,8 +470,11 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
     const adf_layer_weights& w = h->layer[l];
     if (n <= 0) return ADF_OK;
     adf_prof_begin(h, ADF_PROF_NODE, s);
-    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s));
-    ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, n, H, H, 1, s));
+    const bool lift = h->lift_on && !h->gemm_f32;
+    // row magnitudes travel with the rows: LayerNorm -> x_proj.0 -> (its epilogue) -> x_proj.2
+    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s, lift ? h->mag_a : nullptr));
+    ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, n, H, H, 1, s, lift ? h->mag_a : nullptr,
+                       lift ? h->mag_b : nullptr));
     if (h->gemm_f32) {
         if (row_map) { adf_set_error("internal: mapped records need the f16x3 path"); return ADF_EINVAL; }
         ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, n, 3 * H, H, 0, s));
@@ -472,6 +483,7 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
         adf_epi ep = {};
         ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
         ep.row_map = row_map;
+        ep.rmag = lift ? h->mag_b : nullptr;
         ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, n, H, H, 1, &ep, s));
     }
     adf_prof_end(h, s);
@@ -502,8 +514,11 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
               // xvec_proj.0 then reads its [x | |v2|] input from the two arrays
         adf_epi ep = {};
         ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H;
-        ADF_TRY(adf_launch_gemm16_fused(vec, H, &w.vp_16, N, H, H, 3, &ep, s));
-        ADF_TRY(adf_launch_gemm16(x, H, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H));
+        const adf_lift* lf = h->lift_on ? &h->lift : nullptr;
+        // vec rows and the [x | |v2|] rows are measured by a pass of their own; xvec_proj.0 hands its output rows' on
+        ADF_TRY(adf_launch_gemm16_fused(vec, H, &w.vp_16, N, H, H, 3, &ep, s, lf));
+        ADF_TRY(adf_launch_gemm16(x, H, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H, lf, nullptr,
+                                  h->lift_on ? h->mag_b : nullptr));
     }
     int32_t st;
     if (h->gemm_f32) {
@@ -512,6 +527,7 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
     } else {  // xvec_proj.2 with gating + residuals + ScaleFactor applied on the accumulators
         adf_epi ep = {};
         ep.x = x; ep.vec = vec; ep.dot = h->dot; ep.vv = h->vv; ep.scale = h->scale[l]; ep.H = H;
+        ep.rmag = h->lift_on ? h->mag_b : nullptr;
         st = adf_launch_gemm16_fused(h->y, H, &w.xv2_16, N, H, H, 2, &ep, s);
     }
     adf_prof_end(h, s);
@@ -797,9 +813,15 @@ extern "C" int32_t adf_linear_forward(const float* A, const float* W, const floa
     w16.hi = buf; w16.lo = buf + n * 2; w16.inv_scale = reinterpret_cast<float*>(buf + n * 4);
     unsigned int* scratch = reinterpret_cast<unsigned int*>(buf + n * 4 + 16);
     int32_t st = adf_split_weight(W, (long long)n, &w16, scratch, s);
-    if (st == ADF_OK) st = adf_launch_gemm16(A, K, &w16, bias, C, N, M, N, K, act_ssilu, s);
+    float* mags = nullptr;
+    const char* el = getenv("ADF_LIFT");
+    const bool lift = !(el && strcmp(el, "0") == 0);
+    if (st == ADF_OK && lift) st = dev_alloc(&mags, (size_t)M);
+    adf_lift lf = {mags, M};
+    if (st == ADF_OK) st = adf_launch_gemm16(A, K, &w16, bias, C, N, M, N, K, act_ssilu, s, nullptr, 0, lift ? &lf : nullptr);
     (void)hipStreamSynchronize(s);
     (void)hipFree(buf);
+    if (mags) (void)hipFree(mags);
     return st;
 }
 

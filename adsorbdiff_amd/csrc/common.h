@@ -59,6 +59,16 @@ struct adf_epi {
     const float* A2;      // any EPI: second source of the A operand for columns [K1, K) (same row stride), K1 % 32 == 0
     int K1;               // 0 = single source
     const int32_t* row_map;  // EPI 1: record row of tile row n is row_map[n] (compact rows of an incremental layer); null = n
+    // any EPI: per-row magnitudes max|a| of the A rows (indexed like the rows are loaded: atom*3 + component for EPI 3/4).
+    // Each row is lifted by its own power of two before the fp16 hi/lo split and the lift is divided out in the epilogue
+    // (an unlifted element below ~0.1 loses its a_lo term to the matrix core's subnormal flush).  null = no lift.
+    const float* rmag;
+    unsigned int* out_mag;   // EPI 0: receives max|c| of every output row (atomicMax on float bits; zeroed by the launcher)
+};
+// scratch for the row magnitudes a launcher measures itself (adf_launch_rowmag) when the caller has none to hand over
+struct adf_lift {
+    float* buf;
+    long long cap;   // rows
 };
 struct adf_layer_weights {
     const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
@@ -94,6 +104,12 @@ struct adf_painn {
     unsigned int* w16_scratch;
     bool gemm_f32;
     bool msg_f32;
+    // per-row power-of-two lifts of the f16x3 products' A operands (default on; ADF_LIFT=0 = the unlifted split of rounds 1-2)
+    bool lift_on;
+    adf_lift lift;       // [3 capN] magnitudes a launcher measures itself
+    float *mag_a, *mag_b;  // [capN] magnitudes handed from a producer (LayerNorm, a product's epilogue) to the next product
+    float* mag_v3;         // [3 capN] magnitudes of the vec rows entering the heads (measured once, used by both heads)
+    bool mag_v3_valid;
 
     // ---- grow-only workspaces
     int64_t capN, capB, capE;
@@ -169,19 +185,25 @@ void adf_prof_end(adf_painn* h, hipStream_t s);
 // ---- kernels' host launchers (each enqueues on `s`, returns ADF_*)
 int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc,
                         int M, int N, int K, int act_ssilu, hipStream_t s);
+// lf: measure the A rows' magnitudes into lf->buf first (row lifts, see adf_epi::rmag); premag: they are already known
+// (written by the producer of A: LayerNorm, a previous product's out_mag); out_mag: emit the output rows' magnitudes
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
-                          int N, int K, int act_ssilu, hipStream_t s, const float* A2 = nullptr, int K1 = 0);
+                          int N, int K, int act_ssilu, hipStream_t s, const float* A2 = nullptr, int K1 = 0,
+                          const adf_lift* lf = nullptr, const float* premag = nullptr, float* out_mag = nullptr);
+int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s);
 int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
                          int perm_H = 0, int K = 0, const float* bias = nullptr, int parts = 3);
 int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, float* nrm, int M, int N, int K,
-                                  hipStream_t s);
+                                  hipStream_t s, const adf_lift* lf = nullptr, const float* premag = nullptr);
 int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
-                                const adf_epi* ep, hipStream_t s);
+                                const adf_epi* ep, hipStream_t s, const adf_lift* lf = nullptr);
 // C = act(A . W^T + b): f16x3 split MFMA by default, exact-f32 MFMA when h->gemm_f32 (ADF_GEMM=f32)
 static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, const float* W, const adf_w16* W16,
-                                 const float* bias, float* C, int ldc, int M, int N, int K, int act, hipStream_t s) {
+                                 const float* bias, float* C, int ldc, int M, int N, int K, int act, hipStream_t s,
+                                 const float* premag = nullptr, float* out_mag = nullptr) {
     if (h->gemm_f32) return adf_launch_gemm(A, lda, W, K, bias, C, ldc, M, N, K, act, s);
-    return adf_launch_gemm16(A, lda, W16, bias, C, ldc, M, N, K, act, s);
+    return adf_launch_gemm16(A, lda, W16, bias, C, ldc, M, N, K, act, s, nullptr, 0, h->lift_on ? &h->lift : nullptr,
+                             h->lift_on ? premag : nullptr, h->lift_on ? out_mag : nullptr);
 }
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
 // incremental.hip
@@ -199,7 +221,8 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
 int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s,
                          float* rec = nullptr);
 int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s);
-int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s);
+int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s,
+                               float* out_mag = nullptr);  // out_mag: max|y| per row
 int32_t adf_nodewise_update_prep(const float* vv, const float* x, float* cat, float* dot, int N, int H, hipStream_t s);
 int32_t adf_nodewise_update_apply(const float* h3, const float* dot, const float* vv, float* x, float* vec,
                                   float scale, int N, int H, hipStream_t s);

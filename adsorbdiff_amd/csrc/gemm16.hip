@@ -35,6 +35,16 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define TLD2 64
 #define HLD 40  // halves per LDS row (32 + 8 pad)
 
+// 2^e with mx 2^e in [2^14, 2^15); 1 for mx == 0 or non-finite
+__device__ __forceinline__ float adf_pow2_lift(float mx) {
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(mx, &e);
+    e = 15 - e;
+    e = e > 120 ? 120 : (e < -120 ? -120 : e);
+    return ldexpf(1.0f, e);
+}
+
 __device__ __forceinline__ float ssilu16(float x) {
     float s = x / (1.0f + expf(-x));
     return s * 1.6666666666666667f;
@@ -62,6 +72,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     constexpr int TN = 64 * NJ;   // columns per workgroup
     constexpr int NA = TM / 32;   // float4 A loads per thread
     __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * HLD];
+    __shared__ float rinv[TM];  // 1 / lift of every staged A row
     _Float16* Ahi = lds;
     _Float16* Alo = Ahi + TM * HLD;
     _Float16* Bhi = Alo + TM * HLD;
@@ -87,20 +98,25 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     // (the [x | norm] inputs of the update / head MLPs are never concatenated in memory).
     unsigned int a_goff[NA];
     int a_off[NA];
+    float a_rs[NA];
+    auto global_row = [&](int row) -> unsigned int {
+        if constexpr (EPI >= 3) {  // LDS row = (wave row)*96 + component*32 + atom
+            const int atom = m0 + (row / 96) * 32 + (row & 31), ax = (row % 96) >> 5;
+            return (unsigned int)min(atom, M - 1) * 3u + ax;
+        } else {
+            return (unsigned int)min(m0 + row, M - 1);
+        }
+    };
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int f = tid + 256 * i;
         const int row = f >> 3, kq = f & 7;
-        unsigned int grow;
-        if constexpr (EPI >= 3) {  // LDS row = (wave row)*96 + component*32 + atom
-            const int atom = m0 + (row / 96) * 32 + (row & 31), ax = (row % 96) >> 5;
-            grow = (unsigned int)min(atom, M - 1) * 3u + ax;
-        } else {
-            grow = (unsigned int)min(m0 + row, M - 1);
-        }
+        const unsigned int grow = global_row(row);
         a_goff[i] = (grow * (unsigned int)lda + kq * 4) * 4u;
         a_off[i] = row * HLD + kq * 4;
+        a_rs[i] = ep.rmag ? adf_pow2_lift(ep.rmag[grow]) : 1.0f;
     }
+    if (tid < TM) rinv[tid] = ep.rmag ? 1.0f / adf_pow2_lift(ep.rmag[global_row(tid)]) : 1.0f;
     const char* const A1b = reinterpret_cast<const char*>(A);
     const char* const A2b = reinterpret_cast<const char*>(ep.A2) - (size_t)ep.K1 * 4;
     // W staging: NJ pieces of 16 B (8 halves) of hi and of lo per thread (4 lanes per 64-B row)
@@ -139,10 +155,11 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
+            const float sx = ra[i].x * a_rs[i], sy = ra[i].y * a_rs[i], sz = ra[i].z * a_rs[i], sw = ra[i].w * a_rs[i];
             half4 h, l;
-            h[0] = (_Float16)ra[i].x; h[1] = (_Float16)ra[i].y; h[2] = (_Float16)ra[i].z; h[3] = (_Float16)ra[i].w;
-            l[0] = (_Float16)(ra[i].x - (float)h[0]); l[1] = (_Float16)(ra[i].y - (float)h[1]);
-            l[2] = (_Float16)(ra[i].z - (float)h[2]); l[3] = (_Float16)(ra[i].w - (float)h[3]);
+            h[0] = (_Float16)sx; h[1] = (_Float16)sy; h[2] = (_Float16)sz; h[3] = (_Float16)sw;
+            l[0] = (_Float16)(sx - (float)h[0]); l[1] = (_Float16)(sy - (float)h[1]);
+            l[2] = (_Float16)(sz - (float)h[2]); l[3] = (_Float16)(sw - (float)h[3]);
             *reinterpret_cast<half4*>(Ahi + a_off[i]) = h;
             *reinterpret_cast<half4*>(Alo + a_off[i]) = l;
         }
@@ -204,10 +221,18 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        float v0 = acc[i][2 * jj][r] * isc + bv0, v1 = acc[i][2 * jj + 1][r] * isc + bv1;
+                        const float sc = isc * rinv[wm + 32 * i + lr];
+                        float v0 = acc[i][2 * jj][r] * sc + bv0, v1 = acc[i][2 * jj + 1][r] * sc + bv1;
                         if (ACT) { v0 = ssilu16(v0); v1 = ssilu16(v1); }
                         T[lr * TLD2 + q] = v0;
                         T[lr * TLD2 + 32 + q] = v1;
+                        if (ep.out_mag) {  // all 32 lanes of a half-wave hold the same output row
+                            float mg = fmaxf(cb + q < N ? fabsf(v0) : 0.f, cb + 32 + q < N ? fabsf(v1) : 0.f);
+#pragma unroll
+                            for (int o = 16; o > 0; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
+                            const int orow = m0 + wm + 32 * i + lr;
+                            if (q == 0 && orow < M) atomicMax(ep.out_mag + orow, __float_as_uint(mg));
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -236,9 +261,10 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < M) {
-                        float v = acc[i][j][r] * isc + bv;
+                        float v = acc[i][j][r] * (isc * rinv[row - m0]) + bv;
                         if (ACT) v = ssilu16(v);
                         C[(size_t)row * ldc + col] = v;
+                        if (ep.out_mag) atomicMax(ep.out_mag + row, __float_as_uint(fabsf(v)));
                     }
                 }
             }
@@ -259,7 +285,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             float d = 0.f, qq = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float v1 = acc[i][0][r] * isc, v2 = acc[i][1][r] * isc;
+                const float sc = isc * rinv[wm + 32 * i + lr];
+                const float v1 = acc[i][0][r] * sc, v2 = acc[i][1][r] * sc;
                 d += v1 * v2;
                 qq += v2 * v2;
                 T[lr * TLD3 + i * 32 + q] = v1;
@@ -314,7 +341,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float a = acc[0][j][r] * isc, b = acc[1][j][r] * isc, d = acc[2][j][r] * isc;
+                const float a = acc[0][j][r] * (isc * rinv[wm + lr]), b = acc[1][j][r] * (isc * rinv[wm + 32 + lr]),
+                            d = acc[2][j][r] * (isc * rinv[wm + 64 + lr]);
                 T[lr * TLD2 + j * 32 + q] = sqrtf(a * a + b * b + d * d);
             }
         }
@@ -344,9 +372,10 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                T[lr * TLD3 + q] = acc[i][0][r] * isc + b0;
-                T[lr * TLD3 + 32 + q] = acc[i][1][r] * isc + b1;
-                T[lr * TLD3 + 64 + q] = acc[i][2][r] * isc + b2;
+                const float sc = isc * rinv[wm + 32 * i + lr];
+                T[lr * TLD3 + q] = acc[i][0][r] * sc + b0;
+                T[lr * TLD3 + 32 + q] = acc[i][1][r] * sc + b1;
+                T[lr * TLD3 + 64 + q] = acc[i][2][r] * sc + b2;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -439,6 +468,50 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     }
 }
 
+// mag[r] = max over the K1 leading elements of A row r (and the K2 of A2 row r, same row stride): one wave per row
+__global__ __launch_bounds__(256) void adf_rowmag_kernel(const float* __restrict__ A, int lda, int K1,
+                                                         const float* __restrict__ A2, int K2, long long M,
+                                                         float* __restrict__ mag) {
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= M) return;
+    float mx = 0.f;
+    const float* a = A + (size_t)r * lda;
+    for (int k = lane * 4; k < K1; k += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(a + k);
+        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (A2) {
+        const float* b = A2 + (size_t)r * lda;
+        for (int k = lane * 4; k < K2; k += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(b + k);
+            mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) mag[r] = mx;
+}
+
+int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s) {
+    if (M <= 0) return ADF_OK;
+    hipLaunchKernelGGL(adf_rowmag_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, A, lda, K1, A2, K2, M, mag);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// row magnitudes for a launcher: the caller's (premag), or measured into lf->buf, or none
+static int32_t lift_mags(const float* A, int lda, int K1, const float* A2, int K2, long long rows, const adf_lift* lf,
+                         const float* premag, const float** out, hipStream_t s) {
+    *out = premag;
+    if (!premag && lf && lf->buf) {
+        if (rows > lf->cap) { adf_set_error("gemm16: lift scratch holds %lld rows, need %lld", lf->cap, rows); return ADF_EINVAL; }
+        ADF_TRY(adf_launch_rowmag(A, lda, K1, A2, K2, rows, lf->buf, s));
+        *out = lf->buf;
+    }
+    return ADF_OK;
+}
+
 // ---- weight preparation: per-matrix power-of-two scale, then hi/lo split
 __global__ void adf_absmax_kernel(const float* __restrict__ w, long long n, unsigned int* out_bits) {
     float m = 0.f;
@@ -497,7 +570,8 @@ static int32_t check_a_span(long long rows, int lda) {
 }
 
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
-                          int N, int K, int act_ssilu, hipStream_t s, const float* A2, int K1) {
+                          int N, int K, int act_ssilu, hipStream_t s, const float* A2, int K1, const adf_lift* lf,
+                          const float* premag, float* out_mag) {
     if (M <= 0) return ADF_OK;
     if (K % HK != 0 || (lda & 3) || (A2 && (K1 <= 0 || K1 % HK != 0 || K1 >= K))) {
         adf_set_error("gemm16: K=%d (K1=%d) must be multiples of %d and lda a multiple of 4", K, K1, HK);
@@ -513,6 +587,11 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
     adf_epi ep = {};
     ep.A2 = A2; ep.K1 = A2 ? K1 : 0;
+    ADF_TRY(lift_mags(A, lda, A2 ? K1 : K, A2, A2 ? K - K1 : 0, M, lf, premag, &ep.rmag, s));
+    if (out_mag) {
+        ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));
+        ep.out_mag = reinterpret_cast<unsigned int*>(out_mag);
+    }
 #define LAUNCH16(ACT_, MI_)                                                                                  \
     hipLaunchKernelGGL((adf_gemm_f16x3_kernel<ACT_, MI_, 4, 0>), grid, dim3(256), 0, s, A, lda,              \
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, \
@@ -526,12 +605,13 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
 
 // ||W v||_xyz of a [M,3,K] vector field -> nrm [M, N]  (EPI 4; N % 4 == 0)
 int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, float* nrm, int M, int N, int K,
-                                  hipStream_t s) {
+                                  hipStream_t s, const adf_lift* lf, const float* premag) {
     if (M <= 0) return ADF_OK;
     if (K % HK != 0 || (lda & 3) || (N & 3)) { adf_set_error("gemm16_vecnorm: bad shape"); return ADF_EINVAL; }
     ADF_TRY(check_a_span(3ll * M, lda));
     adf_epi ep = {};
     ep.cat = nrm;
+    ADF_TRY(lift_mags(A, lda, K, nullptr, 0, 3ll * M, lf, premag, &ep.rmag, s));
     const int tn = (N + 127) / 128, tm8 = ((M + 63) / 64 + 7) / 8 * 8;
     hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 4>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, (const float*)nullptr,
@@ -542,13 +622,16 @@ int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, flo
 
 // 3H-wide layer with row-permuted weights and a fused consumer epilogue (EPI 1 or 2, see kernel comment)
 int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M, int H, int K, int epi,
-                                const adf_epi* ep, hipStream_t s) {
+                                const adf_epi* ep_in, hipStream_t s, const adf_lift* lf) {
+    adf_epi epv = *ep_in;
+    const adf_epi* ep = &epv;
     if (M <= 0) return ADF_OK;
     if (K % HK != 0 || (lda & 3) || H % 64 != 0 || (epi != 3 && !W->bias_perm)) {
         adf_set_error("gemm16_fused: bad shape");
         return ADF_EINVAL;
     }
     ADF_TRY(check_a_span(epi == 3 ? 3ll * M : (long long)M, lda));
+    ADF_TRY(lift_mags(A, lda, K, nullptr, 0, epi == 3 ? 3ll * M : (long long)M, lf, ep_in->rmag, &epv.rmag, s));
     const int N = 3 * H, TM = 128, TN = 192;
     const int tiles_n = N / TN;  // H % 64 == 0
     const int tiles_m = (M + TM - 1) / TM;

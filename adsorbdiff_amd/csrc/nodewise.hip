@@ -32,7 +32,7 @@ __global__ void adf_embed_kernel(const float* __restrict__ emb, const int32_t* _
 // torch.nn.LayerNorm(H), eps = 1e-5, biased variance.  One wave per row, 16 B per lane and access.
 __global__ __launch_bounds__(256) void adf_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ y,
-                                                             int N, int H) {
+                                                             int N, int H, float* __restrict__ out_mag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
@@ -62,14 +62,22 @@ __global__ __launch_bounds__(256) void adf_layernorm_kernel(const float* __restr
     float4* yr = reinterpret_cast<float4*>(y + (size_t)row * H);
     const float4* w4 = reinterpret_cast<const float4*>(w);
     const float4* b4 = reinterpret_cast<const float4*>(b);
+    float mg = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = lane + 64 * i;
         if (c < h4) {
             const float4 ww = w4[c], bb = b4[c];
-            yr[c] = make_float4((vals[i].x - mean) * rstd * ww.x + bb.x, (vals[i].y - mean) * rstd * ww.y + bb.y,
-                                (vals[i].z - mean) * rstd * ww.z + bb.z, (vals[i].w - mean) * rstd * ww.w + bb.w);
+            const float4 o = make_float4((vals[i].x - mean) * rstd * ww.x + bb.x, (vals[i].y - mean) * rstd * ww.y + bb.y,
+                                         (vals[i].z - mean) * rstd * ww.z + bb.z, (vals[i].w - mean) * rstd * ww.w + bb.w);
+            yr[c] = o;
+            mg = fmaxf(fmaxf(fmaxf(mg, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
+    }
+    if (out_mag) {  // the row's magnitude for the f16x3 product that reads it (gemm16.hip row lifts)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
+        if (lane == 0) out_mag[row] = mg;
     }
 }
 
@@ -222,8 +230,9 @@ int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipS
     return ADF_OK;
 }
 
-int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s) {
-    hipLaunchKernelGGL(adf_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, w, b, y, N, H);
+int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s,
+                               float* out_mag) {
+    hipLaunchKernelGGL(adf_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, w, b, y, N, H, out_mag);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
@@ -256,17 +265,27 @@ int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const fl
     float* x1 = h->xh + (size_t)N * H;
     float* t1b = x1 + (size_t)N * H2;
     float* cat1 = h->dot;
+    // row lifts (gemm16.hip): the vec rows feed vec1_proj and vec2_proj of BOTH heads: measured once, by head 0
+    const bool lift = h->lift_on && !h->gemm_f32;
+    const adf_lift* lf = lift ? &h->lift : nullptr;
+    const float* vmag = nullptr;
+    if (lift) {
+        if (head == 0 || !h->mag_v3_valid) ADF_TRY(adf_launch_rowmag(vec, H, H, nullptr, 0, 3ll * N, h->mag_v3, s));
+        h->mag_v3_valid = head == 0;
+        vmag = h->mag_v3;
+    }
     // block 0: H -> H/2
     if (h->gemm_f32) {
         ADF_TRY(adf_linear(h, vec, H, b0.vec1_w, &b0.vec1_16, nullptr, t1, H, 3 * N, H, H, 0, s));
         hipLaunchKernelGGL(adf_head_norm_cat_kernel, dim3(ew_grid((long long)N * H / 4)), dim3(256), 0, s, x, t1, h->cat, N, H);
     } else {  // ||vec1_proj(vec)|| straight from the accumulators into cat [N,H]
-        ADF_TRY(adf_launch_gemm16_vecnorm(vec, H, &b0.vec1_16, h->cat, N, H, H, s));
+        ADF_TRY(adf_launch_gemm16_vecnorm(vec, H, &b0.vec1_16, h->cat, N, H, H, s, lf, vmag));
     }
-    ADF_TRY(adf_linear(h, vec, H, b0.vec2_w, &b0.vec2_16, nullptr, t2, H2, 3 * N, H2, H, 0, s));
+    ADF_TRY(adf_linear(h, vec, H, b0.vec2_w, &b0.vec2_16, nullptr, t2, H2, 3 * N, H2, H, 0, s, vmag));
     if (h->gemm_f32) ADF_TRY(adf_linear(h, h->cat, 2 * H, b0.un0_w, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s));
-    else ADF_TRY(adf_launch_gemm16(x, H, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H));  // [x | norm]
-    ADF_TRY(adf_linear(h, h->y, H, b0.un2_w, &b0.un2_16, b0.un2_b, o, H, N, H, H, 0, s));
+    else ADF_TRY(adf_launch_gemm16(x, H, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H,  // [x | norm]
+                                   h->lift_on ? &h->lift : nullptr, nullptr, h->lift_on ? h->mag_b : nullptr));
+    ADF_TRY(adf_linear(h, h->y, H, b0.un2_w, &b0.un2_16, b0.un2_b, o, H, N, H, H, 0, s, (h->lift_on && !h->gemm_f32) ? h->mag_b : nullptr));
     hipLaunchKernelGGL(adf_head_gate_kernel, dim3(ew_grid((long long)N * H2 / 4)), dim3(256), 0, s, o, t2, x1, v1, N, H2);
     // block 1: H/2 -> 1
     if (h->gemm_f32) {
@@ -274,8 +293,8 @@ int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const fl
         hipLaunchKernelGGL(adf_head_norm_cat_kernel, dim3(ew_grid((long long)N * H2 / 4)), dim3(256), 0, s, x1, t1b, cat1, N, H2);
         ADF_TRY(adf_linear(h, cat1, H, b1.un0_w, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s));
     } else {
-        ADF_TRY(adf_launch_gemm16_vecnorm(v1, H2, &b1.vec1_16, cat1, N, H2, H2, s));
-        ADF_TRY(adf_launch_gemm16(x1, H2, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s, cat1, H2));
+        ADF_TRY(adf_launch_gemm16_vecnorm(v1, H2, &b1.vec1_16, cat1, N, H2, H2, s, h->lift_on ? &h->lift : nullptr));
+        ADF_TRY(adf_launch_gemm16(x1, H2, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s, cat1, H2, h->lift_on ? &h->lift : nullptr));
     }
     hipLaunchKernelGGL(adf_head_final_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->y, v1, b1.vec2_w, b1.un2_w,
                        b1.un2_b, out, N, H2, h->flags);

@@ -117,12 +117,13 @@ def test_linear_kernels_vs_fp64(mode, shape):
     assert rel_err(out, ref) < (1e-6 if mode == 0 else 3e-6)
 
 
-@pytest.mark.parametrize("scale,tol", [(1.0e3, 2e-6), (1.0, 2e-6), (1.0e-2, 4e-4), (1.0e-4, 4e-4)])
+@pytest.mark.parametrize("scale,tol", [(1.0e6, 5e-6), (1.0e3, 5e-6), (1.0, 5e-6), (1.0e-2, 5e-6), (1.0e-4, 5e-6), (1.0e-8, 5e-6)])
 def test_linear_f16x3_activation_range(scale, tol):
-    """Documented range of the f16x3 split (gemm16.hip): activations are split into fp16 hi/lo unscaled, so a product
-    keeps ~2^-22 relative precision for 0.125 <= |a| <= 65504; below 0.125 a_lo is an fp16 subnormal that the matrix
-    core flushes and that element carries 2^-11 (random signs: a K = 512 dot product then sits at ~1e-4 relative, the
-    bound asserted here); above 65504 a_hi overflows and the forward reports ADF_ENUMERIC (next test)."""
+    """Row lifts of the f16x3 split (gemm16.hip, round 3): every A row is multiplied by its own power of two before the
+    fp16 hi/lo split (its largest element lands in [2^14, 2^15)) and the lift is divided out in the epilogue, so a
+    product keeps ~2^-22 relative precision whatever the magnitude of the activations — rounds 1-2 split them unscaled:
+    an element below 0.125 lost its a_lo term to the matrix core's subnormal flush (4e-4 at scales 1e-2 and 1e-4) and
+    one above 65504 overflowed.  The lift depends on the row alone (batch-independent bits)."""
     import ctypes as C
 
     from adsorbdiff_amd import lib as L
@@ -139,13 +140,21 @@ def test_linear_f16x3_activation_range(scale, tol):
     ref = A.double() @ W.double().T
     err = float((Cm.double() - ref).norm() / ref.norm())
     assert err < tol, (scale, err)
+    # rows of very different magnitude in one launch: each against its own norm
+    A[::5] *= 1e-4
+    L.check(lib.adf_linear_forward(A.data_ptr(), W.data_ptr(), None, Cm.data_ptr(), M, N, K, 0, 1,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().T
+    assert float(((Cm.double() - ref).norm(dim=1) / ref.norm(dim=1)).max()) < tol
 
 
-def test_out_of_range_activations_fall_back_to_exact_f32():
+def test_out_of_range_activations_are_lifted_or_fall_back(monkeypatch):
     """LayerNorm gain x 1e5 with x_proj.0 weights x 1e-5: the same function in exact arithmetic, but the GEMM input
-    exceeds the fp16 range (|a| > 65504), so the f16x3 forward produces a non-finite output; adf_check_flags reports
-    ADF_ENUMERIC and the engine re-runs in exact f32 - the caller sees the oracle's answer.  The sampler does the
-    same for a whole run."""
+    exceeds the fp16 range (|a| > 65504).  With the row lifts the f16x3 forward handles it directly (no fallback, the
+    oracle's answer at 1e-4).  Without them (ADF_LIFT=0, the arithmetic of rounds 1-2) the forward produces a non-finite
+    output, adf_check_flags reports ADF_ENUMERIC and the engine re-runs in exact f32 - the caller still sees the oracle's
+    answer; the sampler does the same for a whole run."""
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.trainer import DenoisingTrainer
     from oracle import painn_oracle as O
@@ -159,8 +168,12 @@ def test_out_of_range_activations_fall_back_to_exact_f32():
             mm.message_layers[1].x_proj[0].weight.mul_(1.0e-5)
         return mm
 
-    m = rescaled()
+    ml = rescaled()
     b = batch_from_fixture(fx, device=DEV)
+    l1, l2 = ml(b)
+    assert not ml.engine().exact_f32 and bool(torch.isfinite(l1).all()) and bool(torch.isfinite(l2).all())
+    monkeypatch.setenv("ADF_LIFT", "0")
+    m = rescaled()
     f1, f2 = m(b)
     assert m.engine().exact_f32 and bool(torch.isfinite(f1).all()) and bool(torch.isfinite(f2).all())
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
@@ -169,6 +182,7 @@ def test_out_of_range_activations_fall_back_to_exact_f32():
                              num_layers=int(fx["hp_num_layers"]), cutoff=float(fx["hp_cutoff"]),
                              max_neighbors=int(fx["hp_max_neighbors"]), scale_factors=m.scale_factors())
     assert rel_err(f1.cpu(), o1) < REL_TOL and rel_err(f2.cpu(), o2) < REL_TOL
+    assert rel_err(l1.cpu(), o1) < REL_TOL and rel_err(l2.cpu(), o2) < REL_TOL
     # a fresh engine (f16x3 again) inside the sampler: the run is repeated in exact f32 from the initial placement
     m2 = rescaled()
     params = dict(num_steps=2, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
@@ -233,6 +247,35 @@ def test_exact_f32_mode_matches_default(monkeypatch):
     e1, e2 = small_model(fx)(b)
     assert rel_err(f1, e1) < 2e-5 and rel_err(f2, e2) < 2e-5
     assert rel_err(e1.cpu(), fx["f1"]) < 1e-5 and rel_err(e2.cpu(), fx["f2"]) < 1e-5
+
+
+def test_painn_trained_like_magnitudes_vs_reference_fixture(monkeypatch):
+    """Reference outputs for weights rescaled to trained-like magnitudes (LayerNorm gain x 0.05, vec stream x 1e-2:
+    oracle/make_golden.py section 9): |vec| ~ 1e-3, i.e. every operand row of vec_proj sits below the unlifted fp16
+    split's 0.1 threshold.  With the row lifts: 1e-4 on the outputs and on every layer's activations."""
+    fx = load_npz("painn_small_scaled.npz")
+    b = batch_from_fixture(fx, device=DEV)
+
+    def run():
+        m = small_model(fx)
+        f1, f2 = m(b)
+        eng = m.engine()
+        eng.build_graph(b)
+        H = m.hidden_channels
+        x = m.atom_emb.embeddings.weight.detach()[b.atomic_numbers.long() - 1].contiguous()
+        vec = torch.zeros(x.shape[0], 3, H, device=DEV)
+        worst = max(rel_err(f1.cpu(), fx["f1"]), rel_err(f2.cpu(), fx["f2"]))
+        for li in range(m.num_layers):
+            x, vec = eng.message_layer(li, x.contiguous(), vec.contiguous())
+            x, vec = eng.update_layer(li, x.contiguous(), vec.contiguous())
+            worst = max(worst, rel_err(x.cpu(), fx[f"layer{li}_x"]), rel_err(vec.cpu(), fx[f"layer{li}_vec"]))
+        return worst
+
+    lifted = run()
+    monkeypatch.setenv("ADF_LIFT", "0")
+    unlifted = run()
+    print(f"trained-like magnitudes: worst rel err with row lifts {lifted:.2e}, without {unlifted:.2e}")
+    assert lifted < REL_TOL
 
 
 def test_painn_full_h512_vs_reference_fixture():
