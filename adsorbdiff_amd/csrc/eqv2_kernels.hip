@@ -15,6 +15,8 @@
 // indexed by e - eptr[n0].
 #include <hipcub/hipcub.hpp>
 
+#include <stdlib.h>
+
 #include "eqv2.h"
 #include "graph.h"
 
@@ -638,7 +640,7 @@ typedef _Float16 eqhalf8 __attribute__((ext_vector_type(8)));
 struct eq_rdesc { int m, o1, o2; float sg; };
 
 template <int NBK>
-__global__ __launch_bounds__(512, 2) void eq_s2act_mfma_kernel(const float* __restrict__ y0, int ld0, int off0, int gate_off,
+__global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __restrict__ y0, int ld0, int off0, int gate_off,
                                                                eq_ptrs ym, const int32_t* __restrict__ eptr, int n0, int n1,
                                                                const eq_dims* __restrict__ dg, int Sr, int L, int M, int Hd,
                                                                const eqhalf8* __restrict__ tabs, int npb, float inv_sT,
@@ -649,9 +651,9 @@ __global__ __launch_bounds__(512, 2) void eq_s2act_mfma_kernel(const float* __re
     __shared__ const float* in_ptr[EQ_MAX_M + 1];
     __shared__ float* out_ptr[EQ_MAX_M + 1];
     __shared__ unsigned int* mag_ptr[EQ_MAX_M + 1];
-    __shared__ unsigned int wmag[8][2 * EQ_MAX_M + 2];  // per wave: magnitudes of the item's destination rows
+    __shared__ unsigned int wmag[16][2 * EQ_MAX_M + 2];  // per wave: magnitudes of the item's destination rows
     const int ntab = npb * 2 * 2 * 64;
-    for (int t = threadIdx.x; t < 2 * ntab; t += 512) tab[t] = tabs[t];
+    for (int t = threadIdx.x; t < 2 * ntab; t += 1024) tab[t] = tabs[t];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + EQ_MAX_M + 1) {
         const int m = threadIdx.x - 64;
         in_ptr[m] = m == 0 ? y0 : ym.p[m <= M ? m : 0];
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void eq_s2act_mfma_kernel(const float* __re
     const long long Ec = eptr[n1] - ebase;
     // one wave per (edge, block of 32 hidden channels)
     const int nblk = Hd >> 5;
-    for (long long item = (long long)blockIdx.x * 8 + wave; item < Ec * nblk; item += (long long)gridDim.x * 8) {
+    for (long long item = (long long)blockIdx.x * 16 + wave; item < Ec * nblk; item += (long long)gridDim.x * 16) {
         const long long el = item / nblk;
         const int cb = (int)(item - el * nblk) * 32;
         const float* base0 = y0 + (size_t)el * ld0;
@@ -826,7 +828,7 @@ int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, in
         const size_t dyn = (size_t)h->s2_npb * 2 * 2 * 64 * 16 * 2;
         ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_s2act_mfma_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(eq_s2act_mfma_kernel<1>, dim3(h->num_cus), dim3(512), dyn, s, y0, ld0, extra, gate_off, a, h->eptr,
+        hipLaunchKernelGGL(eq_s2act_mfma_kernel<1>, dim3(h->num_cus), dim3(1024), dyn, s, y0, ld0, extra, gate_off, a, h->eptr,
                            n0, n1, h->d_dev, d.Sr, d.L, d.M, d.Hd, (const eqhalf8*)h->s2tab, h->s2_npb, h->s2_inv_sT,
                            h->s2_inv_sF, h->s2_gain_shift, b, r);
         ADF_HIP_CHECK(hipGetLastError());
@@ -925,6 +927,8 @@ int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, i
 // (D_l^T on the kept rows, with the m-truncation rescale) and summed over the edges of its target — one workgroup per
 // target, thread = value channel, the target's S coefficients in registers, edges in CSR order (run-to-run identical).
 // ONLY1: only the l = 1 coefficients (all a force block's projection reads), written as [N, 3, HV].
+// (Measured alternative: several thread groups per target, each taking every k-th edge, partial sums added through LDS —
+// slower, 61 -> 80 ms per forward at 256 k edges: the edge's Wigner rows stop being wave-uniform scalar loads.)
 template <int LT, bool ONLY1>
 __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, const float* __restrict__ alpha,
                                      const float* __restrict__ wig, const int32_t* __restrict__ eptr, int n0, int n1,
