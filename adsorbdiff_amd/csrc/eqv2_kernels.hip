@@ -447,6 +447,8 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
                                     const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src,
                                     const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb, eq_ptrs rs,
                                     const int32_t* __restrict__ Z, int pair_ne) {
+    // (Measured alternative: one workgroup per TARGET looping over its edges with the target's own features loaded once —
+    // slower, 63 -> 82 ms per forward at 256 k edges: fewer, longer workgroups with two barriers per edge.)
     // PRESPLIT: the operand rows are written as fp16 hi / lo images lifted by the row's own power of two (what
     // eq_gemm16p_kernel stages by plain copies): mb.p[m] holds [rows][nm 2C] halves of hi followed by the same of lo
     __shared__ unsigned int smax[2 * EQ_MAX_M + 1];  // |.| maxima of the edge's operand rows (bit patterns order like floats)
