@@ -471,10 +471,13 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
     if (n <= 0) return ADF_OK;
     adf_prof_begin(h, ADF_PROF_NODE, s);
     const bool lift = h->lift_on && !h->gemm_f32;
+    static int emit = -1;
+    if (emit < 0) { const char* e = getenv("ADF_LIFT_EMIT"); emit = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool em = lift && emit;
     // row magnitudes travel with the rows: LayerNorm -> x_proj.0 -> (its epilogue) -> x_proj.2
-    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s, lift ? h->mag_a : nullptr));
-    ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, n, H, H, 1, s, lift ? h->mag_a : nullptr,
-                       lift ? h->mag_b : nullptr));
+    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s, em ? h->mag_a : nullptr));
+    ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, n, H, H, 1, s, em ? h->mag_a : nullptr,
+                       em ? h->mag_b : nullptr));
     if (h->gemm_f32) {
         if (row_map) { adf_set_error("internal: mapped records need the f16x3 path"); return ADF_EINVAL; }
         ADF_TRY(adf_launch_gemm(h->cat, H, w.xp2_w, H, w.xp2_b, h->xh, 3 * H, n, 3 * H, H, 0, s));
@@ -483,8 +486,8 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
         adf_epi ep = {};
         ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
         ep.row_map = row_map;
-        ep.rmag = lift ? h->mag_b : nullptr;
-        ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, n, H, H, 1, &ep, s));
+        ep.rmag = em ? h->mag_b : nullptr;
+        ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, n, H, H, 1, &ep, s, lift ? &h->lift : nullptr));
     }
     adf_prof_end(h, s);
     return ADF_OK;

@@ -257,13 +257,13 @@ def main():
         # recompute nothing for those systems, which a trained model would not allow.  Same workload with the last linear
         # map of both heads scaled by 100 so that every system keeps moving through step 49 (checked: the per-step
         # fraction of recomputed rows is printed).
-        import copy
-
-        model_mv = copy.deepcopy(model).to(dev).eval()
+        torch.manual_seed(0)
+        model_mv = PaiNN(None, 50, 1, hidden_channels=512, num_layers=6, num_rbf=128, cutoff=10.0, max_neighbors=50,
+                         scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True).eval()
+        model_mv.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
         with torch.no_grad():
             for hname in ("out_forces", "out_forces2"):
                 getattr(model_mv, hname).output_network[1].vec2_proj.weight.mul_(100.0)
-        model_mv._engine = None
         trainer_mv = DenoisingTrainer(model_mv, device=dev)
         eng_mv = model_mv.engine(dev)
         rows_log = []
