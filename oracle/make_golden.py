@@ -712,8 +712,95 @@ def main_painn_scaled():
     np.savez_compressed(GOLD / "painn_small_scaled.npz", **npify(out))
 
 
+def _reference_training_functions():
+    """tr_so3_schedule and DenoisingTrainer._compute_loss executed from the reference's source file (the functions only:
+    importing the trainer module drags in the whole training stack)."""
+    import ast
+
+    from adsorbdiff.utils import rot_utils as ref_rot
+    import torch_scatter as _ts
+
+    tree = ast.parse(Path("/root/reference/adsorbdiff/trainers/sde_denoising_trainer.py").read_text())
+    wanted = {}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("pbc_correction", "tr_so3_schedule"):
+            wanted[node.name] = node
+        if isinstance(node, ast.ClassDef) and node.name == "DenoisingTrainer":
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == "_compute_loss":
+                    wanted[sub.name] = sub
+    assert set(wanted) == {"pbc_correction", "tr_so3_schedule", "_compute_loss"}, set(wanted)
+    ns = {"torch": torch, "np": np, "scatter": _ts.scatter, "rot_utils": ref_rot}
+    exec(compile(ast.Module(body=list(wanted.values()), type_ignores=[]), "<reference functions>", "exec"), ns)
+    return ns["tr_so3_schedule"], ns["_compute_loss"], ref_rot
+
+
+def perturb_biases_(model, seed):
+    """Biases and LayerNorm affine parameters away from their initial 0 / 1 (so that they are exercised), reproducibly
+    from a seed: tests rebuild the same weights instead of loading 86 MB of them."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias") or "layernorm" in n_:
+                p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+
+
+def main_train_full():
+    # ---------------------------------------------------------------- 10. training step at config-5 width
+    # H = 512, 6 layers, 128 radial functions, 12 A / 50 neighbours (configs/painn yml) on 2 x 200-atom systems: the
+    # reference's noising, its model's loss and torch.autograd's gradients for all 114 parameters.  The weights are
+    # seed 0 + perturb_biases_(seed 3) and are NOT stored (the mirror class reproduces them bit for bit, asserted here);
+    # of every gradient the norm and a strided sample of 256 elements are.
+    import types as _types
+
+    ref_tr_so3_schedule, ref_compute_loss, ref_rot = _reference_training_functions()
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    ref = RefPaiNN(None, 50, 1, cutoff=12.0, max_neighbors=50, scale_file=SCALE_FILE, so3_denoising=True)
+    perturb_biases_(ref, 3)
+    torch.manual_seed(0)
+    mine = MyPaiNN(None, 50, 1, cutoff=12.0, max_neighbors=50, scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True)
+    perturb_biases_(mine, 3)
+    sd_r, sd_m = ref.state_dict(), mine.state_dict()
+    assert [k for k, _ in ref.named_parameters()] == [k for k, _ in mine.named_parameters()]
+    assert all(torch.equal(sd_r[k], sd_m[k]) for k in sd_r if k != "atom_radii")
+    tparams = dict(ads_std_low=0.1, ads_std_high=10, free_std_low=0.0, free_std_high=0.0, rot_std_low=0.01,
+                   rot_std_high=1.55, num_steps=50)
+    bt = make_batch(2, seed=77)
+    bt.fixed = bt.fixed.clone()
+    pos_clean = bt.pos.clone()
+    torch.manual_seed(2025)
+    np.random.seed(2025)
+    nb = ref_tr_so3_schedule(bt.clone(), tparams)
+    ref.train()
+    ref.zero_grad()
+    o1, o2 = ref(nb.clone())
+    fake_self = _types.SimpleNamespace(config={"optim": {}, "model_attributes": {"so3_denoising": True}}, device="cpu")
+    loss_r = ref_compute_loss(fake_self, {"positions": o1, "positions_free": o2}, nb)
+    loss_r.backward()
+    names, norms, samples = [], [], {}
+    for k, p in ref.named_parameters():
+        names.append(k)
+        if p.grad is None:
+            norms.append(0.0)
+            continue
+        g = p.grad.reshape(-1)
+        norms.append(float(g.double().norm()))
+        idx = torch.linspace(0, g.numel() - 1, min(256, g.numel())).round().long()
+        samples["gidx::" + k] = idx
+        samples["gval::" + k] = g[idx].clone()
+    print(f"[train full-H] loss {loss_r.item():.8f}; {sum(1 for v in norms if v > 0)} of {len(names)} parameters with gradient;"
+          f" |g| from {min(v for v in norms if v > 0):.3e} to {max(norms):.3e}")
+    fxt = dict(pos_clean=pos_clean, pos_noised=nb.pos, tr_sigma=nb.tr_sigma, rot_sigma=nb.rot_sigma, tr_score=nb.tr_score,
+               rot_score=nb.rot_score, out1=o1.detach(), out2=o2.detach(), loss=loss_r.detach(), weight_seed=0, bias_seed=3,
+               cutoff=12.0, max_neighbors=50, grad_names=np.array(names), grad_norms=np.array(norms),
+               **{k: v for k, v in batch_inputs(bt).items() if k != "pos"})
+    fxt.update(samples)
+    np.savez_compressed(GOLD / "train_full.npz", **npify(fxt))
+
+
 def main():
-    """ADF_GOLDEN_ONLY=eqv2 / painn / painn_scaled / handoff regenerates one family (all are deterministic)."""
+    """ADF_GOLDEN_ONLY=eqv2 / painn / painn_scaled / handoff / train_full regenerates one family (all are deterministic)."""
     only = os.environ.get("ADF_GOLDEN_ONLY")
     if only in (None, "", "painn"):
         main_painn()
@@ -723,6 +810,8 @@ def main():
         main_eqv2()
     if only in (None, "", "handoff"):
         main_handoff()
+    if only in (None, "", "train_full"):
+        main_train_full()
     print("all goldens written to", GOLD)
 
 

@@ -55,6 +55,49 @@ def test_loss_and_gradients_vs_reference_autograd():
             assert rel_err(P[name].grad.cpu(), fx[key]) < 1e-4, (name, rel_err(P[name].grad.cpu(), fx[key]))
 
 
+def test_config5_width_loss_and_gradients_vs_reference_autograd():
+    """H = 512, 6 layers, 12 A / 50 neighbours (the shipped PaiNN config) on 2 x 200-atom systems: tests/golden/
+    train_full.npz (oracle/make_golden.py section 10) holds the reference model's loss and, for each of its 114
+    parameters, the norm and a strided 256-element sample of torch.autograd's gradient.  The weights are rebuilt from the
+    seeds (the generator asserts that this mirror reproduces the reference's bit for bit)."""
+    from adsorbdiff_amd.scaling import PAINN_NB6_SCALE_FACTORS
+
+    fx = load_npz("train_full.npz")
+    tb = load_npz("igso3_tables.npz")
+    torch.manual_seed(int(fx["weight_seed"]))
+    m = PaiNN(None, 50, 1, cutoff=float(fx["cutoff"]), max_neighbors=int(fx["max_neighbors"]),
+              scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True)
+    g = torch.Generator().manual_seed(int(fx["bias_seed"]))
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if n_.endswith("bias") or "layernorm" in n_:
+                p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+    m = m.to(DEV)
+    b = batch_from_fixture(fx, pos_key="pos_noised", device=DEV)
+    targets = {k: torch.from_numpy(fx[k]) for k in ("tr_sigma", "rot_sigma", "tr_score", "rot_score")}
+    step = PaiNNTrainStep(m, DEV, igso3=Igso3Tables(tb["omegas"], None, None, tb["exp_score_norm"]))
+    step.zero_grad()
+    loss = step.loss_and_grad(b, targets).cpu()
+    assert rel_err(step.last_outputs[0].cpu(), fx["out1"]) < 1e-5 and rel_err(step.last_outputs[1].cpu(), fx["out2"]) < 1e-5
+    assert abs(float(loss[0]) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    P = dict(m.named_parameters())
+    assert list(P) == [str(n) for n in fx["grad_names"]]
+    worst = 0.0
+    for name, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        name = str(name)
+        got = P[name].grad
+        if gn == 0.0:
+            assert got is None or float(got.norm()) == 0.0, name
+            continue
+        assert abs(float(got.double().norm()) - gn) < 1e-4 * gn, (name, float(got.norm()), gn)
+        idx = torch.from_numpy(fx["gidx::" + name])
+        ref = torch.from_numpy(fx["gval::" + name]).double()
+        e = float((got.reshape(-1).cpu()[idx].double() - ref).norm() / ref.norm())
+        worst = max(worst, e)
+        assert e < 1e-4, (name, e)
+    print(f"config-5 width: worst sampled gradient error {worst:.2e}")
+
+
 def test_igso3_tables_computed_on_the_device_are_finite_and_pinned():
     """compute_tables on the ROCm device (what a fresh checkout does on first use): every row of the grid finite
     (in the tail of a narrow distribution the series is cancellation noise and a device reduction order can land on
