@@ -37,6 +37,10 @@ struct eq_ffn {         // FeedForwardNetwork with grid MLP + separable S2 activ
     const float *l1_w, *l1_b, *l2_w, *l2_b;
     eq_lin l1[EQ_MAX_L + 1], l2[EQ_MAX_L + 1];
     eq_lin scalar, g0, g2, g4;
+    // The grid MLP's first and last maps act on channels only and have no bias, the grid transforms act on coefficients
+    // only: grid_mlp[0] commutes with to_grid and grid_mlp[4] with from_grid.  l1f[l] = g0 . l1[l] and (l >= 1)
+    // l2f[l] = l2[l] . g4 are formed once per weight binding, so that only ONE product runs on the 324-point grid rows.
+    eq_lin l1f[EQ_MAX_L + 1], l2f[EQ_MAX_L + 1];
 };
 struct eq_block {
     eq_norm n1, n2;
@@ -71,6 +75,8 @@ struct adf_eqv2 {
     eq_dims* d_dev;   // device copy (kernels that index its tables per lane)
     int device, num_cus;
     bool weights_set, consts_set, exact_f32, s2_emit_mag, presplit;
+    bool fold_on, folded;      // grid-MLP end maps folded into the SO(3) linears (eq_ffn); ADF_EQV2_FOLD=0 switches it off
+    float* fold_arena; size_t fold_floats;
     // constants (device)
     float *jd, *to_red, *from_red, *to_full, *from_full;
     // weights
@@ -145,7 +151,9 @@ int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, i
                         hipStream_t s);
 int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* alpha, int n0, int n1, float* agg,
                              bool only_l1, hipStream_t s);
-int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, hipStream_t s);
+// silu: apply SiLU to the grid values (the folded feed-forward network, eq_ffn)
+int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, bool silu, hipStream_t s);
+int32_t eq_launch_fold(const float* A, const float* B, int O, int K, int I, float* out, hipStream_t s);
 int32_t eq_launch_from_grid(const adf_eqv2* h, const float* g, const float* gate, int n0, int n1, float* h2, hipStream_t s);
 int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* agg3, int N, float* f, hipStream_t s);
 int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float* W, const float* bias, float* Cm, int ldc,

@@ -122,6 +122,7 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     // instead of a separate pass over them: measured slower on MI355X (+8 ms vs -3 ms per forward at 256 k edges): off
     { const char* e2 = getenv("ADF_EQV2_S2_EMIT"); h->s2_emit_mag = e2 && atoi(e2) != 0; }
     { const char* e3 = getenv("ADF_EQV2_PRESPLIT"); h->presplit = !(e3 && atoi(e3) == 0); }
+    { const char* e4 = getenv("ADF_EQV2_FOLD"); h->fold_on = !(e4 && atoi(e4) == 0); }
     h->prof_ev = new std::vector<hipEvent_t>();
     h->prof_cat = new std::vector<int>();
     int32_t st = eq_alloc(&h->flags, EQ_NFLAGS);
@@ -155,7 +156,7 @@ extern "C" int32_t adf_eqv2_destroy(adf_eqv2_t h) {
     { unsigned char* t = (unsigned char*)h->gtab_to; eq_free(t); h->gtab_to = nullptr; }
     { unsigned char* t = (unsigned char*)h->gtab_from; eq_free(t); h->gtab_from = nullptr; }
     eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
-    eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena); eq_free(h->rtab_arena);
+    eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena); eq_free(h->rtab_arena); eq_free(h->fold_arena);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
     delete h->prof_cat;
     delete h;
@@ -320,6 +321,8 @@ static void eq_collect_lins(adf_eqv2* h, std::vector<eq_lin*>& v) {
         attn(&b.ga, true);
         v.push_back(&b.ffn.scalar); v.push_back(&b.ffn.g0); v.push_back(&b.ffn.g2); v.push_back(&b.ffn.g4);
         for (int l = 0; l <= d.L; ++l) { v.push_back(&b.ffn.l1[l]); v.push_back(&b.ffn.l2[l]); }
+        if (h->folded)
+            for (int l = 0; l <= d.L; ++l) { v.push_back(&b.ffn.l1f[l]); if (l) v.push_back(&b.ffn.l2f[l]); }
     }
     attn(&h->force[0], false); attn(&h->force[1], false);
 }
@@ -416,6 +419,42 @@ static int32_t eq_radial_static(adf_eqv2* h, eq_radial** rads, int nrad, hipStre
     return ADF_OK;
 }
 
+// Folded feed-forward weights (eq_ffn): l1f[l] = g0 . l1[l] (+ bias g0 . b on l = 0), l2f[l] = l2[l] . g4 for l >= 1.
+static int32_t eq_fold_ffn(adf_eqv2* h, hipStream_t s) {
+    const eq_dims& d = h->d;
+    h->folded = false;
+    if (!h->fold_on) return ADF_OK;
+    const size_t per = (size_t)(d.L + 1) * d.F * d.C + d.F + (size_t)d.L * d.C * d.F;
+    const size_t total = per * h->hp.num_layers;
+    if (h->fold_floats < total) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        eq_free(h->fold_arena);
+        h->fold_floats = 0;
+        ADF_TRY(eq_alloc(&h->fold_arena, total));
+        h->fold_floats = total;
+    }
+    float* p = h->fold_arena;
+    for (int i = 0; i < h->hp.num_layers; ++i) {
+        eq_ffn& f = h->blk[i].ffn;
+        float* b0 = p + (size_t)(d.L + 1) * d.F * d.C;
+        for (int l = 0; l <= d.L; ++l) {
+            float* w = p + (size_t)l * d.F * d.C;
+            ADF_TRY(eq_launch_fold(f.g0.w, f.l1[l].w, d.F, d.F, d.C, w, s));
+            f.l1f[l] = mk_lin(w, l == 0 ? b0 : nullptr, d.F, d.C);
+        }
+        ADF_TRY(eq_launch_fold(f.g0.w, f.l1_b, d.F, d.F, 1, b0, s));
+        float* q = b0 + d.F;
+        for (int l = 1; l <= d.L; ++l) {
+            float* w = q + (size_t)(l - 1) * d.C * d.F;
+            ADF_TRY(eq_launch_fold(f.l2[l].w, f.g4.w, d.C, d.F, d.F, w, s));
+            f.l2f[l] = mk_lin(w, nullptr, d.C, d.F);
+        }
+        p += per;
+    }
+    h->folded = true;
+    return ADF_OK;
+}
+
 extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const void* const* weights, void* stream) {
     if (!h || !weights) { adf_set_error("eqv2_set_weights: null argument"); return ADF_EINVAL; }
     const eq_dims& d = h->d;
@@ -465,7 +504,10 @@ extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const v
         rads[i]->w0t = h->wt_arena + per * i;
         ADF_TRY(eq_launch_transpose(rads[i]->l0.w, rads[i]->w0t, d.EC, d.NB + 2 * d.EC, s));
     }
+    ADF_TRY(eq_fold_ffn(h, s));
     ADF_TRY(eq_split_weights(h, s));
+    if (h->folded)
+        for (int i = 0; i < h->hp.num_layers; ++i) h->blk[i].ffn.l2f[0] = h->blk[i].ffn.l2[0];  // l = 0 comes from the gate
     ADF_TRY(eq_radial_static(h, rads, k, s));
     h->weights_set = true;
     return ADF_OK;
@@ -760,13 +802,20 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
             const eq_ffn& f = bk.ffn;
             // scalar gate from the l = 0 row of every node (row stride S*C)
             ADF_TRY(eq_gemm(h, h->y, d.S * d.C, nullptr, &f.scalar, true, h->gate, d.F, nullptr, N, 2, false, s));
-            ADF_TRY(eq_so3_linear(h, f.l1, h->y, d.C, h->h1, d.F, N, false, s));
+            const bool fold = h->folded && !h->exact_f32;
+            ADF_TRY(eq_so3_linear(h, fold ? f.l1f : f.l1, h->y, d.C, h->h1, d.F, N, false, s));
             for (int n0 = 0; n0 < N; n0 += (int)h->chunk_nodes) {
                 const int n1 = (int)((n0 + h->chunk_nodes < N) ? n0 + h->chunk_nodes : N);
                 const long long rows = (long long)(n1 - n0) * d.G;
                 float* ga = h->garena;
                 float* gb = h->garena + (size_t)h->chunk_nodes * d.G * d.F;
-                ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, s));
+                if (fold) {  // silu(to_grid(.)) -> one product + SiLU -> from_grid
+                    ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, true, s));
+                    ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g2, false, gb, d.F, nullptr, rows, 2, false, s));
+                    ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
+                    continue;
+                }
+                ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, false, s));
                 // the first product measures its operand rows itself; the next two get them from the producer's epilogue
                 const bool chain = eq_uses_mfma(h, ga, d.F, &f.g0, gb, d.F) && eq_uses_mfma(h, gb, d.F, &f.g2, ga, d.F) &&
                                    eq_uses_mfma(h, ga, d.F, &f.g4, gb, d.F) && 3 * rows <= h->rs_cap;
@@ -777,7 +826,7 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
                 ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g4, false, gb, d.F, nullptr, rows, 0, false, s, m2, nullptr));
                 ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
             }
-            ADF_TRY(eq_so3_linear(h, f.l2, h->h2, d.F, h->x, d.C, N, true, s));
+            ADF_TRY(eq_so3_linear(h, fold ? f.l2f : f.l2, h->h2, d.F, h->x, d.C, N, true, s));
         }
         if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks + (size_t)(i + 1) * xs, h->x, xs * 4, hipMemcpyDeviceToDevice, s));
     }

@@ -1021,7 +1021,7 @@ int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* a
 // grid -> SO3 (from_full), l = 0 replaced by the scalar gate.  One workgroup per node, thread = hidden channel.
 template <int LT>
 __global__ void eq_to_grid_kernel(const float* __restrict__ h1, const float* __restrict__ tg, int n0, int n1, eq_dims d,
-                                  float* __restrict__ g) {
+                                  int silu, float* __restrict__ g) {
     extern __shared__ float T[];  // [G][S]
     constexpr int S = (LT + 1) * (LT + 1);
     for (int t = threadIdx.x; t < d.G * S; t += blockDim.x) T[t] = tg[t];
@@ -1037,7 +1037,7 @@ __global__ void eq_to_grid_kernel(const float* __restrict__ h1, const float* __r
         float a = 0.f;
 #pragma unroll
         for (int s = 0; s < S; ++s) a += T[p * S + s] * in[s];
-        gr[(size_t)p * d.F] = a;
+        gr[(size_t)p * d.F] = silu ? eq_silu(a) : a;
     }
 }
 
@@ -1071,7 +1071,7 @@ __global__ void eq_from_grid_kernel(const float* __restrict__ g, const float* __
 //   from grid: out[s, f] = sum_p F[p, s] g[p, f]     A = F^T (M = coefficient, 2 blocks; K = grid point), B from memory
 __global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __restrict__ h1, const eqhalf8* __restrict__ tabs,
                                                                   int npb, float inv_sT, int n0, int n1, int S, int F, int G,
-                                                                  float* __restrict__ g) {
+                                                                  int silu, float* __restrict__ g) {
     extern __shared__ eqhalf8 tab[];  // [npb][4 ks][hi|lo][64]
     const int ntab = npb * 4 * 2 * 64;
     for (int t = threadIdx.x; t < ntab; t += 512) tab[t] = tabs[t];
@@ -1123,80 +1123,130 @@ __global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pp = 32 * pb + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (pp < G) gr[(size_t)pp * F] = acc[r] * sc;
+                const float v = acc[r] * sc;
+                if (pp < G) gr[(size_t)pp * F] = silu ? eq_silu(v) : v;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(512, 2) void eq_from_grid_mfma_kernel(const float* __restrict__ g, const eqhalf8* __restrict__ tabs,
+// One pass over memory: the item's [G, 32] tile is taken in chunks of CH k-steps (16 grid points each); every chunk has
+// its loads in flight together, its own power-of-two lift PER CHANNEL (a lane and its partner 32 lanes on hold one column
+// of the B operand, and every accumulator register of a lane belongs to that column, so the lift is a per-lane scalar) and
+// its own accumulators, folded into the running sums in fp32.  FT > 0: the channel count as a compile-time constant
+// (row offsets become instruction immediates).
+template <int CH, int FT>
+__global__ __launch_bounds__(512, 1) void eq_from_grid_mfma_kernel(const float* __restrict__ g, const eqhalf8* __restrict__ tabs,
                                                                     int nkst, float inv_sF, const float* __restrict__ gate,
-                                                                    int n0, int n1, int S, int F, int G, float* __restrict__ h2) {
+                                                                    int n0, int n1, int S, int Frt, int G, float* __restrict__ h2) {
     extern __shared__ eqhalf8 tab[];  // [nkst][2 sb][hi|lo][64]
+    const int F = FT > 0 ? FT : Frt;
     const int ntab = nkst * 2 * 2 * 64;
     for (int t = threadIdx.x; t < ntab; t += 512) tab[t] = tabs[t];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, kh = lane >> 5;
+    const int lane = threadIdx.x & 63, cl = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: item, node and base pointers stay scalar
     const int nblk = F >> 5;
     const long long items = (long long)(n1 - n0) * nblk;
     for (long long item = (long long)blockIdx.x * 8 + wave; item < items; item += (long long)gridDim.x * 8) {
-        const int n = n0 + (int)(item / nblk), f = (int)(item % nblk) * 32 + cl;
-        const float* gr = g + (size_t)(n - n0) * G * F + f;
-        float mx = 0.f;
-        for (int pp = kh; pp < G; pp += 2) mx = fmaxf(mx, fabsf(gr[(size_t)pp * F]));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const float lift = eq_pow2_lift(mx);
-        eqf32x16 acc[2];
+        const int n = n0 + (int)(item / nblk), fb = (int)(item % nblk) * 32, f = fb + cl;
+        const float* gl = g + (size_t)(n - n0) * G * F + fb + 8 * kh * F + cl;
+        eqf32x16 tot[2];
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
-        for (int kst = 0; kst < nkst; ++kst) {
-            eqhalf8 bh, bl;
+            for (int r = 0; r < 16; ++r) tot[sb][r] = 0.f;
+        for (int k0 = 0; k0 < nkst; k0 += CH) {
+            float v[CH][8];
+            float mx = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int pp = 16 * kst + 8 * kh + j;
-                const float sv = (pp < G ? gr[(size_t)pp * F] : 0.f) * lift;
-                const _Float16 hh = (_Float16)sv;
-                bh[j] = hh;
-                bl[j] = (_Float16)(sv - (float)hh);
-            }
+            for (int c = 0; c < CH; ++c)
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
-                const eqhalf8 ah = tab[((kst * 2 + sb) * 2 + 0) * 64 + lane];
-                const eqhalf8 al = tab[((kst * 2 + sb) * 2 + 1) * 64 + lane];
-                acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[sb], 0, 0, 0);
-                acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[sb], 0, 0, 0);
-                acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[sb], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) {
+                    const int pp = 16 * (k0 + c) + 8 * kh + j;
+                    v[c][j] = pp < G ? gl[(size_t)(16 * (k0 + c) + j) * F] : 0.f;
+                }
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf(v[c][j]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float lift = eq_pow2_lift(mx);
+            eqf32x16 acc[2];
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[sb][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (k0 + c < nkst) {
+                    eqhalf8 bh, bl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float sv = v[c][j] * lift;
+                        const _Float16 hh = (_Float16)sv;
+                        bh[j] = hh;
+                        bl[j] = (_Float16)(sv - (float)hh);
+                    }
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb) {
+                        const eqhalf8 ah = tab[(((k0 + c) * 2 + sb) * 2 + 0) * 64 + lane];
+                        const eqhalf8 al = tab[(((k0 + c) * 2 + sb) * 2 + 1) * 64 + lane];
+                        acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[sb], 0, 0, 0);
+                        acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[sb], 0, 0, 0);
+                        acc[sb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[sb], 0, 0, 0);
+                    }
+                }
             }
+            const float il = 1.0f / lift;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot[sb][r] += acc[sb][r] * il;
         }
-        const float sc = inv_sF / lift;
         float* hr = h2 + (size_t)n * S * F + f;
 #pragma unroll
         for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int sidx = 32 * sb + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (sidx < S) hr[(size_t)sidx * F] = sidx == 0 ? gate[(size_t)n * F + f] : acc[sb][r] * sc;
+                if (sidx < S) hr[(size_t)sidx * F] = sidx == 0 ? gate[(size_t)n * F + f] : tot[sb][r] * inv_sF;
             }
     }
 }
 
-int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, hipStream_t s) {
+// out[o, i] = sum_k A[o, k] B[k, i] (row-major, double accumulation): folded weights, once per weight binding
+__global__ void eq_fold_kernel(const float* __restrict__ A, const float* __restrict__ B, int O, int K, int I,
+                               float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)O * I) return;
+    const int o = (int)(t / I), i = (int)(t % I);
+    double a = 0.0;
+    for (int k = 0; k < K; ++k) a += (double)A[(size_t)o * K + k] * (double)B[(size_t)k * I + i];
+    out[t] = (float)a;
+}
+
+int32_t eq_launch_fold(const float* A, const float* B, int O, int K, int I, float* out, hipStream_t s) {
+    const long long n = (long long)O * I;
+    hipLaunchKernelGGL(eq_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, A, B, O, K, I, out);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, bool silu, hipStream_t s) {
     if (n1 <= n0) return ADF_OK;
     if (!h->exact_f32 && h->gtab_to && h->d.S <= 64 && h->d.F % 32 == 0) {
         const size_t dyn = (size_t)h->g_npb * 4 * 2 * 64 * 16;
         ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_to_grid_mfma_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(eq_to_grid_mfma_kernel, dim3(h->num_cus), dim3(512), dyn, s, h1, (const eqhalf8*)h->gtab_to, h->g_npb,
-                           h->g_inv_sT, n0, n1, h->d.S, h->d.F, h->d.G, g);
+                           h->g_inv_sT, n0, n1, h->d.S, h->d.F, h->d.G, silu ? 1 : 0, g);
         ADF_HIP_CHECK(hipGetLastError());
         return ADF_OK;
     }
     const int bd = (h->d.F + 63) / 64 * 64;
     const size_t dyn = sizeof(float) * h->d.G * h->d.S;
-#define EQ_TG(LT_) hipLaunchKernelGGL(eq_to_grid_kernel<LT_>, dim3(n1 - n0), dim3(bd), dyn, s, h1, h->to_full, n0, n1, h->d, g)
+#define EQ_TG(LT_) hipLaunchKernelGGL(eq_to_grid_kernel<LT_>, dim3(n1 - n0), dim3(bd), dyn, s, h1, h->to_full, n0, n1, h->d, silu ? 1 : 0, g)
     EQ_FOR_L(h->d.L, EQ_TG)
 #undef EQ_TG
     ADF_HIP_CHECK(hipGetLastError());
@@ -1207,10 +1257,15 @@ int32_t eq_launch_from_grid(const adf_eqv2* h, const float* g, const float* gate
     if (n1 <= n0) return ADF_OK;
     if (!h->exact_f32 && h->gtab_from && h->d.S <= 64 && h->d.F % 32 == 0) {
         const size_t dyn = (size_t)h->g_nkst * 2 * 2 * 64 * 16;
-        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_from_grid_mfma_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(eq_from_grid_mfma_kernel, dim3(h->num_cus), dim3(512), dyn, s, g, (const eqhalf8*)h->gtab_from,
-                           h->g_nkst, h->g_inv_sF, gate, n0, n1, h->d.S, h->d.F, h->d.G, h2);
+#define EQ_FGM(CH_, FT_)                                                                                                     \
+    do {                                                                                                                     \
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_from_grid_mfma_kernel<CH_, FT_>),                \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                            \
+        hipLaunchKernelGGL((eq_from_grid_mfma_kernel<CH_, FT_>), dim3(h->num_cus), dim3(512), dyn, s, g,                     \
+                           (const eqhalf8*)h->gtab_from, h->g_nkst, h->g_inv_sF, gate, n0, n1, h->d.S, h->d.F, h->d.G, h2);  \
+    } while (0)
+        if (h->d.F == 128) EQ_FGM(7, 128); else EQ_FGM(7, 0);
+#undef EQ_FGM
         ADF_HIP_CHECK(hipGetLastError());
         return ADF_OK;
     }
