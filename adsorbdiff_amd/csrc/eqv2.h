@@ -152,7 +152,10 @@ int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, i
 int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* alpha, int n0, int n1, float* agg,
                              bool only_l1, hipStream_t s);
 // silu: apply SiLU to the grid values (the folded feed-forward network, eq_ffn)
-int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, bool silu, hipStream_t s);
+// node_mag != null: the matrix-core kernel also leaves max |g| of every node's tile in node_mag[n - n0] (zeroed here) and
+// sets *emitted; the VALU kernel does not
+int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, bool silu, hipStream_t s,
+                          float* node_mag = nullptr, bool* emitted = nullptr);
 int32_t eq_launch_fold(const float* A, const float* B, int O, int K, int I, float* out, hipStream_t s);
 int32_t eq_launch_from_grid(const adf_eqv2* h, const float* g, const float* gate, int n0, int n1, float* h2, hipStream_t s);
 int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* agg3, int N, float* f, hipStream_t s);
@@ -162,4 +165,4 @@ int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hip
 // C (+)= act(A . W^T + b): exact f32 for any shape; act: 0 none, 2 SiLU
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
                 float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s,
-                const float* rs_pre = nullptr, float* out_mag = nullptr);
+                const float* rs_pre = nullptr, float* out_mag = nullptr, int rs_div = 1);  // rs_div: row r reads rs_pre[r / rs_div]

@@ -18,7 +18,7 @@ bool eq_gemm16_ok(const float* A, const eq_rowmap* am, const float* Cm, const eq
 int32_t eq_launch_rowscale(const float* A, const eq_rowmap* am, long long M, int K, float* rs, hipStream_t s);
 int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscale, const adf_w16* W, const float* bias,
                          float* Cm, const eq_rowmap* cm, long long M, int N, int K, int act, bool accumulate,
-                         hipStream_t s, float* out_mag);
+                         hipStream_t s, float* out_mag, int rs_div = 1);
 
 template <typename T>
 static int32_t eq_alloc(T** p, size_t count) {
@@ -614,7 +614,7 @@ extern "C" int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, cons
 // ---------------------------------------------------------------------------------------------- dense product dispatch
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
                 float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s,
-                const float* rs_pre, float* out_mag) {
+                const float* rs_pre, float* out_mag, int rs_div) {
     const eq_rowmap a1 = {lda, 1, 0}, c1 = {ldc, 1, 0};
     const eq_rowmap* am = amap ? amap : &a1;
     const eq_rowmap* cm = cmap ? cmap : &c1;
@@ -623,7 +623,7 @@ int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* ama
         if (!rs_pre) ADF_TRY(eq_launch_rowscale(A, am, M, W->in, h->rs, s));
         if (out_mag) ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));
         return eq_launch_gemm16(A, am, rs_pre ? rs_pre : h->rs, &W->w16, use_bias ? W->b : nullptr, Cm, cm, M, W->out, W->in,
-                                act, accumulate, s, out_mag);
+                                act, accumulate, s, out_mag, rs_pre ? rs_div : 1);
     }
     // exact-f32 product: no lifts needed downstream either (out_mag stays untouched; callers only pass it on when the
     // matrix-core path runs, see eq_uses_mfma)
@@ -810,8 +810,13 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
                 float* ga = h->garena;
                 float* gb = h->garena + (size_t)h->chunk_nodes * d.G * d.F;
                 if (fold) {  // silu(to_grid(.)) -> one product + SiLU -> from_grid
-                    ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, true, s));
-                    ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g2, false, gb, d.F, nullptr, rows, 2, false, s));
+                    // the product's row lifts: one per NODE (the largest grid value of its tile, left by to_grid) - from_grid
+                    // sums a node's rows with comparable weights, so a row far below the node's largest carries no weight
+                    bool em = false;
+                    const bool want = eq_uses_mfma(h, ga, d.F, &f.g2, gb, d.F) && (n1 - n0) <= h->rs_cap;
+                    ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, true, s, want ? h->rs : nullptr, &em));
+                    ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g2, false, gb, d.F, nullptr, rows, 2, false, s, em ? h->rs : nullptr,
+                                    nullptr, d.G));
                     ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
                     continue;
                 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void eq_gemm16_kernel(const float* __restri
                                                            const float* __restrict__ inv_scale,
                                                            const float* __restrict__ bias, float* __restrict__ Cm,
                                                            eq_rowmap cm, long long M, int N, int K, int tiles_n,
-                                                           unsigned int* __restrict__ out_mag) {
+                                                           unsigned int* __restrict__ out_mag, int rs_div) {
     constexpr int MI = 2;
     constexpr int TM = 64 * MI, TN = 64 * NJ, NA = TM / 32;
     __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * GLD];
@@ -95,13 +95,13 @@ __global__ __launch_bounds__(256, 2) void eq_gemm16_kernel(const float* __restri
         long long grow = m0 + row;
         if (grow > M - 1) grow = M - 1;
         a_ptr[i] = A + (grow / am.period) * am.outer + (grow % am.period) * (long long)am.inner + kq * 4;
-        a_rs[i] = rscale ? eq16_lift(rscale[grow]) : 1.0f;
+        a_rs[i] = rscale ? eq16_lift(rscale[rs_div > 1 ? grow / rs_div : grow]) : 1.0f;
         a_off[i] = row * GLD + kq * 4;
     }
     if (tid < TM) {
         long long grow = m0 + tid;
         if (grow > M - 1) grow = M - 1;
-        rinv[tid] = rscale ? 1.0f / eq16_lift(rscale[grow]) : 1.0f;
+        rinv[tid] = rscale ? 1.0f / eq16_lift(rscale[rs_div > 1 ? grow / rs_div : grow]) : 1.0f;
     }
     int w_src[NJ], w_off[NJ];
 #pragma unroll
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __re
                                                                const float* __restrict__ inv_scale,
                                                                const float* __restrict__ bias, float* __restrict__ Cm,
                                                                eq_rowmap cm, long long M, int N, int K, int tiles_n,
-                                                           unsigned int* __restrict__ out_mag) {
+                                                               unsigned int* __restrict__ out_mag, int rs_div) {
     constexpr int MI = 4, NJ = 2, TM = 256, TN = 256, NA = 4, NW = 2;
     __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * GLD];
     __shared__ float rinv[TM];
@@ -270,13 +270,13 @@ __global__ __launch_bounds__(512, 2) void eq_gemm16_256_kernel(const float* __re
         long long grow = m0 + row;
         if (grow > M - 1) grow = M - 1;
         a_ptr[i] = A + (grow / am.period) * am.outer + (grow % am.period) * (long long)am.inner + kq * 4;
-        a_rs[i] = rscale ? eq16_lift(rscale[grow]) : 1.0f;
+        a_rs[i] = rscale ? eq16_lift(rscale[rs_div > 1 ? grow / rs_div : grow]) : 1.0f;
         a_off[i] = row * GLD + kq * 4;
     }
     if (tid < TM) {
         long long grow = m0 + tid;
         if (grow > M - 1) grow = M - 1;
-        rinv[tid] = rscale ? 1.0f / eq16_lift(rscale[grow]) : 1.0f;
+        rinv[tid] = rscale ? 1.0f / eq16_lift(rscale[rs_div > 1 ? grow / rs_div : grow]) : 1.0f;
     }
     int w_src[NW], w_off[NW];
 #pragma unroll
@@ -628,7 +628,7 @@ bool eq_gemm16_ok(const float* A, const eq_rowmap* am, const float* Cm, const eq
 
 int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscale, const adf_w16* W, const float* bias,
                          float* Cm, const eq_rowmap* cm, long long M, int N, int K, int act, bool accumulate,
-                         hipStream_t s, float* out_mag) {
+                         hipStream_t s, float* out_mag, int rs_div) {
     if (M <= 0 || N <= 0) return ADF_OK;
     static int big = -1;
     if (big < 0) { const char* e = getenv("ADF_EQV2_GEMM_TILE"); big = (e && atoi(e) == 128) ? 0 : 1; }
@@ -640,7 +640,7 @@ int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscal
 #define EQ_L256(ACT_, ACC_)                                                                                          \
     hipLaunchKernelGGL((eq_gemm16_256_kernel<ACT_, ACC_>), dim3((unsigned)nb), dim3(512), 0, s, A, *am, rscale,      \
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n, \
-                       reinterpret_cast<unsigned int*>(out_mag))
+                       reinterpret_cast<unsigned int*>(out_mag), rs_div)
         if (act == 2) { if (accumulate) EQ_L256(2, true); else EQ_L256(2, false); }
         else { if (accumulate) EQ_L256(0, true); else EQ_L256(0, false); }
 #undef EQ_L256
@@ -658,7 +658,7 @@ int32_t eq_launch_gemm16(const float* A, const eq_rowmap* am, const float* rscal
 #define EQ_L16(ACT_, NJ_, ACC_)                                                                                       \
     hipLaunchKernelGGL((eq_gemm16_kernel<ACT_, NJ_, ACC_>), grid, dim3(256), 0, s, A, *am, rscale,                    \
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, Cm, *cm, M, N, K, tiles_n, \
-                       reinterpret_cast<unsigned int*>(out_mag))
+                       reinterpret_cast<unsigned int*>(out_mag), rs_div)
     if (NJ == 2) {
         if (act == 2) { if (accumulate) EQ_L16(2, 2, true); else EQ_L16(2, 2, false); }
         else { if (accumulate) EQ_L16(0, 2, true); else EQ_L16(0, 2, false); }

@@ -1071,7 +1071,8 @@ __global__ void eq_from_grid_kernel(const float* __restrict__ g, const float* __
 //   from grid: out[s, f] = sum_p F[p, s] g[p, f]     A = F^T (M = coefficient, 2 blocks; K = grid point), B from memory
 __global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __restrict__ h1, const eqhalf8* __restrict__ tabs,
                                                                   int npb, float inv_sT, int n0, int n1, int S, int F, int G,
-                                                                  int silu, float* __restrict__ g) {
+                                                                  int silu, float* __restrict__ g,
+                                                                  unsigned int* __restrict__ node_mag) {
     extern __shared__ eqhalf8 tab[];  // [npb][4 ks][hi|lo][64]
     const int ntab = npb * 4 * 2 * 64;
     for (int t = threadIdx.x; t < ntab; t += 512) tab[t] = tabs[t];
@@ -1108,6 +1109,7 @@ __global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __
             }
         const float sc = inv_sT / lift;
         float* gr = g + (size_t)(n - n0) * G * F + f;
+        float omx = 0.f;
         for (int pb = 0; pb < npb; ++pb) {
             eqf32x16 acc;
 #pragma unroll
@@ -1123,9 +1125,14 @@ __global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int pp = 32 * pb + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float v = acc[r] * sc;
-                if (pp < G) gr[(size_t)pp * F] = silu ? eq_silu(v) : v;
+                const float v = acc[r] * sc, w = silu ? eq_silu(v) : v;
+                if (pp < G) { gr[(size_t)pp * F] = w; omx = fmaxf(omx, fabsf(w)); }
             }
+        }
+        if (node_mag) {  // float bits of a non-negative value order like unsigned integers
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) omx = fmaxf(omx, __shfl_xor(omx, o));
+            if (lane == 0) atomicMax(node_mag + (n - n0), __float_as_uint(omx));
         }
     }
 }
@@ -1233,14 +1240,18 @@ int32_t eq_launch_fold(const float* A, const float* B, int O, int K, int I, floa
     return ADF_OK;
 }
 
-int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, bool silu, hipStream_t s) {
+int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, float* g, bool silu, hipStream_t s, float* node_mag,
+                          bool* emitted) {
+    if (emitted) *emitted = false;
     if (n1 <= n0) return ADF_OK;
     if (!h->exact_f32 && h->gtab_to && h->d.S <= 64 && h->d.F % 32 == 0) {
         const size_t dyn = (size_t)h->g_npb * 4 * 2 * 64 * 16;
         ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_to_grid_mfma_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        if (node_mag) ADF_HIP_CHECK(hipMemsetAsync(node_mag, 0, sizeof(float) * (size_t)(n1 - n0), s));
         hipLaunchKernelGGL(eq_to_grid_mfma_kernel, dim3(h->num_cus), dim3(512), dyn, s, h1, (const eqhalf8*)h->gtab_to, h->g_npb,
-                           h->g_inv_sT, n0, n1, h->d.S, h->d.F, h->d.G, silu ? 1 : 0, g);
+                           h->g_inv_sT, n0, n1, h->d.S, h->d.F, h->d.G, silu ? 1 : 0, g, reinterpret_cast<unsigned int*>(node_mag));
+        if (emitted) *emitted = node_mag != nullptr;
         ADF_HIP_CHECK(hipGetLastError());
         return ADF_OK;
     }
