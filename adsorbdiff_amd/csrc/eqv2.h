@@ -75,6 +75,7 @@ struct adf_eqv2 {
     eq_dims* d_dev;   // device copy (kernels that index its tables per lane)
     int device, num_cus;
     bool weights_set, consts_set, exact_f32, s2_emit_mag, presplit;
+    bool no_compact;           // ADF_EQV2_COMPACT=0: force blocks evaluate every column of their second convolution
     bool fold_on, folded;      // grid-MLP end maps folded into the SO(3) linears (eq_ffn); ADF_EQV2_FOLD=0 switches it off
     float* fold_arena; size_t fold_floats;
     // constants (device)
@@ -150,7 +151,7 @@ int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, in
 int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, int ldy, int n0, int n1, float* alpha,
                         hipStream_t s);
 int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* alpha, int n0, int n1, float* agg,
-                             bool only_l1, hipStream_t s);
+                             bool only_l1, hipStream_t s, bool compact = false);
 // silu: apply SiLU to the grid values (the folded feed-forward network, eq_ffn)
 // node_mag != null: the matrix-core kernel also leaves max |g| of every node's tile in node_mag[n - n0] (zeroed here) and
 // sets *emitted; the VALU kernel does not

@@ -123,6 +123,7 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     { const char* e2 = getenv("ADF_EQV2_S2_EMIT"); h->s2_emit_mag = e2 && atoi(e2) != 0; }
     { const char* e3 = getenv("ADF_EQV2_PRESPLIT"); h->presplit = !(e3 && atoi(e3) == 0); }
     { const char* e4 = getenv("ADF_EQV2_FOLD"); h->fold_on = !(e4 && atoi(e4) == 0); }
+    { const char* e5 = getenv("ADF_EQV2_COMPACT"); h->no_compact = e5 && atoi(e5) == 0; }
     h->prof_ev = new std::vector<hipEvent_t>();
     h->prof_cat = new std::vector<int>();
     int32_t st = eq_alloc(&h->flags, EQ_NFLAGS);
@@ -612,6 +613,20 @@ extern "C" int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, cons
 }
 
 // ---------------------------------------------------------------------------------------------- dense product dispatch
+// rows [row0, row0 + n) of a weight matrix as a map of their own (the fp16 images are plain [out, in] arrays with one
+// power-of-two scale per matrix, so a block of rows is a pointer offset)
+static eq_lin eq_lin_rows(const eq_lin& p, int row0, int n) {
+    eq_lin r = p;
+    r.w = p.w + (size_t)row0 * p.in;
+    r.b = p.b ? p.b + row0 : nullptr;
+    r.out = n;
+    if (p.has16) {
+        r.w16.hi = static_cast<unsigned char*>(p.w16.hi) + (size_t)row0 * p.in * 2;
+        r.w16.lo = static_cast<unsigned char*>(p.w16.lo) + (size_t)row0 * p.in * 2;
+    }
+    return r;
+}
+
 int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* amap, const eq_lin* W, bool use_bias,
                 float* Cm, int ldc, const eq_rowmap* cmap, long long M, int act, bool accumulate, hipStream_t s,
                 const float* rs_pre, float* out_mag, int rs_div) {
@@ -721,7 +736,20 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
         { eq_prof_scope ps(h, EQ_PROF_ATTN, s); ADF_TRY(eq_launch_alpha(h, at, b.y[0], at->c1_m0.out, n0, n1, b.alpha, s)); }
         bool rs_ok = false;
         { eq_prof_scope ps(h, EQ_PROF_S2ACT, s); ADF_TRY(eq_launch_s2act(h, b.y[0], b.y, extra, d.NH * d.A, n0, n1, b.mb, h->s2_emit_mag ? b.rsb : nullptr, &rs_ok, s)); }
-        {
+        // a force block reads only the l = 1 rows of the rotated-back message: its second convolution keeps only the
+        // output columns that reach them (order 0: l = 1; order 1: real and imaginary part of l = 1; order 2: none)
+        const bool compact = only_l1 && d.M >= 1 && d.L >= 1 && !h->no_compact;
+        if (compact) {
+            eq_prof_scope ps(h, EQ_PROF_CONV, s);
+            const eq_lin w0 = eq_lin_rows(at->c2_m0, d.HV, d.HV);
+            const eq_lin wr = eq_lin_rows(at->c2_m[0], 0, d.HV), wi = eq_lin_rows(at->c2_m[0], d.L * d.HV, d.HV);
+            ADF_TRY(eq_gemm(h, b.mb[0], w0.in, nullptr, &w0, true, b.z[0], d.HV, nullptr, Eub, 0, false, s, rs_ok ? b.rsb[0] : nullptr));
+            const float* rs1 = rs_ok ? b.rsb[1] : nullptr;
+            const bool mf = eq_uses_mfma(h, b.mb[1], wr.in, &wr, b.z[1], 2 * d.HV) && 2 * Eub <= h->rs_cap;
+            if (!rs1 && mf) { const eq_rowmap am1 = {wr.in, 1, 0}; ADF_TRY(eq_launch_rowscale(b.mb[1], &am1, 2 * Eub, wr.in, h->rs, s)); rs1 = h->rs; }
+            ADF_TRY(eq_gemm(h, b.mb[1], wr.in, nullptr, &wr, false, b.z[1], 2 * d.HV, nullptr, 2 * Eub, 0, false, s, rs1));
+            ADF_TRY(eq_gemm(h, b.mb[1], wi.in, nullptr, &wi, false, b.z[1] + d.HV, 2 * d.HV, nullptr, 2 * Eub, 0, false, s, rs1));
+        } else {
             eq_prof_scope ps(h, EQ_PROF_CONV, s);
             ADF_TRY(eq_gemm(h, b.mb[0], at->c2_m0.in, nullptr, &at->c2_m0, true, b.z[0], at->c2_m0.out, nullptr, Eub, 0, false, s,
                             rs_ok ? b.rsb[0] : nullptr));
@@ -729,7 +757,7 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
                 ADF_TRY(eq_gemm(h, b.mb[m], at->c2_m[m - 1].in, nullptr, &at->c2_m[m - 1], false, b.z[m], at->c2_m[m - 1].out,
                                 nullptr, 2 * Eub, 0, false, s, rs_ok ? b.rsb[m] : nullptr));
         }
-        { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_out(h, b.z, b.alpha, n0, n1, agg, only_l1, s)); }
+        { eq_prof_scope ps(h, EQ_PROF_ROTATE, s); ADF_TRY(eq_launch_rotate_out(h, b.z, b.alpha, n0, n1, agg, only_l1, s, compact)); }
     }
     return ADF_OK;
 }

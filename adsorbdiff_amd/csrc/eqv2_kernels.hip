@@ -934,7 +934,8 @@ int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, i
 template <int LT, bool ONLY1>
 __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, const float* __restrict__ alpha,
                                      const float* __restrict__ wig, const int32_t* __restrict__ eptr, int n0, int n1,
-                                     eq_dims d, float* __restrict__ agg) {
+                                     eq_dims d, int compact, float* __restrict__ agg) {
+    // compact (ONLY1): the convolution wrote only the l = 1 columns - z0 [E, HV], z1 [2E, 2 HV] (real | imaginary part)
     const int n = n0 + blockIdx.x, c = threadIdx.x;
     if (n >= n1 || c >= d.HV) return;
     const long long ebase = eptr[n0];
@@ -943,7 +944,7 @@ __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, c
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = 0.f;
     const int hd = c / d.V;
-    const int ld0 = (d.L + 1) * d.HV;
+    const int ld0 = compact ? d.HV : (d.L + 1) * d.HV;
     for (long long e = eptr[n]; e < eptr[n + 1]; ++e) {
         const long long el = e - ebase;
         const float a = alpha[(size_t)el * d.NH + hd];
@@ -957,9 +958,9 @@ __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, c
                 const int mp = ri - ml, am = mp < 0 ? -mp : mp;
                 float v;
                 if (am == 0) {
-                    v = z0[(size_t)el * ld0 + l * d.HV + c];
+                    v = z0[(size_t)el * ld0 + (compact ? 0 : l * d.HV) + c];
                 } else {
-                    const int nm = d.L - am + 1, half = nm * d.HV, W = 2 * half, q = (l - am) * d.HV + c;
+                    const int nm = compact ? 1 : d.L - am + 1, half = nm * d.HV, W = 2 * half, q = (compact ? 0 : (l - am) * d.HV) + c;
                     const float* zr = zm.p[am] + (size_t)(2 * el) * W;
                     v = mp > 0 ? zr[q] - zr[W + half + q] : zr[W + q] + zr[half + q];
                 }
@@ -975,7 +976,8 @@ __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, c
 }
 
 int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* alpha, int n0, int n1, float* agg,
-                             bool only_l1, hipStream_t s) {
+                             bool only_l1, hipStream_t s, bool compact) {
+    if (compact && !only_l1) { adf_set_error("internal: compact rotate-out is for the l = 1 mode"); return ADF_EINVAL; }
     if (n1 <= n0) return ADF_OK;
     eq_ptrs zm;
     for (int m = 0; m <= h->d.M; ++m) zm.p[m] = z[m];
@@ -983,10 +985,10 @@ int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* al
 #define EQ_RO(LT_)                                                                                                     \
     if (only_l1)                                                                                                       \
         hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, true>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
-                           h->eptr, n0, n1, h->d, agg);                                                                \
+                           h->eptr, n0, n1, h->d, compact ? 1 : 0, agg);                                               \
     else                                                                                                               \
         hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, false>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
-                           h->eptr, n0, n1, h->d, agg)
+                           h->eptr, n0, n1, h->d, 0, agg)
     EQ_FOR_L(h->d.L, EQ_RO)
 #undef EQ_RO
     ADF_HIP_CHECK(hipGetLastError());
