@@ -681,11 +681,15 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
     __syncthreads();
     const eqhalf8* TA = tab;
     const eqhalf8* FA = tab + ntab;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: the item's addresses stay scalar
     const int cl = lane & 31, kh = lane >> 5;
     const long long ebase = eptr[n0];
     const long long Ec = eptr[n1] - ebase;
     // one wave per (edge, block of 32 hidden channels)
+    // (Measured alternative: writing the outputs as the second convolution's pre-split operand rows - fp16 hi / lo lifted per
+    // row, the two waves of an edge exchanging their row maxima through LDS - made that product 8 ms per forward faster at
+    // 256 k edges and this kernel 9 ms slower: 600 more VALU instructions per item in a VALU-bound kernel.  Not kept.)
     const int nblk = Hd >> 5;
     for (long long item = (long long)blockIdx.x * 16 + wave; item < Ec * nblk; item += (long long)gridDim.x * 16) {
         const long long el = item / nblk;

@@ -243,9 +243,10 @@ class PaiNNEngine:
         static-atom promise and recompute only rows whose inputs changed.  Bit-identical outputs; default on."""
         _lib.check(self.lib.adf_painn_set_incremental(self.handle, 1 if on else 0))
 
-    def build_graph(self, data):
-        """Graph only; returns the number of symmetrised edges."""
-        prep = self.prepare(data)
+    def build_graph(self, data, prep=None):
+        """Graph only; returns the number of symmetrised edges.  ``prep``: an already prepared batch of ``data``."""
+        if prep is None:
+            prep = self.prepare(data)
         pos = data.pos.to(torch.float32).contiguous()
         desc = prep.desc(pos)
         n = C.c_int64(0)

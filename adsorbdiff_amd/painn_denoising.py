@@ -262,8 +262,14 @@ class PaiNN(nn.Module):
             out.append(float(sf.scale_factor) if sf.fitted else 1.0)
         return out
 
-    def engine(self, device=None):
-        """The device-side engine (C-ABI handle + workspaces) bound to this module's weights."""
+    def engine(self, device=None, refresh=True):
+        """The device-side engine (C-ABI handle + workspaces) bound to this module's weights.
+
+        ``refresh=False`` (the training step, every optimizer step): return the existing engine without fingerprinting
+        86 MB of weights and re-packing the sampling images - the training operators read the parameters through the
+        pointers they are handed, the handle only serves the graph, the embedding table (bound by pointer to the
+        parameter's own storage, updated in place by the optimizer) and the radial-basis constants.  The packed images
+        are marked stale, so the next refreshing call (a sampling forward) re-binds them."""
         from .engine import PaiNNEngine
 
         if device is None:
@@ -274,6 +280,9 @@ class PaiNN(nn.Module):
         if self._engine is not None and self._engine.device != device:
             self._engine.close()
             self._engine = None
+        if not refresh and self._engine is not None:
+            self._engine_key = None
+            return self._engine
         version = self._weights_version(device)
         if self._engine is None:
             self._engine = PaiNNEngine(self, device)

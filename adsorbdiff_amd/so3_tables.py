@@ -9,6 +9,8 @@ Pinned against the reference's own tables by tests/golden/igso3_tables.npz (orac
 """
 from __future__ import annotations
 
+import os
+import zipfile
 from pathlib import Path
 from typing import Optional
 
@@ -66,15 +68,37 @@ class Igso3Tables:
     def shared(cls) -> "Igso3Tables":
         """The full tables: loaded from the cache file, computed (and cached) on first use."""
         if cls._shared is None:
-            if _CACHE.exists():
-                z = np.load(_CACHE)
-                cls._shared = cls(z["omegas"], z["cdf"], z["score"], z["exp_score_norm"])
-            else:
+            t = cls._load_cache()
+            if t is None:
                 t = compute_tables()
-                _CACHE.parent.mkdir(exist_ok=True)
-                np.savez(_CACHE, omegas=t["omegas"], cdf=t["cdf"], score=t["score"], exp_score_norm=t["exp_score_norm"])
-                cls._shared = cls(t["omegas"], t["cdf"], t["score"], t["exp_score_norm"])
+                cls._store_cache(t)
+            cls._shared = cls(t["omegas"], t["cdf"], t["score"], t["exp_score_norm"])
         return cls._shared
+
+    @staticmethod
+    def _load_cache():
+        """The cached tables, or None when the file is missing, unreadable (another rank is still writing an older,
+        non-atomic version of it) or of another shape."""
+        try:
+            with np.load(_CACHE) as z:
+                t = {k: z[k] for k in ("omegas", "cdf", "score", "exp_score_norm")}
+        except (OSError, ValueError, KeyError, EOFError, zipfile.BadZipFile):
+            return None
+        ok = t["omegas"].shape == (X_N,) and t["cdf"].shape == (N_EPS, X_N) and t["score"].shape == (N_EPS, X_N) and \
+            t["exp_score_norm"].shape == (N_EPS,)
+        return t if ok else None
+
+    @staticmethod
+    def _store_cache(t) -> None:
+        """Several ranks may get here at once: each writes its own temporary file and renames it into place (atomic; the
+        contents are identical).  A read-only install just skips the cache."""
+        try:
+            _CACHE.parent.mkdir(exist_ok=True)
+            tmp = _CACHE.with_name(f"{_CACHE.stem}.{os.getpid()}.tmp.npz")
+            np.savez(tmp, omegas=t["omegas"], cdf=t["cdf"], score=t["score"], exp_score_norm=t["exp_score_norm"])
+            os.replace(tmp, _CACHE)
+        except OSError:
+            pass
 
     @staticmethod
     def eps_index(eps):

@@ -84,13 +84,20 @@ class PaiNNTrainStep:
     def _params(self) -> Dict[str, torch.nn.Parameter]:
         return dict(self.model.named_parameters())
 
+    # parameters the score path never reads: the reference's autograd leaves their .grad at None (DDP runs with
+    # find_unused_parameters, base_trainer.py:442-447) and torch.optim.AdamW then skips them - no weight decay either
+    UNUSED_PREFIXES = ("out_energy.",)
+
     def zero_grad(self) -> None:
-        for p in self.model.parameters():
-            if p.requires_grad:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-                else:
-                    p.grad.zero_()
+        for name, p in self.model.named_parameters():
+            if not p.requires_grad:
+                continue
+            if name.startswith(self.UNUSED_PREFIXES):
+                p.grad = None
+            elif p.grad is None:
+                p.grad = torch.zeros_like(p)
+            else:
+                p.grad.zero_()
 
     # ------------------------------------------------------------------ the step
     def loss_and_grad(self, batch, targets: dict) -> torch.Tensor:
@@ -101,15 +108,15 @@ class PaiNNTrainStep:
         m, ops, lib = self.model, self.ops, self.lib
         P = self._params()
         H, L, R = m.hidden_channels, m.num_layers, m.num_rbf
-        eng = m.engine(self.dev)
+        eng = m.engine(self.dev, refresh=False)
         h = eng.handle
-        E = eng.build_graph(batch)
         prep = eng.prepare(batch)
+        E = eng.build_graph(batch, prep)
         N, B = prep.num_atoms, prep.num_systems
         if prep.tags is None:
             raise ValueError("batch.tags is required (tag 2 marks the adsorbate)")
         s = ops.s
-        G = {k: p.grad for k, p in P.items() if p.requires_grad}
+        G = {k: p.grad for k, p in P.items() if p.requires_grad and not k.startswith(self.UNUSED_PREFIXES)}
         for k, g in G.items():
             if g is None:
                 raise RuntimeError("call zero_grad() before loss_and_grad()")

@@ -105,13 +105,14 @@ def safe_batch(n_sys, n_slab, seed):
 
 
 @pytest.mark.parametrize("exact", [False, True])
-@pytest.mark.parametrize("lmax", [4, 6])
-def test_eqv2_matrix_core_path_vs_oracle(lmax, exact):
+@pytest.mark.parametrize("lmax,hidden", [(4, 32), (6, 32), (6, 64)])
+def test_eqv2_matrix_core_path_vs_oracle(lmax, hidden, exact):
     """Shapes the f16x3 matrix-core products take (every K a multiple of 32), against the CPU oracle on the oracle's
-    own edge list; also the exact-f32 arithmetic on the same shapes.  1e-4 on the outputs and on every block."""
+    own edge list; also the exact-f32 arithmetic on the same shapes.  1e-4 on the outputs and on every block.  64 hidden
+    channels (the benchmark's value) = two channel blocks, i.e. two waves of the S2 activation, per edge."""
     from oracle import eqv2_oracle as Q
 
-    m = make_model(lmax, 2, C=32, hidden=32, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=2, cutoff=12.0)
+    m = make_model(lmax, 2, C=32, hidden=hidden, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=2, cutoff=12.0)
     b = safe_batch(2, 36, seed=7)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     ei, sh, nb = Q.radius_graph_pbc(b.pos, b.cell, b.natoms, 12.0, 20)
@@ -124,7 +125,7 @@ def test_eqv2_matrix_core_path_vs_oracle(lmax, exact):
     eng.set_edges(ei, v)
     f1, f2 = m(b.to(DEV))
     e1, e2 = rel_err(f1.cpu(), r1), rel_err(f2.cpu(), r2)
-    print(f"L={lmax} exact={exact}: rel err {e1:.2e} {e2:.2e}")
+    print(f"L={lmax} hidden={hidden} exact={exact}: rel err {e1:.2e} {e2:.2e}")
     assert e1 < REL_TOL and e2 < REL_TOL
     for got, ref in ((f1.cpu(), r1), (f2.cpu(), r2)):
         assert float((got - ref).abs().max()) < REL_TOL * float(ref.norm(dim=1).max())

@@ -44,11 +44,11 @@ def test_loss_and_gradients_vs_reference_autograd():
         p = P[name]
         if not p.requires_grad:
             continue
+        if gn == 0.0:  # out_energy.*: no path to the loss; .grad stays None as under the reference's autograd
+            assert p.grad is None or float(p.grad.norm()) == 0.0, name
+            continue
         got = float(p.grad.norm())
-        if gn == 0.0:
-            assert got == 0.0, name  # out_energy.*: no path to the loss (DDP find_unused_parameters in the reference)
-        else:
-            assert abs(got - gn) < 1e-4 * gn, (name, got, gn)
+        assert abs(got - gn) < 1e-4 * gn, (name, got, gn)
     for key in fx:
         if key.startswith("grad::"):
             name = key[6:]
@@ -122,11 +122,11 @@ def test_gradients_are_reproducible_and_accumulate():
     step = PaiNNTrainStep(m, DEV, igso3=tables)
     step.zero_grad()
     step.loss_and_grad(b, targets)
-    g1 = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
     step.zero_grad()
     step.loss_and_grad(b, targets)
     for k, p in m.named_parameters():
-        if p.requires_grad and k != "atom_emb.embeddings.weight":  # the embedding gradient uses float atomics
+        if k in g1 and k != "atom_emb.embeddings.weight":  # the embedding gradient uses float atomics
             assert torch.equal(p.grad, g1[k]), k
     step.loss_and_grad(b, targets)  # no zero_grad: gradients add up
     k = "message_layers.1.rbf_proj.weight"
@@ -153,7 +153,7 @@ def test_fused_adamw_matches_torch_adamw_clip_ema():
         step.zero_grad()
         step.loss_and_grad(b, targets)
         for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
-            q.grad = p.grad.clone() if p.requires_grad else None
+            q.grad = p.grad.clone() if (p.requires_grad and p.grad is not None) else None
         gn_ref = torch.nn.utils.clip_grad_norm_([q for q in ref.parameters() if q.grad is not None], max_norm=0.05)
         topt.step()
         ema_ref.update()
@@ -191,7 +191,7 @@ for k in ("tr_sigma", "rot_sigma", "tr_score", "rot_score"):
     setattr(mine, k, torch.from_numpy(fx[k])[2 * rank : 2 * rank + 2])
 out = tr.train_step(mine, noised=True)                              # lr = 0: only the averaged gradients matter
 if rank == 0:
-    torch.save({k: p.grad.cpu() for k, p in m.named_parameters() if p.requires_grad}, sys.argv[2])
+    torch.save({k: p.grad.cpu() for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}, sys.argv[2])
 dist.barrier()
 dist.destroy_process_group()
 """
