@@ -449,6 +449,10 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
                                     const int32_t* __restrict__ Z, int pair_ne) {
     // (Measured alternative: one workgroup per TARGET looping over its edges with the target's own features loaded once —
     // slower, 63 -> 82 ms per forward at 256 k edges: fewer, longer workgroups with two barriers per edge.)
+    // (Also measured, no change either way: two adjacent channels per thread - 8-byte gathers, 4-byte fp16 stores, half the
+    // memory instructions - 63.0 vs 63.6 ms; runs of 256...4096 consecutive edges per XCD for L2 locality of the gathered
+    // features - 59.3...60.8 vs 59.8 ms.  PMC: memory unit stalled 42 % of the time, VALU busy 46 %, 3.9 TB/s: the kernel
+    // waits on its chain of dependent loads (edge -> node index -> feature rows) at 4 workgroups per CU.)
     // PRESPLIT: the operand rows are written as fp16 hi / lo images lifted by the row's own power of two (what
     // eq_gemm16p_kernel stages by plain copies): mb.p[m] holds [rows][nm 2C] halves of hi followed by the same of lo
     __shared__ unsigned int smax[2 * EQ_MAX_M + 1];  // |.| maxima of the edge's operand rows (bit patterns order like floats)
