@@ -102,6 +102,9 @@ struct adf_eqv2 {
     bool ext_graph;   // edges were supplied by adf_eqv2_set_edges
     int64_t E_ext; int maxdeg;
     int32_t *xe_src, *xe_dst; float* xe_vec; int64_t xe_cap;   // the caller's edge list (private copy)
+    // incoming edges of a listed subset of targets, compacted (the force blocks of adf_eqv2_forward_subset)
+    int32_t *sub_eptr, *sub_src, *sub_dst; float *sub_vec, *sub_wig, *sub_f; int64_t sub_cap;
+    int64_t last_subset;       // n_out of the last forward, -1 = all atoms
     int64_t arena_kk;   // edges per target the chunk arena was sized for
     // node buffers
     float *x, *y, *agg, *gate, *h1, *h2;
@@ -160,6 +163,9 @@ int32_t eq_launch_to_grid(const adf_eqv2* h, const float* h1, int n0, int n1, fl
 int32_t eq_launch_fold(const float* A, const float* B, int O, int K, int I, float* out, hipStream_t s);
 int32_t eq_launch_from_grid(const adf_eqv2* h, const float* g, const float* gate, int n0, int n1, float* h2, hipStream_t s);
 int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* agg3, int N, float* f, hipStream_t s);
+// CSR + edge arrays of the listed targets only (sub_* of the handle); then rows of f_sub scattered to rows out_idx of f
+int32_t eq_launch_subset_graph(adf_eqv2* h, const int32_t* out_idx, int n_out, hipStream_t s);
+int32_t eq_launch_scatter_rows3(const float* f_sub, const int32_t* out_idx, int n_out, float* f, hipStream_t s);
 int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float* W, const float* bias, float* Cm, int ldc,
                     const eq_rowmap* cmap, long long M, int N, int K, int act, bool accumulate, hipStream_t s);
 int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);

@@ -138,6 +138,8 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
 static void eq_free_workspaces(adf_eqv2* h) {
     eq_free(h->nbr_cnt); eq_free(h->nbr_src); eq_free(h->nbr_shift); eq_free(h->img_cnt); eq_free(h->eptr);
     eq_free(h->e_src); eq_free(h->e_dst); eq_free(h->e_vec); eq_free(h->wig);
+    eq_free(h->sub_eptr); eq_free(h->sub_src); eq_free(h->sub_dst); eq_free(h->sub_vec); eq_free(h->sub_wig); eq_free(h->sub_f);
+    h->sub_cap = 0;
     if (h->scan_tmp) { (void)hipFree(h->scan_tmp); h->scan_tmp = nullptr; }
     eq_free(h->cache_d2); eq_free(h->cache_cid); eq_free(h->cache_cnt);
     eq_free(h->x); eq_free(h->y); eq_free(h->agg); eq_free(h->gate); eq_free(h->h1); eq_free(h->h2);
@@ -395,7 +397,12 @@ static int32_t eq_radial_static(adf_eqv2* h, eq_radial** rads, int nrad, hipStre
     }
     float *t1 = nullptr, *t2 = nullptr, *rs = nullptr;
     const long long rows = (long long)NE * NE;
-    ADF_TRY(eq_alloc(&t1, (size_t)rows * d.EC)); ADF_TRY(eq_alloc(&t2, (size_t)rows * d.EC)); ADF_TRY(eq_alloc(&rs, (size_t)rows));
+    if (eq_alloc(&t1, (size_t)rows * d.EC) != ADF_OK || eq_alloc(&t2, (size_t)rows * d.EC) != ADF_OK ||
+        eq_alloc(&rs, (size_t)rows) != ADF_OK) {  // no room for the scratch rows: per-edge mode
+        eq_free(t1); eq_free(t2); eq_free(rs);
+        (void)hipGetLastError();
+        return ADF_OK;
+    }
     float* keep_rs = h->rs; const int64_t keep_cap = h->rs_cap;
     h->rs = rs; h->rs_cap = rows;
     float* p = h->rtab_arena;
@@ -785,7 +792,27 @@ static int32_t eq_check_batch(const adf_eqv2* h, const adf_batch* b) {
     return ADF_OK;
 }
 
-static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float* f2, float* x_blocks, hipStream_t s) {
+// compact edge arrays for n_out listed targets (at most kk incoming edges each)
+static int32_t eq_ensure_subset(adf_eqv2* h, int64_t n_out) {
+    if (n_out <= h->sub_cap) return ADF_OK;
+    ADF_HIP_CHECK(hipDeviceSynchronize());
+    eq_free(h->sub_eptr); eq_free(h->sub_src); eq_free(h->sub_dst); eq_free(h->sub_vec); eq_free(h->sub_wig); eq_free(h->sub_f);
+    h->sub_cap = 0;
+    const int64_t cap = n_out + n_out / 4 + 64;
+    const int64_t kk = h->arena_kk > 0 ? h->arena_kk : h->hp.max_neighbors;
+    ADF_TRY(eq_alloc(&h->sub_eptr, (size_t)2 * (cap + 2)));  // CSR, then the counts it is scanned from
+    ADF_TRY(eq_alloc(&h->sub_src, (size_t)cap * kk)); ADF_TRY(eq_alloc(&h->sub_dst, (size_t)cap * kk));
+    ADF_TRY(eq_alloc(&h->sub_vec, (size_t)cap * kk * 3)); ADF_TRY(eq_alloc(&h->sub_wig, (size_t)cap * kk * h->d.DR));
+    ADF_TRY(eq_alloc(&h->sub_f, (size_t)cap * 3));
+    h->sub_cap = cap;
+    return ADF_OK;
+}
+
+// out_idx != null: the two force blocks (all that reads the last embedding) run for the listed target atoms only, on a
+// compacted copy of their incoming edges; rows out_idx[*] of f1 / f2 are written, bit-identical to the full forward's
+// (every row of every product, the softmax of a target and its aggregation depend on that target's edges alone).
+static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float* f2, float* x_blocks, hipStream_t s,
+                               const int32_t* out_idx = nullptr, int32_t n_out = 0) {
     const eq_dims& d = h->d;
     const int N = b->num_atoms, B = b->num_systems;
     ADF_TRY(eq_ensure_capacity(h, N, B, h->ext_graph ? h->E_ext : 0));
@@ -864,6 +891,28 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
         if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks + (size_t)(i + 1) * xs, h->x, xs * 4, hipMemcpyDeviceToDevice, s));
     }
     { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &h->final_norm, h->x, h->y, N, s)); }
+    h->last_subset = out_idx ? n_out : -1;
+    if (out_idx) {
+        if (n_out <= 0) return ADF_OK;
+        if (n_out > N) { adf_set_error("eqv2_forward_subset: more indices than atoms"); return ADF_EINVAL; }
+        ADF_TRY(eq_ensure_subset(h, n_out));
+        { eq_prof_scope ps(h, EQ_PROF_GRAPH, s); ADF_TRY(eq_launch_subset_graph(h, out_idx, n_out, s)); }
+        // the attention kernels read the graph through the handle: point it at the compact arrays for the force blocks
+        int32_t *k_eptr = h->eptr, *k_src = h->e_src, *k_dst = h->e_dst;
+        float *k_vec = h->e_vec, *k_wig = h->wig;
+        h->eptr = h->sub_eptr; h->e_src = h->sub_src; h->e_dst = h->sub_dst; h->e_vec = h->sub_vec; h->wig = h->sub_wig;
+        int32_t st = ADF_OK;
+        for (int k = 0; k < 2 && st == ADF_OK; ++k) {
+            float* f = k == 0 ? f1 : f2;
+            if (!f) continue;
+            st = eq_attention(h, &h->force[k], h->y, Z, n_out, h->agg, true, s);
+            eq_prof_scope ps(h, EQ_PROF_NODE, s);
+            if (st == ADF_OK) st = eq_launch_force_out(h, &h->force[k], h->agg, n_out, h->sub_f, s);
+            if (st == ADF_OK) st = eq_launch_scatter_rows3(h->sub_f, out_idx, n_out, f, s);
+        }
+        h->eptr = k_eptr; h->e_src = k_src; h->e_dst = k_dst; h->e_vec = k_vec; h->wig = k_wig;
+        return st;
+    }
     for (int k = 0; k < 2; ++k) {
         float* f = k == 0 ? f1 : f2;
         if (!f) continue;
@@ -880,6 +929,13 @@ extern "C" int32_t adf_eqv2_forward(adf_eqv2_t h, const adf_batch* b, float* f1,
     return eq_forward_impl(h, b, f1, f2, x_blocks, (hipStream_t)stream);
 }
 
+extern "C" int32_t adf_eqv2_forward_subset(adf_eqv2_t h, const adf_batch* b, const int32_t* out_idx, int32_t n_out, float* f1,
+                                          float* f2, void* stream) {
+    ADF_TRY(eq_check_batch(h, b));
+    if (!f1 || !out_idx || n_out < 0) { adf_set_error("eqv2_forward_subset: null argument"); return ADF_EINVAL; }
+    return eq_forward_impl(h, b, f1, f2, nullptr, (hipStream_t)stream, out_idx, n_out);
+}
+
 extern "C" int32_t adf_eqv2_check_flags(adf_eqv2_t h, void* stream) {
     if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
@@ -893,6 +949,7 @@ extern "C" int32_t adf_eqv2_check_flags(adf_eqv2_t h, void* stream) {
     if (fl[2]) { adf_set_error("eqv2 graph: edge capacity exceeded"); return ADF_EOVERFLOW; }
     if (fl[3]) { adf_set_error("eqv2: more than 128 incoming edges on one atom"); return ADF_EOVERFLOW; }
     if (fl[4]) { adf_set_error("eqv2: atomic number outside the embedding / radius tables"); return ADF_EINVAL; }
+    if (fl[5]) { adf_set_error("eqv2_forward_subset: atom index outside the batch"); return ADF_EINVAL; }
     if (fl[1]) { adf_set_error("An image has no neighbors"); return ADF_ENONEIGHBOR; }
     return ADF_OK;
 }
@@ -921,14 +978,17 @@ extern "C" int32_t adf_eqv2_sde_step(adf_eqv2_t h, const adf_batch* b, float* po
 extern "C" int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                                    const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
                                    const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
-                                   float* f1, float* f2, void* stream) {
+                                   const int32_t* out_idx, int32_t n_out, float* f1, float* f2, void* stream) {
     ADF_TRY(eq_check_batch(h, b));
-    if (num_steps <= 0 || !f1 || !f2 || !state || !coefs_dev || !pos || !tags) { adf_set_error("eqv2_sample: bad argument"); return ADF_EINVAL; }
+    if (num_steps <= 0 || !f1 || !f2 || !state || !coefs_dev || !pos || !tags || (out_idx && n_out < 0)) {
+        adf_set_error("eqv2_sample: bad argument");
+        return ADF_EINVAL;
+    }
     if ((z_tr_all == nullptr) != (z_rot_all == nullptr)) { adf_set_error("eqv2_sample: need both noise tables or none"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const size_t zs = (size_t)b->num_systems * 3;
     for (int t = 0; t < num_steps; ++t) {
-        ADF_TRY(eq_forward_impl(h, b, f1, f2, nullptr, s));
+        ADF_TRY(eq_forward_impl(h, b, f1, f2, nullptr, s, out_idx, n_out));
         ADF_TRY(adf_eqv2_sde_step(h, b, pos, tags, fixed, f1, f2, nullptr, coefs_dev, num_steps,
                                   z_tr_all ? z_tr_all + t * zs : nullptr, z_rot_all ? z_rot_all + t * zs : nullptr,
                                   early_stop_count, state, nullptr, nullptr, stream));
@@ -1000,8 +1060,13 @@ extern "C" int32_t adf_eqv2_get_counters(adf_eqv2_t h, adf_eqv2_counters* out, v
     const int64_t blocks = h->hp.num_layers;
     const int64_t macs = E * per_edge_block * (blocks + 2) + N * per_node_block * blocks;
     out->num_edges = E; out->num_atoms = N;
-    out->dense_flops = 2 * macs;
-    out->conv_flops = 2 * E * (conv1 + conv2) * (blocks + 2);
+    out->dense_flops = 2 * macs;  // the reference's algorithm (f32-equivalent), whatever shortcuts this path takes
+    // what the SO(2)-convolution kernels of the last forward executed: the force blocks keep only the l = 1 columns of their
+    // second convolution and, in a subset forward, only the edges of the listed targets (estimated as E n_out / N)
+    const bool compact = d.M >= 1 && d.L >= 1 && !h->no_compact;
+    const int64_t conv2f = compact ? (int64_t)(d.L + 1) * d.Hd * d.HV + 2 * ((int64_t)d.L * d.Hd) * (2 * d.HV) : conv2;
+    const int64_t Ef = h->last_subset >= 0 ? E * h->last_subset / (N > 0 ? N : 1) : E;
+    out->conv_flops = 2 * (E * (conv1 + conv2) * blocks + Ef * (conv1 + conv2f) * 2);
     return ADF_OK;
 }
 

@@ -1026,6 +1026,61 @@ int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* a
     return ADF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ target subsets
+__global__ void eq_subset_count_kernel(const int32_t* __restrict__ eptr, const int32_t* __restrict__ out_idx, int n_out,
+                                       int N, int32_t* __restrict__ cnt, int32_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_out) return;
+    if (i == n_out) { cnt[i] = 0; return; }
+    const int n = out_idx[i];
+    if (n < 0 || n >= N) { cnt[i] = 0; atomicOr(&flags[5], 1); return; }
+    cnt[i] = eptr[n + 1] - eptr[n];
+}
+
+// one workgroup per listed target: its incoming edges (source, target, vector, Wigner rows) to the compact arrays
+__global__ void eq_subset_copy_kernel(const int32_t* __restrict__ eptr, const int32_t* __restrict__ out_idx, int N,
+                                      const int32_t* __restrict__ sub_eptr, const int32_t* __restrict__ e_src,
+                                      const int32_t* __restrict__ e_dst, const float* __restrict__ e_vec,
+                                      const float* __restrict__ wig, int DR, int32_t* __restrict__ s_src,
+                                      int32_t* __restrict__ s_dst, float* __restrict__ s_vec, float* __restrict__ s_wig) {
+    const int i = blockIdx.x, n = out_idx[i];
+    if (n < 0 || n >= N) return;
+    const long long e0 = eptr[n], o0 = sub_eptr[i];
+    const int cnt = eptr[n + 1] - eptr[n];
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+        s_src[o0 + t] = e_src[e0 + t];
+        s_dst[o0 + t] = e_dst[e0 + t];
+    }
+    for (int t = threadIdx.x; t < 3 * cnt; t += blockDim.x) s_vec[3 * o0 + t] = e_vec[3 * e0 + t];
+    for (long long t = threadIdx.x; t < (long long)cnt * DR; t += blockDim.x) s_wig[o0 * DR + t] = wig[e0 * DR + t];
+}
+
+int32_t eq_launch_subset_graph(adf_eqv2* h, const int32_t* out_idx, int n_out, hipStream_t s) {
+    if (n_out <= 0) return ADF_OK;
+    int32_t* cnt = h->sub_eptr + (h->sub_cap + 2);  // the counts the CSR is scanned from live behind it
+    hipLaunchKernelGGL(eq_subset_count_kernel, dim3((n_out + 256) / 256), dim3(256), 0, s, h->eptr, out_idx, n_out, (int)h->lastN,
+                       cnt, h->flags);
+    size_t tmp = h->scan_tmp_bytes;
+    ADF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(h->scan_tmp, tmp, cnt, h->sub_eptr, n_out + 1, s));
+    hipLaunchKernelGGL(eq_subset_copy_kernel, dim3(n_out), dim3(256), 0, s, h->eptr, out_idx, (int)h->lastN, h->sub_eptr, h->e_src,
+                       h->e_dst, h->e_vec, h->wig, h->d.DR, h->sub_src, h->sub_dst, h->sub_vec, h->sub_wig);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+__global__ void eq_scatter_rows3_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int n,
+                                        float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * n) dst[(size_t)idx[i / 3] * 3 + i % 3] = src[i];
+}
+
+int32_t eq_launch_scatter_rows3(const float* f_sub, const int32_t* out_idx, int n_out, float* f, hipStream_t s) {
+    if (n_out <= 0) return ADF_OK;
+    hipLaunchKernelGGL(eq_scatter_rows3_kernel, dim3((3 * n_out + 255) / 256), dim3(256), 0, s, f_sub, out_idx, n_out, f);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ S2 grid of the feed-forward
 // transformer_block.py:497-531: SO3 features -> res^2 grid points (to_full), point-wise MLP (dense products elsewhere),
 // grid -> SO3 (from_full), l = 0 replaced by the scalar gate.  One workgroup per node, thread = hidden channel.

@@ -157,8 +157,19 @@ class EqV2Engine:
     # ------------------------------------------------------------------ calls
     def forward_prepared(self, prep: PreparedBatch, pos: torch.Tensor, f1: torch.Tensor, f2: Optional[torch.Tensor],
                          out_idx=None, x_blocks: Optional[torch.Tensor] = None) -> None:
+        """Enqueue one forward; no host synchronisation.  ``out_idx`` (ascending int32 atom indices on the device): only
+        those rows of f1 / f2 are evaluated - bit-identical to the full forward's - and written
+        (``adf_eqv2_forward_subset``)."""
         desc = prep.desc(pos)
         with torch.cuda.device(self.device):
+            if out_idx is not None:
+                if x_blocks is not None:
+                    raise ValueError("x_blocks are recorded by the full forward only")
+                assert out_idx.dtype == torch.int32 and out_idx.is_contiguous() and out_idx.device == pos.device
+                _lib.check(self.lib.adf_eqv2_forward_subset(
+                    self.handle, C.byref(desc), out_idx.data_ptr(), int(out_idx.numel()), f1.data_ptr(),
+                    f2.data_ptr() if f2 is not None else None, self._stream()))
+                return
             _lib.check(self.lib.adf_eqv2_forward(
                 self.handle, C.byref(desc), f1.data_ptr(), f2.data_ptr() if f2 is not None else None,
                 x_blocks.data_ptr() if x_blocks is not None else None, self._stream()))
@@ -228,8 +239,8 @@ class EqV2Engine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.adf_eqv2_sample(
                 self.handle, C.byref(desc), pos.data_ptr(), prep.tags.data_ptr(), opt(prep.fixed), coefs_dev.data_ptr(),
-                num_steps, opt(z_tr_all), opt(z_rot_all), early_stop_count, poll_every, state.data_ptr(), f1.data_ptr(),
-                f2.data_ptr(), self._stream()))
+                num_steps, opt(z_tr_all), opt(z_rot_all), early_stop_count, poll_every, state.data_ptr(), opt(out_idx),
+                int(out_idx.numel()) if out_idx is not None else 0, f1.data_ptr(), f2.data_ptr(), self._stream()))
 
     def counters(self) -> _lib.EqV2Counters:
         c = _lib.EqV2Counters()

@@ -397,6 +397,12 @@ int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, const int32_t* 
  * force blocks (equiformer_v2_denoising.py:307-318).  x_blocks (optional, may be NULL): [num_layers + 1][N][S][C]
  * node embeddings after the edge-degree embedding and after every block (parity tests). */
 int32_t adf_eqv2_forward(adf_eqv2_t h, const adf_batch* b, float* f1, float* f2, float* x_blocks, void* stream);
+/* The sampler's forward (cf. adf_painn_forward_subset): only the force blocks read the last node embedding, and the
+ * update reads the adsorbate rows of f1 / f2 alone (denoising_torch.py:263-268, 460-467) - the force blocks run for the
+ * listed target atoms only (n_out ascending indices, device int32), on a compacted copy of their incoming edges.  Rows
+ * out_idx[*] of f1 / f2 are bit-identical to adf_eqv2_forward's; the other rows are NOT written. */
+int32_t adf_eqv2_forward_subset(adf_eqv2_t h, const adf_batch* b, const int32_t* out_idx, int32_t n_out, float* f1,
+                                float* f2, void* stream);
 int32_t adf_eqv2_check_flags(adf_eqv2_t h, void* stream);
 
 /* Reverse-diffusion stepper on an EquiformerV2 handle: same contracts as adf_sde_init_placement,
@@ -409,7 +415,8 @@ int32_t adf_eqv2_sde_step(adf_eqv2_t h, const adf_batch* b, float* pos, const in
                           int32_t* state, float* dcom, float* drot, void* stream);
 int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                         const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
-                        int32_t early_stop_count, int32_t poll_every, int32_t* state, float* f1, float* f2, void* stream);
+                        int32_t early_stop_count, int32_t poll_every, int32_t* state, const int32_t* out_idx, int32_t n_out,
+                        float* f1, float* f2, void* stream);
 
 /* Stand-alone torch.nn.functional.linear (+ optional SiLU, act = 2) through this path's dense-product kernels (unit tests
  * and micro-benchmarks of so2_ops.py:12-79,158-238 / so3.py:694-745 shapes).  A [M,K], W [N,K], bias [N] or NULL, C [M,N],
@@ -425,8 +432,9 @@ int32_t adf_eqv2_linear_forward(const float* A, const float* W, const float* bia
 #define ADF_EQV2_PROF_NCAT 9
 typedef struct {
     int64_t num_edges, num_atoms;
-    int64_t dense_flops;       /* 2 x multiply-adds of every dense product of one forward */
-    int64_t conv_flops;        /* the SO(2) convolution share of it                       */
+    int64_t dense_flops;       /* 2 x multiply-adds of every dense product of the REFERENCE's forward (f32-equivalent work) */
+    int64_t conv_flops;        /* 2 x multiply-adds the SO(2)-convolution kernels of the last forward executed (force blocks:
+                                * l = 1 columns only; subset forward: the listed targets' edges only, estimated) */
 } adf_eqv2_counters;
 int32_t adf_eqv2_get_counters(adf_eqv2_t h, adf_eqv2_counters* out, void* stream);
 int32_t adf_eqv2_profile_enable(adf_eqv2_t h, int32_t on);

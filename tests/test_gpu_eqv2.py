@@ -195,6 +195,68 @@ def test_eqv2_static_radial_tables_equal_per_edge_evaluation(monkeypatch):
     assert rel_err(f1.cpu(), g1.cpu()) < 2e-6 and rel_err(f2.cpu(), g2.cpu()) < 2e-6
 
 
+def test_eqv2_folded_feed_forward_and_compact_force_blocks_equal_the_plain_evaluation(monkeypatch):
+    """Two algebraic shortcuts of the default path: the grid MLP's first / last map folded into the SO(3) linears around
+    it (one product on the grid rows instead of three) and the force blocks' second convolution restricted to the columns
+    that reach l = 1.  ADF_EQV2_FOLD=0 / ADF_EQV2_COMPACT=0 evaluate everything as the reference does: same outputs and
+    same node embeddings after every block."""
+    m = make_model(6, 2, C=32, hidden=64, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=2, cutoff=12.0).to(DEV)
+    b = safe_batch(2, 36, seed=9).to(DEV)
+    f1, f2, xb = m.engine().forward(b, return_blocks=True)
+    monkeypatch.setenv("ADF_EQV2_FOLD", "0")
+    monkeypatch.setenv("ADF_EQV2_COMPACT", "0")
+    m._engine.close()
+    m._engine = None
+    g1, g2, yb = m.engine().forward(b, return_blocks=True)
+    assert rel_err(f1.cpu(), g1.cpu()) < 2e-6 and rel_err(f2.cpu(), g2.cpu()) < 2e-6
+    for k in range(xb.shape[0]):
+        assert rel_err(xb[k].cpu(), yb[k].cpu()) < 2e-6, k
+
+
+def test_eqv2_subset_forward_rows_are_bit_identical():
+    """adf_eqv2_forward_subset: the force blocks on the listed targets' incoming edges only (what the sampler needs: the
+    adsorbate rows).  Listed rows equal the full forward's bit for bit, the other rows are not written."""
+    m = make_model(6, 2, C=32, hidden=64, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=2, cutoff=12.0).to(DEV)
+    b = safe_batch(3, 36, seed=13).to(DEV)
+    eng = m.engine()
+    f1, f2 = eng.forward(b)
+    prep = eng.prepare(b)
+    idx = torch.nonzero(prep.tags == 2).reshape(-1).to(torch.int32).contiguous()
+    assert 0 < idx.numel() < prep.num_atoms
+    g1 = torch.full_like(f1, 7.0)
+    g2 = torch.full_like(f2, 7.0)
+    eng.forward_prepared(prep, b.pos.float().contiguous(), g1, g2, out_idx=idx)
+    eng.check_flags()
+    li = idx.long()
+    assert torch.equal(g1[li], f1[li]) and torch.equal(g2[li], f2[li])
+    rest = torch.ones(prep.num_atoms, dtype=torch.bool, device=DEV)
+    rest[li] = False
+    assert bool((g1[rest] == 7.0).all()) and bool((g2[rest] == 7.0).all())
+
+
+def test_eqv2_sampling_on_adsorbate_scores_only_gives_identical_sites():
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    m = make_model(4, 2, C=32, hidden=32, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=1, cutoff=12.0)
+    m.so3_denoising = True
+    m = m.to(DEV)
+    params = dict(num_steps=3, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+                  early_stop=False)
+    placement = torch.rand(2, 3, generator=torch.Generator().manual_seed(3))
+    outs = []
+    for ads_only in (False, True):
+        b = safe_batch(2, 36, seed=21)
+        trainer = DenoisingTrainer(m, device=DEV)
+        den = Denoiser(b.clone().to(DEV), DiffTorchCalc(trainer),
+                       dict(params, placement_noise=placement, scores_on_adsorbate_only=ads_only), device=DEV)
+        out = den.run()
+        assert den.steps_applied == 3
+        outs.append(out.pos.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - safe_batch(2, 36, seed=21).pos).abs().max()) > 0.1  # the adsorbates did move
+
+
 def test_eqv2_distance_basis_path_vs_oracle():
     """Radii small enough for the Gaussian distance basis to be non-zero (the table divided by 100: what the
     reference's discarded `/ 100` would have produced, equiformer_v2_denoising.py:168-169): the per-edge radial path
