@@ -120,6 +120,8 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
     {   // incremental layers: on unless ADF_INCREMENTAL=0 (adf_painn_set_incremental overrides)
         const char* e = getenv("ADF_INCREMENTAL");
         h->inc_on = !(e && e[0] == '0');
+        const char* e2 = getenv("ADF_INC_SYNC");
+        h->inc_sync = e2 && e2[0] == '1';
     }
     const int H = hp->hidden_channels, R = hp->num_rbf, L = hp->num_layers;
     int32_t st = dev_alloc(&h->rbf_pack, (size_t)L * (H / ADF_SLICE_CH) * R * 192);
@@ -197,6 +199,8 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->rec0) (void)hipFree(h->rec0);
     inc_free(h);
     if (h->inc_cnt_host) (void)hipHostFree(h->inc_cnt_host);
+    for (int i = 0; i < 2; ++i)
+        if (h->inc_ev[i]) (void)hipEventDestroy((hipEvent_t)h->inc_ev[i]);
     if (h->sub_x) (void)hipFree(h->sub_x);
     if (h->sub_vec) (void)hipFree(h->sub_vec);
     if (h->sub_f) (void)hipFree(h->sub_f);
@@ -475,7 +479,7 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
     if (emit < 0) { const char* e = getenv("ADF_LIFT_EMIT"); emit = (e && atoi(e) == 0) ? 0 : 1; }
     const bool em = lift && emit;
     // row magnitudes travel with the rows: LayerNorm -> x_proj.0 -> (its epilogue) -> x_proj.2
-    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s, em ? h->mag_a : nullptr));
+    ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s, em ? h->mag_a : nullptr, h->rows_dev));
     ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, n, H, H, 1, s, em ? h->mag_a : nullptr,
                        em ? h->mag_b : nullptr));
     if (h->gemm_f32) {
@@ -487,6 +491,7 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
         ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
         ep.row_map = row_map;
         ep.rmag = em ? h->mag_b : nullptr;
+        ep.m_dev = h->rows_dev;
         ADF_TRY(adf_launch_gemm16_fused(h->cat, H, &w.xp2_16, n, H, H, 1, &ep, s, lift ? &h->lift : nullptr));
     }
     adf_prof_end(h, s);
@@ -500,7 +505,8 @@ static int32_t message_layer(adf_painn* h, int l, int N, const float* x, const f
                              int n_targets = 0, float* rec = nullptr, bool records_ready = false) {
     if (!records_ready) ADF_TRY(make_records(h, l, N, x, vec, vec_is_zero, rec, nullptr, s));
     adf_prof_begin(h, ADF_PROF_MESSAGE, s);
-    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec);
+    const int32_t st = adf_message_impl(h, l, N, x, h->xh, vec, x_out, vec_out, vec_is_zero, s, tlist, n_targets, rec,
+                                        tlist ? h->rows_dev : nullptr);
     adf_prof_end(h, s);
     return st;
 }
@@ -516,12 +522,12 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
     } else {  // vec_proj with dot and |v2| formed on the accumulators (v1 -> vv [N,3,H], |v2| -> cat [N,H]);
               // xvec_proj.0 then reads its [x | |v2|] input from the two arrays
         adf_epi ep = {};
-        ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H;
+        ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H; ep.m_dev = h->rows_dev;
         const adf_lift* lf = h->lift_on ? &h->lift : nullptr;
         // vec rows and the [x | |v2|] rows are measured by a pass of their own; xvec_proj.0 hands its output rows' on
         ADF_TRY(adf_launch_gemm16_fused(vec, H, &w.vp_16, N, H, H, 3, &ep, s, lf));
         ADF_TRY(adf_launch_gemm16(x, H, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H, lf, nullptr,
-                                  h->lift_on ? h->mag_b : nullptr));
+                                  h->lift_on ? h->mag_b : nullptr, h->rows_dev));
     }
     int32_t st;
     if (h->gemm_f32) {
@@ -531,6 +537,7 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
         adf_epi ep = {};
         ep.x = x; ep.vec = vec; ep.dot = h->dot; ep.vv = h->vv; ep.scale = h->scale[l]; ep.H = H;
         ep.rmag = h->lift_on ? h->mag_b : nullptr;
+        ep.m_dev = h->rows_dev;
         st = adf_launch_gemm16_fused(h->y, H, &w.xv2_16, N, H, H, 2, &ep, s);
     }
     adf_prof_end(h, s);
@@ -610,8 +617,11 @@ static int inc_prepare(adf_painn* h, int N) {
             h->inc_tmp = tmp;
         }
         if (st == ADF_OK && !h->inc_cnt_host &&
-            hipHostMalloc(reinterpret_cast<void**>(&h->inc_cnt_host), sizeof(int32_t) * (2 * ADF_MAX_LAYERS + 1)) != hipSuccess)
+            hipHostMalloc(reinterpret_cast<void**>(&h->inc_cnt_host), sizeof(int32_t) * 2 * (2 * ADF_MAX_LAYERS + 1)) != hipSuccess)
             st = ADF_EOOM;
+        for (int i = 0; i < 2 && st == ADF_OK; ++i)
+            if (!h->inc_ev[i] && hipEventCreateWithFlags(reinterpret_cast<hipEvent_t*>(&h->inc_ev[i]), hipEventDisableTiming) != hipSuccess)
+                st = ADF_EHIP;
         if (st != ADF_OK) {
             (void)hipGetLastError();
             inc_free(h);
@@ -634,6 +644,37 @@ static int inc_prepare(adf_painn* h, int N) {
 __global__ void adf_scatter_rows3_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int n,
                                          float* __restrict__ dst);
 
+// Counts of an earlier forward that have reached the pinned buffer: remember them (they steer the next forwards' choice
+// between the list and the all-rows form of a layer) and book that forward's statistics.  wait: block until they are there.
+static int32_t inc_harvest(adf_painn* h, int slot, bool wait, bool peek = false) {
+    // peek: only read the counts (they steer THIS forward, ADF_INC_SYNC=1); the statistics are booked by a later call, once
+    // the forward has noted which form each layer took
+    if (!h->inc_ev_live[slot]) return ADF_OK;
+    hipEvent_t ev = (hipEvent_t)h->inc_ev[slot];
+    if (wait) {
+        ADF_HIP_CHECK(hipEventSynchronize(ev));
+    } else {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return ADF_OK; }
+        ADF_HIP_CHECK(q);
+    }
+    const int L = h->inc_layers, N = h->inc_pend_N[slot];
+    const int32_t* c = h->inc_cnt_host + (size_t)slot * (2 * ADF_MAX_LAYERS + 1);
+    for (int i = 0; i < 2 * L + 1; ++i) h->inc_seen[i] = c[i];
+    h->inc_seen_valid = true;
+    h->inc_pend_Nseen = N;
+    if (peek) return ADF_OK;
+    h->inc_ev_live[slot] = false;
+    for (int l = 0; l < L; ++l) {
+        const bool whole = h->inc_pend_whole[slot][l] != 0;
+        h->inc_rows += (unsigned long long)(whole ? N : c[l]);
+        h->inc_rows_full += (unsigned long long)N;
+        h->inc_edges += (unsigned long long)(whole ? c[2 * L] : c[L + l]);
+        if (whole || c[l] > 0) ++h->inc_launches;
+    }
+    return ADF_OK;
+}
+
 // One forward on the kept per-layer state.  The graph of this step is built; prev_* hold the previous build's CSR.
 static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const int32_t* out_idx, int32_t n_out,
                                    float* f1, float* f2, bool first, hipStream_t s) {
@@ -652,22 +693,30 @@ static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const 
     if (out_idx) ADF_TRY(adf_inc_need_from_list(h, N, L, out_idx, n_out, s));
     for (int l = 0; l < L; ++l) ADF_TRY(adf_inc_plan_layer(h, l, N, first, out_idx != nullptr, s));
     ADF_HIP_CHECK(hipMemcpyAsync(h->inc_cnt + 2 * L, h->nptr + N, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_cnt_host, h->inc_cnt, sizeof(int32_t) * (2 * L + 1), hipMemcpyDeviceToHost, s));
-    ADF_HIP_CHECK(hipStreamSynchronize(s));
+    // the counts go to the host behind an event; nobody waits for them (unless ADF_INC_SYNC=1)
+    const int slot = h->inc_slot;
+    h->inc_slot ^= 1;
+    if (h->inc_ev_live[slot]) ADF_TRY(inc_harvest(h, slot, true));  // two forwards behind: cannot happen on one stream, but be safe
+    int32_t* host = h->inc_cnt_host + (size_t)slot * (2 * ADF_MAX_LAYERS + 1);
+    ADF_HIP_CHECK(hipMemcpyAsync(host, h->inc_cnt, sizeof(int32_t) * (2 * L + 1), hipMemcpyDeviceToHost, s));
+    ADF_HIP_CHECK(hipEventRecord((hipEvent_t)h->inc_ev[slot], s));
+    h->inc_ev_live[slot] = true;
+    h->inc_pend_N[slot] = N;
+    ADF_TRY(inc_harvest(h, slot ^ 1, false));   // the previous forward's counts, if they have arrived
+    if (h->inc_sync) ADF_TRY(inc_harvest(h, slot, true, true));
     adf_prof_end(h, s);
     if (first) ADF_TRY(make_records(h, 0, N, h->incX[0], nullptr, true, h->incR[0], nullptr, s));
     for (int l = 0; l < L; ++l) {
-        const int n = h->inc_cnt_host[l];
-        const bool whole = n == N || (long long)n * 10 >= (long long)N * 9;
-        h->inc_rows += (unsigned long long)(whole ? N : n); h->inc_rows_full += (unsigned long long)N;
-        h->inc_edges += (unsigned long long)(whole ? h->inc_cnt_host[2 * L] : h->inc_cnt_host[L + l]);
-        if (n == 0) continue;
-        ++h->inc_launches;
-        const float* vin = l == 0 ? h->vecA : h->incV[l];  // layer 0: vec is zero, the pointer is not read
-        // (nearly) every row: straight into the next layer's tables.  Recomputing a row that was not listed is
+        // all rows (straight into the next layer's tables) or the listed rows.  Recomputing a row that was not listed is
         // harmless: a row without pending changes has unchanged inputs and gets the same value again; a pending but
-        // unwanted row keeps its flag and is recomputed before it is next read.  Above ~90 % the compaction costs
-        // more than the rows it saves.
+        // unwanted row keeps its flag and is recomputed before it is next read.  Above ~90 % the compaction costs more
+        // than the rows it saves.  The choice rests on the latest counts the host has seen (this forward's with
+        // ADF_INC_SYNC=1, else an earlier forward's: only the choice is late, never a result); none seen yet = all rows.
+        const int n_seen = h->inc_seen_valid ? h->inc_seen[l] : N;
+        const bool whole = first || !h->inc_seen_valid || h->inc_pend_Nseen != N || (long long)n_seen * 10 >= (long long)N * 9;
+        h->inc_pend_whole[slot][l] = whole ? 1 : 0;
+        if (h->inc_sync && !whole && n_seen == 0) continue;  // exact count: nothing to do
+        const float* vin = l == 0 ? h->vecA : h->incV[l];  // layer 0: vec is zero, the pointer is not read
         if (whole) {
             ADF_TRY(message_layer(h, l, N, h->incX[l], vin, h->incX[l + 1], h->incV[l + 1], l == 0, s, nullptr, 0,
                                   h->incR[l], true));
@@ -676,14 +725,21 @@ static int32_t forward_incremental(adf_painn* h, int N, const int32_t* Z, const 
                 ADF_TRY(make_records(h, l + 1, N, h->incX[l + 1], h->incV[l + 1], false, h->incR[l + 1], nullptr, s));
             continue;
         }
+        // listed rows: launches sized for `cap` rows, the kernels stop at the list length they read from inc_cnt[l]
         const int32_t* list = h->inc_list + cap * l;
-        ADF_TRY(message_layer(h, l, N, h->incX[l], vin, h->x, h->vecB, l == 0, s, list, n, h->incR[l], true));
-        ADF_TRY(update_layer(h, l, n, h->x, h->vecB, s));
-        adf_prof_begin(h, ADF_PROF_NODE, s);
-        ADF_TRY(adf_inc_scatter_rows(h->x, list, n, H, h->incX[l + 1], s));
-        ADF_TRY(adf_inc_scatter_rows(h->vecB, list, n, 3 * H, h->incV[l + 1], s));
-        adf_prof_end(h, s);
-        if (l + 1 < L) ADF_TRY(make_records(h, l + 1, n, h->x, h->vecB, false, h->incR[l + 1], list, s));
+        const int ncap = h->inc_sync ? n_seen : N;
+        h->rows_dev = h->inc_cnt + l;
+        int32_t st = message_layer(h, l, N, h->incX[l], vin, h->x, h->vecB, l == 0, s, list, ncap, h->incR[l], true);
+        if (st == ADF_OK) st = update_layer(h, l, ncap, h->x, h->vecB, s);
+        if (st == ADF_OK) {
+            adf_prof_begin(h, ADF_PROF_NODE, s);
+            st = adf_inc_scatter_rows(h->x, list, ncap, H, h->incX[l + 1], s, h->rows_dev);
+            if (st == ADF_OK) st = adf_inc_scatter_rows(h->vecB, list, ncap, 3 * H, h->incV[l + 1], s, h->rows_dev);
+            adf_prof_end(h, s);
+        }
+        if (st == ADF_OK && l + 1 < L) st = make_records(h, l + 1, ncap, h->x, h->vecB, false, h->incR[l + 1], list, s);
+        h->rows_dev = nullptr;
+        ADF_TRY(st);
     }
     adf_prof_begin(h, ADF_PROF_HEADS, s);
     if (!out_idx) {
@@ -856,6 +912,9 @@ extern "C" int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on) {
         }
     }
     h->inc_valid = false;
+    (void)inc_harvest(h, h->inc_slot, true);
+    (void)inc_harvest(h, h->inc_slot ^ 1, true);
+    h->inc_seen_valid = false;
     h->inc_rows = h->inc_rows_full = h->inc_edges = h->inc_launches = 0;
     return ADF_OK;
 }
@@ -948,6 +1007,8 @@ extern "C" int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stre
     const int64_t head = 2 * (3 * N * H * H + 3 * N * H * H / 2 + N * 2 * H * H + N * H * H + 3 * N * (H / 2) * (H / 2) +
                               N * H * H / 2);
     out->dense_flops = L * (30 * H * H * N + 2 * R * 3 * H * E) + h->hp.num_heads * head;
+    ADF_TRY(inc_harvest(h, h->inc_slot, true));      // the older of the two outstanding forwards first
+    ADF_TRY(inc_harvest(h, h->inc_slot ^ 1, true));
     out->inc_rows = (int64_t)h->inc_rows; out->inc_rows_full = (int64_t)h->inc_rows_full;
     out->inc_msg_launches = (int64_t)h->inc_launches; out->inc_msg_edges = (int64_t)h->inc_edges;
     return ADF_OK;

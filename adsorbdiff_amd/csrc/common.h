@@ -64,6 +64,9 @@ struct adf_epi {
     // (an unlifted element below ~0.1 loses its a_lo term to the matrix core's subnormal flush).  null = no lift.
     const float* rmag;
     unsigned int* out_mag;   // EPI 0: receives max|c| of every output row (atomicMax on float bits; zeroed by the launcher)
+    // any EPI: the row count lives on the device (an incremental layer's recompute list, incremental.hip): rows =
+    // min(M, *m_dev); the launch is sized for M.  null = M.
+    const int32_t* m_dev;
 };
 // scratch for the row magnitudes a launcher measures itself (adf_launch_rowmag) when the caller has none to hand over
 struct adf_lift {
@@ -159,7 +162,21 @@ struct adf_painn {
     unsigned char *inc_pend, *inc_need, *inc_tf;  // [L][capN] row has unapplied changes / is needed / is recomputed now
     int32_t* inc_list;                 // [L][capN] compacted recompute lists (ascending)
     int32_t* inc_cnt;                  // device [2L+1]: list lengths, in-edges of the listed rows, all edges
-    int32_t* inc_cnt_host;             // pinned copy
+    // The list lengths never gate a launch: list-mode kernels are sized for all N rows and read their row count from
+    // inc_cnt on the device (rows_dev below).  The host sees the counts one forward late, through a pinned double buffer
+    // and an event it polls without waiting, and uses them only to choose between the list and the all-rows form of a
+    // layer and for the statistics.  ADF_INC_SYNC=1: read them back synchronously instead (exact launch sizes).
+    int32_t* inc_cnt_host;             // pinned [2][2L+1]
+    void* inc_ev[2];                   // hipEvent_t after the copy into inc_cnt_host[slot]
+    bool inc_ev_live[2];
+    int inc_slot;
+    bool inc_sync;
+    int32_t inc_seen[2 * ADF_MAX_LAYERS + 1];  // the latest counts the host has seen
+    bool inc_seen_valid;
+    unsigned char inc_pend_whole[2][ADF_MAX_LAYERS];  // per slot: which layers of that forward ran in the all-rows form
+    int32_t inc_pend_N[2];
+    int32_t inc_pend_Nseen;            // the atom count inc_seen belongs to
+    const int32_t* rows_dev;           // device row count of the launches being enqueued (a list-mode layer), else null
     void* inc_tmp; size_t inc_tmp_bytes;  // hipcub select workspace
     unsigned long long inc_rows, inc_rows_full, inc_edges, inc_launches;  // totals since adf_painn_set_incremental
     unsigned long long build_serial, inc_serial;  // graph builds made / the build the kept state belongs to
@@ -189,8 +206,11 @@ int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const 
 // (written by the producer of A: LayerNorm, a previous product's out_mag); out_mag: emit the output rows' magnitudes
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s, const float* A2 = nullptr, int K1 = 0,
-                          const adf_lift* lf = nullptr, const float* premag = nullptr, float* out_mag = nullptr);
-int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s);
+                          const adf_lift* lf = nullptr, const float* premag = nullptr, float* out_mag = nullptr,
+                          const int32_t* m_dev = nullptr);  // m_dev: see adf_epi::m_dev
+// m_dev / m_mul: rows = min(M, *m_dev * m_mul) when the count lives on the device (m_mul = 3: [N,3,K] vector rows)
+int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s,
+                          const int32_t* m_dev = nullptr, int m_mul = 1);
 int32_t adf_split_weight(const float* w, long long n, adf_w16* out, unsigned int* scratch_bits, hipStream_t s,
                          int perm_H = 0, int K = 0, const float* bias = nullptr, int parts = 3);
 int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, float* nrm, int M, int N, int K,
@@ -203,7 +223,7 @@ static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, co
                                  const float* premag = nullptr, float* out_mag = nullptr) {
     if (h->gemm_f32) return adf_launch_gemm(A, lda, W, K, bias, C, ldc, M, N, K, act, s);
     return adf_launch_gemm16(A, lda, W16, bias, C, ldc, M, N, K, act, s, nullptr, 0, h->lift_on ? &h->lift : nullptr,
-                             h->lift_on ? premag : nullptr, h->lift_on ? out_mag : nullptr);
+                             h->lift_on ? premag : nullptr, h->lift_on ? out_mag : nullptr, h->rows_dev);
 }
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
 // incremental.hip
@@ -211,18 +231,21 @@ size_t adf_inc_temp_bytes(int64_t n);
 int32_t adf_inc_compare(adf_painn* h, int N, hipStream_t s);  // inc_c0 from (nptr, e_src, e_geom) vs prev_*
 int32_t adf_inc_need_from_list(adf_painn* h, int N, int L, const int32_t* out_idx, int n_out, hipStream_t s);
 int32_t adf_inc_plan_layer(adf_painn* h, int l, int N, bool first, bool have_need, hipStream_t s);
-int32_t adf_inc_scatter_rows(const float* src, const int32_t* idx, int n, int width, float* dst, hipStream_t s);
+// n_dev: rows = min(n, *n_dev) (the list length stays on the device)
+int32_t adf_inc_scatter_rows(const float* src, const int32_t* idx, int n, int width, float* dst, hipStream_t s,
+                             const int32_t* n_dev = nullptr);
 int32_t adf_inc_gather_rows(const float* src, const int32_t* idx, int n, int width, float* dst, hipStream_t s);
 size_t adf_scan_temp_bytes(int64_t n);
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s,
-                         const int32_t* tlist = nullptr, int n_targets = 0, const float* rec = nullptr);
+                         const int32_t* tlist = nullptr, int n_targets = 0, const float* rec = nullptr,
+                         const int32_t* n_targets_dev = nullptr);  // n_targets_dev: the list length lives on the device
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
 int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s,
                          float* rec = nullptr);
 int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s);
 int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s,
-                               float* out_mag = nullptr);  // out_mag: max|y| per row
+                               float* out_mag = nullptr, const int32_t* n_dev = nullptr);  // out_mag: max|y| per row
 int32_t adf_nodewise_update_prep(const float* vv, const float* x, float* cat, float* dot, int N, int H, hipStream_t s);
 int32_t adf_nodewise_update_apply(const float* h3, const float* dot, const float* vv, float* x, float* vec,
                                   float scale, int N, int H, hipStream_t s);

@@ -66,8 +66,9 @@ __device__ __forceinline__ float ssilu16(float x) {
 template <int ACT, int MI, int NJ, int EPI>
 __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const float* __restrict__ A, int lda, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
-    const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ C, int ldc, int M, int N,
+    const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ C, int ldc, int Mh, int N,
     int K, int tiles_n, adf_epi ep) {
+    const int M = ep.m_dev ? min(Mh, (int)*ep.m_dev) : Mh;  // rows: the host's bound, or fewer by a device-side count
     constexpr int TM = 64 * MI;   // rows per workgroup
     constexpr int TN = 64 * NJ;   // columns per workgroup
     constexpr int NA = TM / 32;   // float4 A loads per thread
@@ -471,10 +472,11 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
 // mag[r] = max over the K1 leading elements of A row r (and the K2 of A2 row r, same row stride): one wave per row
 __global__ __launch_bounds__(256) void adf_rowmag_kernel(const float* __restrict__ A, int lda, int K1,
                                                          const float* __restrict__ A2, int K2, long long M,
-                                                         float* __restrict__ mag) {
+                                                         float* __restrict__ mag, const int32_t* __restrict__ m_dev,
+                                                         int m_mul) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (r >= M) return;
+    if (r >= M || (m_dev && r >= (long long)*m_dev * m_mul)) return;
     float mx = 0.f;
     const float* a = A + (size_t)r * lda;
     for (int k = lane * 4; k < K1; k += 256) {
@@ -493,20 +495,22 @@ __global__ __launch_bounds__(256) void adf_rowmag_kernel(const float* __restrict
     if (lane == 0) mag[r] = mx;
 }
 
-int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s) {
+int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s,
+                          const int32_t* m_dev, int m_mul) {
     if (M <= 0) return ADF_OK;
-    hipLaunchKernelGGL(adf_rowmag_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, A, lda, K1, A2, K2, M, mag);
+    hipLaunchKernelGGL(adf_rowmag_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, A, lda, K1, A2, K2, M, mag, m_dev,
+                       m_mul);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
 
 // row magnitudes for a launcher: the caller's (premag), or measured into lf->buf, or none
 static int32_t lift_mags(const float* A, int lda, int K1, const float* A2, int K2, long long rows, const adf_lift* lf,
-                         const float* premag, const float** out, hipStream_t s) {
+                         const float* premag, const float** out, hipStream_t s, const int32_t* m_dev = nullptr, int m_mul = 1) {
     *out = premag;
     if (!premag && lf && lf->buf) {
         if (rows > lf->cap) { adf_set_error("gemm16: lift scratch holds %lld rows, need %lld", lf->cap, rows); return ADF_EINVAL; }
-        ADF_TRY(adf_launch_rowmag(A, lda, K1, A2, K2, rows, lf->buf, s));
+        ADF_TRY(adf_launch_rowmag(A, lda, K1, A2, K2, rows, lf->buf, s, m_dev, m_mul));
         *out = lf->buf;
     }
     return ADF_OK;
@@ -571,7 +575,7 @@ static int32_t check_a_span(long long rows, int lda) {
 
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s, const float* A2, int K1, const adf_lift* lf,
-                          const float* premag, float* out_mag) {
+                          const float* premag, float* out_mag, const int32_t* m_dev) {
     if (M <= 0) return ADF_OK;
     if (K % HK != 0 || (lda & 3) || (A2 && (K1 <= 0 || K1 % HK != 0 || K1 >= K))) {
         adf_set_error("gemm16: K=%d (K1=%d) must be multiples of %d and lda a multiple of 4", K, K1, HK);
@@ -586,8 +590,8 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
     adf_epi ep = {};
-    ep.A2 = A2; ep.K1 = A2 ? K1 : 0;
-    ADF_TRY(lift_mags(A, lda, A2 ? K1 : K, A2, A2 ? K - K1 : 0, M, lf, premag, &ep.rmag, s));
+    ep.A2 = A2; ep.K1 = A2 ? K1 : 0; ep.m_dev = m_dev;
+    ADF_TRY(lift_mags(A, lda, A2 ? K1 : K, A2, A2 ? K - K1 : 0, M, lf, premag, &ep.rmag, s, m_dev, 1));
     if (out_mag) {
         ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));
         ep.out_mag = reinterpret_cast<unsigned int*>(out_mag);
@@ -631,7 +635,8 @@ int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M
         return ADF_EINVAL;
     }
     ADF_TRY(check_a_span(epi == 3 ? 3ll * M : (long long)M, lda));
-    ADF_TRY(lift_mags(A, lda, K, nullptr, 0, epi == 3 ? 3ll * M : (long long)M, lf, ep_in->rmag, &epv.rmag, s));
+    ADF_TRY(lift_mags(A, lda, K, nullptr, 0, epi == 3 ? 3ll * M : (long long)M, lf, ep_in->rmag, &epv.rmag, s, ep_in->m_dev,
+                      epi == 3 ? 3 : 1));
     const int N = 3 * H, TM = 128, TN = 192;
     const int tiles_n = N / TN;  // H % 64 == 0
     const int tiles_m = (M + TM - 1) / TM;

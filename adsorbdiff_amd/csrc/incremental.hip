@@ -84,7 +84,8 @@ __global__ void adf_inc_need_kernel(const int32_t* __restrict__ nptr, const int3
 }
 
 __global__ void adf_inc_scatter_kernel(const float4* __restrict__ src, const int32_t* __restrict__ idx, long long total,
-                                       int w4, float4* __restrict__ dst) {
+                                       int w4, float4* __restrict__ dst, const int32_t* __restrict__ n_dev) {
+    if (n_dev) total = min(total, (long long)*n_dev * w4);
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const long long r = t / w4;
         const int c = (int)(t - r * w4);
@@ -150,11 +151,12 @@ static int rows_grid(long long total) {
     return (int)(g > 65536 ? 65536 : (g < 1 ? 1 : g));
 }
 
-int32_t adf_inc_scatter_rows(const float* src, const int32_t* idx, int n, int width, float* dst, hipStream_t s) {
+int32_t adf_inc_scatter_rows(const float* src, const int32_t* idx, int n, int width, float* dst, hipStream_t s,
+                             const int32_t* n_dev) {
     if (n <= 0) return ADF_OK;
     const long long total = (long long)n * (width / 4);
     hipLaunchKernelGGL(adf_inc_scatter_kernel, dim3(rows_grid(total)), dim3(256), 0, s, (const float4*)src, idx, total,
-                       width / 4, (float4*)dst);
+                       width / 4, (float4*)dst, n_dev);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

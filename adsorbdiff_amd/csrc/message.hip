@@ -56,6 +56,7 @@ struct MsgParams {
     float* vec_out;
     const int32_t* tlist;    // optional: targets to evaluate (ascending atom indices); outputs are then compact rows
     int items;               // number of targets: N, or the length of tlist
+    const int32_t* items_dev;  // optional: the list length on the device (items is then its upper bound)
     const int32_t* nptr;
     const int32_t* e_src;
     const float4* e_geom;
@@ -108,6 +109,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const int slice = blockIdx.x % p.nslices;
     const int worker = blockIdx.x / p.nslices;
     const int nworkers = gridDim.x / p.nslices;
+    const int items = p.items_dev ? min(p.items, (int)*p.items_dev) : p.items;
+    const int ngroups = (items + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
+    if (worker >= ngroups) return;  // nothing for this workgroup (before the weight image is staged)
     const int H = p.H;
     const int c0 = slice * ADF_SLICE_CH;
 
@@ -167,9 +171,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             if (lane == 0) t = atomicAdd(Ctr, 1);
             t = __builtin_amdgcn_readfirstlane(t);
             const int g = worker + (t >> 5) * nworkers;
-            if (g >= p.G) return false;
+            if (g >= ngroups) return false;
             const int e = g * ADF_GROUP_NODES + (t & 31);
-            if (e < p.items) { o_out = e; n_out = p.tlist ? p.tlist[e] : e; return true; }
+            if (e < items) { o_out = e; n_out = p.tlist ? p.tlist[e] : e; return true; }
         }
     };
     auto load_block = [&](int eb, int e1, float4& geo, int& src, bool& valid) {
@@ -570,7 +574,7 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
 
 int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const float* xh, const float* vec,
                          float* x_out, float* vec_out, bool vec_is_zero, hipStream_t s, const int32_t* tlist,
-                         int n_targets, const float* rec) {
+                         int n_targets, const float* rec, const int32_t* n_targets_dev) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
     if ((unsigned long long)(N + 1) * 5ull * H * sizeof(float) >= (1ull << 32)) {
         adf_set_error("message kernel uses 32-bit byte offsets into the node tables: N=%d is too large, split the batch", N);
@@ -587,7 +591,7 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     p.inv_scale = h->rbf_scales + layer;
     p.mu = h->rbf_offset;
     p.N = N; p.H = H; p.R = R;
-    p.tlist = tlist; p.items = tlist ? n_targets : N;
+    p.tlist = tlist; p.items = tlist ? n_targets : N; p.items_dev = tlist ? n_targets_dev : nullptr;
     if (p.items <= 0) return ADF_OK;
     p.G = (p.items + ADF_GROUP_NODES - 1) / ADF_GROUP_NODES;
     p.inv_cutoff = 1.0f / h->hp.cutoff;

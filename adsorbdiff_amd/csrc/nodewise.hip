@@ -32,10 +32,11 @@ __global__ void adf_embed_kernel(const float* __restrict__ emb, const int32_t* _
 // torch.nn.LayerNorm(H), eps = 1e-5, biased variance.  One wave per row, 16 B per lane and access.
 __global__ __launch_bounds__(256) void adf_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ y,
-                                                             int N, int H, float* __restrict__ out_mag) {
+                                                             int N, int H, float* __restrict__ out_mag,
+                                                             const int32_t* __restrict__ n_dev) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= N) return;
+    if (row >= N || (n_dev && row >= *n_dev)) return;
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * H);
     const int h4 = H / 4;  // H <= 1024: at most 4 float4 per lane
     float4 vals[4];
@@ -231,8 +232,8 @@ int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipS
 }
 
 int32_t adf_nodewise_layernorm(const float* x, const float* w, const float* b, float* y, int N, int H, hipStream_t s,
-                               float* out_mag) {
-    hipLaunchKernelGGL(adf_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, w, b, y, N, H, out_mag);
+                               float* out_mag, const int32_t* n_dev) {
+    hipLaunchKernelGGL(adf_layernorm_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, w, b, y, N, H, out_mag, n_dev);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

@@ -65,6 +65,9 @@ def parse():
                     help="exchange step: torch.distributed.all_gather (nccl backend = RCCL) or the library's own "
                          "C-ABI adf_allgather_sites (RCCL communicator created by the library)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the adsorbate-only and exact-f32 extra passes")
+    ap.add_argument("--no-incremental", action="store_true",
+                    help="PaiNN: recompute every node row of every layer at every step, as the reference does "
+                         "(denoising_pos_params['incremental_layers']=False) - timed like the default, warm-up included")
     ap.add_argument("--cpu-full", action="store_true",
                     help="CPU baseline at SURVEY 8d's sizes (8 systems x 50 steps and 64 x 1 step; ~10 min)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,6 +214,8 @@ def main():
     total_systems = args.systems * world if args.scaling == "weak" else args.systems
     params = dict(num_steps=args.num_steps, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55,
                   ode=True, early_stop=False)
+    if args.no_incremental:
+        params["incremental_layers"] = False
     eng = model.engine(dev)
     # initial-placement uniforms keyed by global system id: an N-rank strong-scaling run samples exactly the sites
     # of the 1-rank run (the reference draws torch.rand(B,3) per process, denoising_torch.py:215)
@@ -297,6 +302,7 @@ def main():
         del moved_last, sites_mv
         eng_mv.close()
         del model_mv, trainer_mv
+        one_pass({"incremental_layers": False})  # untimed: switching the feature off frees its 22 GB of kept state
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         sites_full = one_pass({"incremental_layers": False})
@@ -305,7 +311,8 @@ def main():
         all_rows = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
                     "identical_sites": bool(torch.equal(sites_full, sites)),
                     "note": "denoising_pos_params['incremental_layers']=False: every node row of every layer recomputed "
-                            "at every step, as the reference does; one pass, not part of `value`"}
+                            "at every step, as the reference does; one pass after one untimed pass, not part of `value` "
+                            "(`--no-incremental` times it like the default)"}
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         sites_ads = one_pass({"scores_on_adsorbate_only": True})
