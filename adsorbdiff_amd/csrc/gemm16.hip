@@ -50,6 +50,17 @@ __device__ __forceinline__ float ssilu16(float x) {
     return s * 1.6666666666666667f;
 }
 
+// max over the 16 lanes of a DPP row (non-negative values), left in every lane: four v_max_f32 with row rotations
+__device__ __forceinline__ float adf_row16_max(float v) {
+#define ADF_ROR(n_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n_), 0xf, 0xf, false))
+    v = fmaxf(v, ADF_ROR(8));
+    v = fmaxf(v, ADF_ROR(4));
+    v = fmaxf(v, ADF_ROR(2));
+    v = fmaxf(v, ADF_ROR(1));
+#undef ADF_ROR
+    return v;
+}
+
 // Workgroup = 4 waves as 2(M) x 2(N); wave tile = (32*MI) rows x (32*NJ) columns of MFMA 32x32 blocks.
 //   MI=2,NJ=4 (default): 128 x 256 tile, 2 workgroups per CU.
 //   NJ=3 with EPI != 0: the three column blocks of a wave are the three H-wide parts of a 3H-wide
@@ -227,13 +238,6 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                         if (ACT) { v0 = ssilu16(v0); v1 = ssilu16(v1); }
                         T[lr * TLD2 + q] = v0;
                         T[lr * TLD2 + 32 + q] = v1;
-                        if (ep.out_mag) {  // all 32 lanes of a half-wave hold the same output row
-                            float mg = fmaxf(cb + q < N ? fabsf(v0) : 0.f, cb + 32 + q < N ? fabsf(v1) : 0.f);
-#pragma unroll
-                            for (int o = 16; o > 0; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
-                            const int orow = m0 + wm + 32 * i + lr;
-                            if (q == 0 && orow < M) atomicMax(ep.out_mag + orow, __float_as_uint(mg));
-                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -242,9 +246,13 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                         const int item = lane + 64 * it;
                         const int lr = item >> 4, c4 = item & 15;
                         const int row = m0 + wm + 32 * i + lr, col = cb + 4 * c4;
-                        if (row < M && col < N)
-                            *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) =
-                                *reinterpret_cast<const float4*>(T + lr * TLD2 + 4 * c4);
+                        const float4 v = *reinterpret_cast<const float4*>(T + lr * TLD2 + 4 * c4);
+                        if (row < M && col < N) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+                        if (ep.out_mag) {  // the 16 lanes of a DPP row hold one output row: its maximum by four rotations
+                            float mg = col < N ? fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) : 0.f;
+                            mg = adf_row16_max(mg);
+                            if (c4 == 0 && row < M) atomicMax(ep.out_mag + row, __float_as_uint(mg));
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();  // T is rewritten by the next piece
                 }

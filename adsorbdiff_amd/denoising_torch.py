@@ -187,7 +187,8 @@ class Denoiser:
             # forward the layer-0 records (loop-invariant; results are bit-identical either way)
             if params.get("static_atom_cache", True):
                 eng.set_moving_atoms(prep, prep.tags == 2)
-            # (a captured step cannot hand the recompute-list lengths to the host: graph replay runs without it)
+            # (a captured step replays fixed buffers: the previous-graph / current-graph swap the comparison rests on, and
+            # the late read-back of the list lengths that picks between the list and the all-rows form, do not replay)
             eng.set_incremental(bool(params.get("incremental_layers", True)) and not params.get("use_graph", False))
 
             pos0 = pos.clone()  # a run that leaves the f16x3 range is repeated in exact f32 from here

@@ -232,7 +232,8 @@ int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, float* pos, co
  * z_tr_all, z_rot_all: [num_steps][B][3] standard normals (SDE) or both NULL (ODE).  poll_every > 0 (and
  * early_stop_count > 0): every poll_every steps the frozen flag state[1] is read back (one stream synchronisation)
  * and the loop ends once it is set — the reference's `break`; 0 = never synchronise for that (steps after the stop
- * are no-ops on pos; incremental layers, if on, synchronise once per forward for their list lengths).  out_idx / n_out: optional subset of atoms whose model outputs are evaluated (see
+ * are no-ops on pos; incremental layers never synchronise: their list lengths stay on the device, ADF_INC_SYNC=1 restores the
+ * per-forward read-back).  out_idx / n_out: optional subset of atoms whose model outputs are evaluated (see
  * adf_painn_forward_subset), NULL = all.  f1, f2: [N,3] work arrays (last step's outputs on return). */
 int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                    const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
