@@ -647,11 +647,13 @@ def main_eqv2(args, rank, world, dev):
     for _ in range(args.warmup):
         one_pass()
     # secondary (one pass): the force blocks evaluated for the adsorbate atoms only (adf_eqv2_forward_subset)
-    fence()
-    t0 = time.perf_counter()
-    sites_ads = one_pass({"scores_on_adsorbate_only": True})
-    fence()
-    ads_s = time.perf_counter() - t0
+    sites_ads, ads_s = None, 0.0
+    if not args.no_secondary:
+        fence()
+        t0 = time.perf_counter()
+        sites_ads = one_pass({"scores_on_adsorbate_only": True})
+        fence()
+        ads_s = time.perf_counter() - t0
     eng.profile_enable(True)
     fence()
     t0 = time.perf_counter()
@@ -724,12 +726,13 @@ def main_eqv2(args, rank, world, dev):
                         "stream (includes the row-lift passes that feed them)",
             },
             "measured_peaks": measured,
-            "scores_on_adsorbate_only": {
+        }
+        if sites_ads is not None:
+            out["scores_on_adsorbate_only"] = {
                 "value": total_systems / ads_s, "unit": "sites/s", "identical_sites": bool(torch.equal(sites_ads, sites)),
                 "note": "opt-in denoising_pos_params['scores_on_adsorbate_only']: the two force blocks run for the tag-2 "
                         "target atoms only (adf_eqv2_forward_subset); one pass, this rank's clock",
-            },
-        }
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = eqv2_cpu_baseline(model, params)
         print(json.dumps(out), flush=True)

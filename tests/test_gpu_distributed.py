@@ -80,19 +80,23 @@ def test_two_ranks_on_one_gpu_equal_single_rank(tmp_path):
     assert torch.equal(torch.nan_to_num(one["sites"]), torch.nan_to_num(two["sites"]))
 
 
-def test_bench_launches_its_own_ranks(tmp_path):
-    """`python bench.py --gpus 2 --backend gloo` on one GPU: n_gpus 2 in the JSON line, same sites as --gpus 1."""
+@pytest.mark.parametrize("model", ["painn", "eqv2"])
+def test_bench_launches_its_own_ranks(tmp_path, model):
+    """`python bench.py --gpus 2 --backend gloo` on one GPU: n_gpus 2 in the JSON line, same sites as --gpus 1 - with
+    either score model (BASELINE config 3 sharding; config 4's model through the same launcher)."""
     def bench(n):
-        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--backend", "gloo", "--systems", "6",
-               "--num-steps", "3", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"]
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--backend", "gloo", "--model", model,
+               "--systems", "6" if model == "painn" else "4", "--num-steps", "3" if model == "painn" else "2",
+               "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary"]
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         assert res.returncode == 0, res.stderr[-2000:]
         return json.loads(res.stdout.strip().splitlines()[-1])
 
     a, b = bench(1), bench(2)
+    total = 6 if model == "painn" else 4
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "strong"
-    assert b["config"]["systems_total"] == 6 and b["config"]["systems_per_gpu"] == 3
+    assert b["config"]["systems_total"] == total and b["config"]["systems_per_gpu"] == total // 2
     assert a["sites_sha256_16"] == b["sites_sha256_16"]
 
 
