@@ -100,6 +100,25 @@ def test_bench_launches_its_own_ranks(tmp_path, model):
     assert a["sites_sha256_16"] == b["sites_sha256_16"]
 
 
+def test_bench_under_torch_distributed_run(tmp_path):
+    """The driver's launch form: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` (gloo here: two
+    ranks share the one GPU of this box).  Rank 0 prints the JSON line; same sites as the self-launched run."""
+    args = ["--gpus", "2", "--backend", "gloo", "--systems", "6", "--num-steps", "3", "--steps", "1", "--warmup", "0",
+            "--no-cpu-baseline", "--no-secondary"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py")] + args
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    a = json.loads(lines[0])
+    res2 = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, timeout=900, env=env)
+    assert res2.returncode == 0, res2.stderr[-2000:]
+    b = json.loads(res2.stdout.strip().splitlines()[-1])
+    assert a["n_gpus"] == 2 and a["sites_sha256_16"] == b["sites_sha256_16"]
+
+
 def test_rccl_allgather_c_abi_single_rank():
     """adf_comm_* / adf_allgather_sites through RCCL with a 1-rank communicator (all this box can host)."""
     import ctypes as C
