@@ -686,6 +686,18 @@ def main_eqv2(args, rank, world, dev):
         measured = {"hbm_copy_gbps": float(pk[0]), "mfma_f16_tflops": float(pk[1]), "mfma_f32_tflops": float(pk[2])}
         gpu_ms = {k: round(v[0] / args.steps, 2) for k, v in prof.items()}
         total_gpu_s = sum(v[0] for v in prof.values()) * 1e-3
+        conv_traffic = conv_traffic_src = None
+        pmc = ROOT / "profiles" / "eqv2_conv_pmc.json"
+        if pmc.exists():  # PMC counters need their own rocprofv3 passes: the committed result scaled to this run's edge count
+            try:
+                chunk = int(os.environ.get("ADF_EQV2_CHUNK_EDGES", 1 << 19))  # edges per launch: the engine's chunking
+                per_launch = c.num_edges / max(1, -(-c.num_edges // chunk))
+                conv_traffic = json.loads(pmc.read_text())["hbm_bytes_per_conv_launch_and_edge"] * per_launch
+                conv_traffic_src = ("static: profiles/eqv2_conv_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at "
+                                    "64 systems, 2*FETCH+WRITE per launch of the convolution product kernels and per edge) x this "
+                                    "run's edges per launch; not measured in this run")
+            except Exception:
+                conv_traffic = None
         import hashlib
 
         out = {
@@ -718,7 +730,8 @@ def main_eqv2(args, rank, world, dev):
                 "achieved": issued, "peak": PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": issued / (PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS),
                 "measured_peak": measured["mfma_f16_tflops"] if f16 else measured["mfma_f32_tflops"],
-                "traffic": None,
+                "traffic": conv_traffic,
+                "traffic_source": conv_traffic_src,
                 "flops_per_forward": c.conv_flops * products,
                 "share_of_gpu_time": conv_s / total_gpu_s if total_gpu_s > 0 else None,
                 "note": "achieved = 2 x multiply-adds of the SO(2) convolutions (5.83 M + 2.40 M per edge and block at this "
