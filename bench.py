@@ -55,8 +55,8 @@ def parse():
                     help="sample = the headline (reverse-diffusion sampling); train = BASELINE config 5: one score-matching "
                          "training step (PaiNN, --systems graphs per GPU, weak scaling, gradient all-reduce over RCCL)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 2 sampling passes; 10 training steps)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 1; 3 training steps)")
     ap.add_argument("--systems", type=int, default=None,
                     help="systems per rank (weak) or in total (strong); default 1000 (painn) / 128 (eqv2)")
     ap.add_argument("--num-steps", type=int, default=50, help="reverse-diffusion steps per sample")
@@ -79,8 +79,10 @@ def parse():
     if a.mode == "train":
         if a.model != "painn":
             raise SystemExit("bench.py --mode train: the training step exists for the PaiNN denoiser (config 5)")
-        if a.steps == 2 and a.warmup == 1:
-            a.steps, a.warmup = 10, 3
+    if a.steps is None:
+        a.steps = 10 if a.mode == "train" else 2
+    if a.warmup is None:
+        a.warmup = 3 if a.mode == "train" else 1
     return a
 
 
