@@ -938,7 +938,9 @@ int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, i
 // target, thread = value channel, the target's S coefficients in registers, edges in CSR order (run-to-run identical).
 // ONLY1: only the l = 1 coefficients (all a force block's projection reads), written as [N, 3, HV].
 // (Measured alternative: several thread groups per target, each taking every k-th edge, partial sums added through LDS —
-// slower, 61 -> 80 ms per forward at 256 k edges: the edge's Wigner rows stop being wave-uniform scalar loads.)
+// slower, 61 -> 80 ms per forward at 256 k edges: the edge's Wigner rows stop being wave-uniform scalar loads.  Dealing the
+// DEGREES of a target to four thread groups instead - whole waves, scalar Wigner loads kept, bit-identical sums, four times
+// the waves per target - was slower too: 64.4 vs 60.9 ms.  Unrolling the edge loop 2x / 4x: no change.)
 template <int LT, bool ONLY1>
 __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, const float* __restrict__ alpha,
                                      const float* __restrict__ wig, const int32_t* __restrict__ eptr, int n0, int n1,
