@@ -289,3 +289,25 @@ def test_final_frame_records_append_per_batch(tmp_path):
 
     with pytest.raises(ValueError):
         write_final_frames(b, tmp_path / "frames.lmdb", start_index=3, apply_lift=False)
+
+
+def test_igso3_table_cache_is_atomic_and_validated(tmp_path, monkeypatch):
+    """so3_tables: the cache file is written under a temporary name and renamed; an unreadable or mis-shaped file is
+    ignored (several ranks may race on first use)."""
+    import numpy as np
+
+    from adsorbdiff_amd import so3_tables as S
+
+    cache = tmp_path / "c" / "igso3.npz"
+    monkeypatch.setattr(S, "_CACHE", cache)
+    assert S.Igso3Tables._load_cache() is None
+    t = {"omegas": np.linspace(0, np.pi, S.X_N), "cdf": np.zeros((S.N_EPS, S.X_N), np.float32),
+         "score": np.ones((S.N_EPS, S.X_N), np.float32), "exp_score_norm": np.arange(S.N_EPS, dtype=np.float64)}
+    S.Igso3Tables._store_cache(t)
+    assert cache.exists() and not list(cache.parent.glob("*.tmp.npz"))
+    back = S.Igso3Tables._load_cache()
+    assert back is not None and np.array_equal(back["exp_score_norm"], t["exp_score_norm"])
+    cache.write_bytes(cache.read_bytes()[:1000])  # a partially written file
+    assert S.Igso3Tables._load_cache() is None
+    np.savez(cache, omegas=t["omegas"][:10], cdf=t["cdf"], score=t["score"], exp_score_norm=t["exp_score_norm"])
+    assert S.Igso3Tables._load_cache() is None  # wrong shape
