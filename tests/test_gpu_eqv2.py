@@ -257,6 +257,22 @@ def test_eqv2_sampling_on_adsorbate_scores_only_gives_identical_sites():
     assert float((outs[0] - safe_batch(2, 36, seed=21).pos).abs().max()) > 0.1  # the adsorbates did move
 
 
+def test_eqv2_forward_is_run_to_run_and_batch_independent():
+    """No atomics on values (row magnitudes are order-independent maxima), sums in CSR order, lifts per row / per node:
+    the same forward twice gives the same bits, and a system evaluated alone gives the bits it has inside a batch."""
+    m = make_model(6, 2, C=32, hidden=64, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=2, cutoff=12.0).to(DEV)
+    b3 = safe_batch(3, 36, seed=17)
+    f1, f2 = m(b3.clone().to(DEV))
+    g1, g2 = m(b3.clone().to(DEV))
+    assert torch.equal(f1, g1) and torch.equal(f2, g2)
+    from adsorbdiff_amd.data import Batch
+
+    first = Batch.from_data_list(b3.to_data_list()[:1])
+    n0 = int(first.natoms[0])
+    h1, h2 = m(first.to(DEV))
+    assert torch.equal(h1, f1[:n0]) and torch.equal(h2, f2[:n0])
+
+
 def test_eqv2_distance_basis_path_vs_oracle():
     """Radii small enough for the Gaussian distance basis to be non-zero (the table divided by 100: what the
     reference's discarded `/ 100` would have produced, equiformer_v2_denoising.py:168-169): the per-edge radial path
