@@ -142,16 +142,23 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
 }
 
 // Same contraction on 128 x 128 tiles (N % 128 == 0, K % 128 == 0): each wave owns 64 x 64 = 2 x 2 MFMA blocks, so an LDS
-// value feeds two MFMAs and a staged row serves twice as many; rows are staged with 16-byte loads.
+// value feeds two MFMAs and a staged row serves twice as many; rows are staged with 16-byte loads.  A 32-column block of
+// the A chunk that is entirely zero is skipped (exactly the same sums): the radial basis rows of rbf_proj's weight
+// gradient - 5 M edge rows, the largest product of the step - are zero outside +-14 centres of the edge's distance, and
+// consecutive edges of a target are sorted by distance.
 __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A,
                                                            int lda, float* __restrict__ part, int M, int N, int K,
                                                            int rows_per_split, int tiles_k, float* __restrict__ bpart) {
     __shared__ __attribute__((aligned(16))) float Cs[32][128];
     __shared__ __attribute__((aligned(16))) float As[32][128];
+    __shared__ unsigned int nzblk[2][4];  // [chunk parity][32-column block of As]: some element is non-zero
+    if (threadIdx.x < 8) nzblk[threadIdx.x >> 2][threadIdx.x & 3] = 0u;
     const int tile = blockIdx.x, split = blockIdx.y;
     const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    // the two waves along k take the 32-column blocks {0, 2} and {1, 3} of the A chunk: a window of adjacent non-zero blocks
+    // (see the header) is then shared between them
+    const int wn = (wave >> 1) * 64, kb = wave & 1;
     const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
     f32x16 acc[2][2];
 #pragma unroll
@@ -163,7 +170,8 @@ __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restric
     const bool colsum = bpart && k0 == 0 && tid < 128;
     float bs = 0.f;
     const int lr = tid >> 5, lc = (tid & 31) * 4;  // staging: 8 rows x 32 float4 per pass, 4 passes
-    for (int m0 = mbeg; m0 < mend; m0 += 32) {
+    int par = 0;
+    for (int m0 = mbeg; m0 < mend; m0 += 32, par ^= 1) {
         float4 c4[4], a4[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -178,20 +186,35 @@ __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restric
             *reinterpret_cast<float4*>(&Cs[lr + 8 * ps][lc]) = c4[ps];
             *reinterpret_cast<float4*>(&As[lr + 8 * ps][lc]) = a4[ps];
         }
+        {   // this thread's 16 values lie in column block lc / 32
+            bool nz = false;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) nz = nz || a4[ps].x != 0.f || a4[ps].y != 0.f || a4[ps].z != 0.f || a4[ps].w != 0.f;
+            if (nz) nzblk[par][lc >> 5] = 1u;  // benign race: every writer stores 1
+            if (tid < 4) nzblk[par ^ 1][tid] = 0u;  // the other parity's flags were last read before the barrier above
+        }
         __syncthreads();
         if (colsum) {
 #pragma unroll
             for (int r = 0; r < 32; ++r) bs += Cs[r][tid];  // rows in order: reproducible
         }
+        const bool do0 = nzblk[par][kb] != 0u, do1 = nzblk[par][kb + 2] != 0u;  // wave-uniform
+        if (do0 || do1) {
 #pragma unroll
-        for (int mm = 0; mm < 32; mm += 2) {
-            const int rr = mm + (lane >> 5), cc = lane & 31;
-            const float a0 = Cs[rr][wn + cc], a1 = Cs[rr][wn + 32 + cc];
-            const float b0 = As[rr][wk + cc], b1 = As[rr][wk + 32 + cc];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int mm = 0; mm < 32; mm += 2) {
+                const int rr = mm + (lane >> 5), cc = lane & 31;
+                const float a0 = Cs[rr][wn + cc], a1 = Cs[rr][wn + 32 + cc];
+                if (do0) {
+                    const float b0 = As[rr][32 * kb + cc];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                }
+                if (do1) {
+                    const float b1 = As[rr][32 * (kb + 2) + cc];
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            }
         }
     }
     float* out = part + (size_t)split * N * K;
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restric
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = k0 + wk + 32 * j + (lane & 31);
+            const int col = k0 + 32 * (kb + 2 * j) + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
