@@ -26,6 +26,23 @@ def axis_angle_to_matrix(v: torch.Tensor) -> torch.Tensor:
         two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)]).reshape(3, 3)
 
 
+def axis_angle_to_matrix_batch(v: np.ndarray) -> np.ndarray:
+    """[B,3] float64 axis-angles -> [B,3,3] float64: the same formulas, all systems at once (the per-system torch version
+    above costs ~20 small CPU tensor ops per system: 20 ms per 256-system batch)."""
+    v = np.asarray(v, dtype=np.float64)
+    ang = np.linalg.norm(v, axis=1)
+    half = 0.5 * ang
+    small = np.abs(ang) < 1e-6
+    k = np.where(small, 0.5 - ang * ang / 48, np.sin(half) / np.where(small, 1.0, ang))
+    qr = np.cos(half)
+    qi, qj, qk = v[:, 0] * k, v[:, 1] * k, v[:, 2] * k
+    two_s = 2.0 / (qr * qr + qi * qi + qj * qj + qk * qk)
+    return np.stack([
+        1 - two_s * (qj * qj + qk * qk), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+        two_s * (qi * qj + qk * qr), 1 - two_s * (qi * qi + qk * qk), two_s * (qj * qk - qi * qr),
+        two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi * qi + qj * qj)], axis=1).reshape(-1, 3, 3)
+
+
 @torch.no_grad()
 def pbc_correction(noise_vec: torch.Tensor, cell: torch.Tensor) -> torch.Tensor:
     """[B,3] vectors wrapped to the minimum image of their system's cell: fractional coordinates by an fp64 solve with
@@ -53,21 +70,20 @@ def tr_so3_schedule(batch, denoise_pos_params: dict, tables: Igso3Tables = None)
     noise = torch.zeros(center.shape, device=dev).normal_() * tr_sigma[:, None]
     noise = pbc_correction(noise, batch.cell.reshape(B, 3, 3))
     noise[:, -1] = 0
-    rot_sigma_h = rot_sigma.cpu()
-    R, rot_score = [], []
-    for b in range(B):
-        eps = rot_sigma_h[b].item()
-        upd = tables.sample_vec(eps=eps)
-        R.append(axis_angle_to_matrix(torch.tensor(upd)).float())
-        rot_score.append(torch.from_numpy(tables.score_vec(vec=upd, eps=eps)).float())
-    R = torch.stack(R).to(dev)
+    rot_sigma_h = rot_sigma.cpu().numpy()
+    upds, rot_score = np.empty((B, 3)), np.empty((B, 3))
+    for b in range(B):  # the numpy stream is consumed system by system, as the reference does
+        eps = float(rot_sigma_h[b])
+        upds[b] = tables.sample_vec(eps=eps)
+        rot_score[b] = tables.score_vec(vec=upds[b], eps=eps)
+    R = torch.from_numpy(axis_angle_to_matrix_batch(upds).astype(np.float32)).to(dev)
     rel = batch.pos[ads] - center[bidx]
     new_ads = torch.einsum("nj,nij->ni", rel, R[bidx]) + noise[bidx] + center[bidx]
     new_ads[:, -1] += 1  # the reference lifts the noised adsorbate by 1 A
     batch.pos = batch.pos.clone()
     batch.pos[ads] = new_ads
     batch.tr_sigma, batch.rot_sigma = tr_sigma[:, None], rot_sigma[:, None]
-    batch.rot_score = torch.stack(rot_score).to(dev)
+    batch.rot_score = torch.from_numpy(rot_score.astype(np.float32)).to(dev)
     batch.ads_center_noise_vec = noise
     batch.tr_score = -noise / tr_sigma[:, None] ** 2
     return batch
