@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256) void tr_wgrad_kernel(const float* __restrict__
 // value feeds two MFMAs and a staged row serves twice as many; rows are staged with 16-byte loads.  A 32-column block of
 // the A chunk that is entirely zero is skipped (exactly the same sums): the radial basis rows of rbf_proj's weight
 // gradient - 5 M edge rows, the largest product of the step - are zero outside +-14 centres of the edge's distance, and
-// consecutive edges of a target are sorted by distance.
+// consecutive edges of a target are sorted by distance.  (Measured: walking the edges in GLOBAL order of their length - a
+// radix sort per step, rows gathered through an index - narrows the window of a chunk to one row's, but every workgroup
+// then reads its 512-byte slice of scattered 6 KB rows: 835 vs 837 graphs/s, no gain; not kept.)
 __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A,
                                                            int lda, float* __restrict__ part, int M, int N, int K,
                                                            int rows_per_split, int tiles_k, float* __restrict__ bpart) {
