@@ -42,10 +42,11 @@ __device__ __forceinline__ float tr_dssilu(float x) {
 }
 
 // ------------------------------------------------------------------------------------------------ linear layers
-// C = A W^T (+ bias) of the forward.  Default: the f16x3 split GEMM of the sampling path (gemm16.hip; ~1e-6 relative on
-// O(1) activations; the data-gradient GEMMs stay exact f32: their operands are ~1e-6 and would need a scale) with the weight
-// split per call - in training the weights change every step; the hi/lo image lives in a per-device scratch that
-// consecutive calls on one stream reuse in order.  ADF_TRAIN_GEMM=f32 selects the exact-f32 MFMA GEMM (gemm.hip).
+// C = A W^T (+ bias): the f16x3 split GEMM of the sampling path (gemm16.hip) with the same per-row power-of-two lifts
+// (every A row is measured by adf_launch_rowmag and lifted before the split: activations of any magnitude, and the
+// ~1e-6 gradient rows of the data-gradient products, keep both fp16 terms) and the weight split per call - in training
+// the weights change every step; the hi/lo image and the row magnitudes live in per-device scratch that consecutive
+// calls on one stream reuse in order.  ADF_TRAIN_GEMM=f32 selects the exact-f32 MFMA GEMM (gemm.hip) everywhere.
 static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, long long M, int N,
                        int K, hipStream_t s) {
     static int mode = -1;
@@ -69,12 +70,26 @@ static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bia
         }
         cap[dev] = want;
     }
+    static float* mag[16] = {};
+    static long long mag_cap[16] = {};
+    if (M > mag_cap[dev]) {
+        ADF_HIP_CHECK(hipDeviceSynchronize());
+        if (mag[dev]) (void)hipFree(mag[dev]);
+        mag[dev] = nullptr; mag_cap[dev] = 0;
+        const long long want = M + M / 4 + 1024;
+        if (hipMalloc(reinterpret_cast<void**>(&mag[dev]), sizeof(float) * (size_t)want) != hipSuccess) {
+            (void)hipGetLastError();
+            return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
+        }
+        mag_cap[dev] = want;
+    }
     adf_w16 w16;
     w16.hi = buf[dev]; w16.lo = buf[dev] + n * 2;
     w16.inv_scale = reinterpret_cast<float*>(buf[dev] + n * 4);
     w16.bias_perm = nullptr;
     ADF_TRY(adf_split_weight(W, (long long)n, &w16, reinterpret_cast<unsigned int*>(buf[dev] + n * 4 + 16), s));
-    return adf_launch_gemm16(A, lda, &w16, bias, C, ldc, (int)M, N, K, 0, s);
+    const adf_lift lf = {mag[dev], mag_cap[dev]};
+    return adf_launch_gemm16(A, lda, &w16, bias, C, ldc, (int)M, N, K, 0, s, nullptr, 0, &lf);
 }
 
 __global__ void tr_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
@@ -312,11 +327,11 @@ extern "C" int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W
         if (N % 32 == 0) {
             hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(32, 8), 0, s, W, Wt, N, K);
             if (!acc_dA) {
-                // exact f32: gradients are ~1e-6 and would sit in the fp16 subnormal range of the unscaled f16x3 split
-                ADF_TRY(adf_launch_gemm(dC, ldc, Wt, N, nullptr, dA, ldda, (int)M, K, N, 0, s));
+                // dA = dC Wt^T through the same lifted f16x3 product (rows of dC are ~1e-6: the lift keeps both fp16 terms)
+                ADF_TRY(tr_gemm(dC, ldc, Wt, nullptr, dA, ldda, M, K, N, s));
             } else {
                 float* tmp = part + (size_t)64 * ((size_t)N * K + N);  // [M,K]
-                ADF_TRY(adf_launch_gemm(dC, ldc, Wt, N, nullptr, tmp, K, (int)M, K, N, 0, s));
+                ADF_TRY(tr_gemm(dC, ldc, Wt, nullptr, tmp, K, M, K, N, s));
                 hipLaunchKernelGGL(tr_add_rows_kernel, dim3(tr_grid(M * K)), dim3(256), 0, s, tmp, K, dA, ldda, (long long)M, K);
             }
         } else if (N <= 4) {

@@ -538,7 +538,7 @@ def main_train(args, rank, world, dev):
                       "all-reduce + AdamW + EMA)",
             "value": graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (forward products f16x3-split MFMA, gradient products exact-f32 MFMA)", "data": "synthetic",
+            "dtype": "f32 (forward and data-gradient products f16x3-split MFMA with per-row lifts, weight-gradient products exact-f32 MFMA)", "data": "synthetic",
             "config": {"workload": "BASELINE config 5: PaiNN score-matching step, %d graphs x 200 atoms per GPU and step"
                                    % args.systems,
                        "graphs_per_gpu_and_step": args.systems,
@@ -547,14 +547,14 @@ def main_train(args, rank, world, dev):
             "grad_norm": float(out["grad_norm"]) if out.get("grad_norm") is not None else None,
             "allreduce_ms_per_step": ar_ms if world > 1 else 0.0,
             "gradient_bytes": grad_bytes,
-            "roofline": {"kernel": "whole step: dense products of forward + backward (weight-gradient and data-gradient "
-                                   "GEMMs in exact-f32 MFMA dominate: profiles/r02_train_step_kernel_stats.csv)",
+            "roofline": {"kernel": "whole step: dense products of forward + backward (the exact-f32 weight-gradient kernel "
+                                   "dominates: profiles/r03_train_bench_kernel_stats.csv)",
                          "bound": "mfma", "achieved": step_flops * world * args.steps / elapsed / 1e12 / world,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": step_flops * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "note": "achieved = 3 x the forward's dense flops (SURVEY 8d: 34.6 GFLOP per graph) per graph and "
-                                 "step / wall time per step, per GPU; priced against the f32 matrix peak because the "
-                                 "gradient products run in exact f32"},
+                                 "step / wall time per step, per GPU; priced against the f32 matrix peak because the dominant "
+                                 "(weight-gradient) products run in exact f32"},
         }
         print(json.dumps(out_line), flush=True)
     if world > 1:
