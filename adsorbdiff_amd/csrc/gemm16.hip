@@ -512,7 +512,9 @@ int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int 
     return ADF_OK;
 }
 
-// row magnitudes for a launcher: the caller's (premag), or measured into lf->buf, or none
+// row magnitudes for a launcher: the caller's (premag), or measured into lf->buf, or none.  (Measured alternative: every
+// workgroup measuring its own A panel in a prologue - no separate pass, same bits: 231.2 vs 233.5 sites/s at 1000 systems,
+// 473 vs 493 it/s at B = 1: the panel is re-read by each of its 2-8 column tiles and the prologue is serial; not kept.)
 static int32_t lift_mags(const float* A, int lda, int K1, const float* A2, int K2, long long rows, const adf_lift* lf,
                          const float* premag, const float** out, hipStream_t s, const int32_t* m_dev = nullptr, int m_mul = 1) {
     *out = premag;
