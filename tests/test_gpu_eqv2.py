@@ -273,6 +273,29 @@ def test_eqv2_forward_is_run_to_run_and_batch_independent():
     assert torch.equal(h1, f1[:n0]) and torch.equal(h2, f2[:n0])
 
 
+def test_eqv2_error_contract():
+    """The reference's exceptions on this path: an image without neighbours raises ValueError (models/base.py via
+    generate_graph; message "An image has no neighbors"), an atomic number outside the embedding / radius tables raises
+    ValueError instead of reading out of bounds; the sticky device flags are cleared by the failed check."""
+    from adsorbdiff_amd.synthetic import make_batch
+
+    m = make_model(4, 2, C=8, hidden=8, heads=2, alpha=4, value=4, ffn=16, ec=8, layers=1, cutoff=2.0).to(DEV)
+    far = make_batch(1, n_slab=16, n_ads=1, seed=3)
+    far.pos = far.pos * 0 + torch.arange(far.pos.shape[0]).float()[:, None] * 40.0  # everything far apart
+    far.cell = far.cell * 50
+    with pytest.raises(ValueError, match="no neighbors"):
+        m(far.to(DEV))
+    m2 = make_model(4, 2, C=8, hidden=8, heads=2, alpha=4, value=4, ffn=16, ec=8, layers=1, cutoff=12.0).to(DEV)
+    b = safe_batch(1, 36, seed=5)
+    bad = b.clone()
+    bad.atomic_numbers = bad.atomic_numbers.clone()
+    bad.atomic_numbers[0] = 200
+    with pytest.raises(ValueError, match="atomic number"):
+        m2(bad.to(DEV))
+    f1, _ = m2(b.to(DEV))  # the flags were cleared
+    assert bool(torch.isfinite(f1).all())
+
+
 def test_eqv2_distance_basis_path_vs_oracle():
     """Radii small enough for the Gaussian distance basis to be non-zero (the table divided by 100: what the
     reference's discarded `/ 100` would have produced, equiformer_v2_denoising.py:168-169): the per-edge radial path
