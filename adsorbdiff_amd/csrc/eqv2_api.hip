@@ -405,6 +405,11 @@ static int32_t eq_radial_static(adf_eqv2* h, eq_radial** rads, int nrad, hipStre
     }
     float* keep_rs = h->rs; const int64_t keep_cap = h->rs_cap;
     h->rs = rs; h->rs_cap = rows;
+    // The tables are built ONCE per weight binding and are then read by both arithmetics (adf_eqv2_set_arithmetic only flips
+    // a flag), so they are always evaluated in exact f32: an exact-f32 forward must not multiply by f16x3-evaluated tables
+    // (NE^2 rows: the cost is negligible).
+    const bool keep_exact = h->exact_f32;
+    h->exact_f32 = true;
     float* p = h->rtab_arena;
     int32_t st = ADF_OK;
     for (int i = 0; i < nrad && st == ADF_OK; ++i) {
@@ -420,6 +425,7 @@ static int32_t eq_radial_static(adf_eqv2* h, eq_radial** rads, int nrad, hipStre
         p += (size_t)rows * r->l6.out;
     }
     (void)hipStreamSynchronize(s);
+    h->exact_f32 = keep_exact;
     h->rs = keep_rs; h->rs_cap = keep_cap;
     eq_free(t1); eq_free(t2); eq_free(rs);
     if (st != ADF_OK) { for (int i = 0; i < nrad; ++i) rads[i]->table = nullptr; return st; }

@@ -280,15 +280,37 @@ class EquiformerV2S_OC20_DenoisingPos(nn.Module):
                     out.append(mname + "." + pname)
         return set(out)
 
+    # constant buffers of the reference's modules (functions of the hyper-parameters only; rebuilt by the engine):
+    # S2 grid matrices (so3.py:566-599), CoefficientMapping tables (so3.py:22-115), SO3_LinearV2.expand_index
+    # (so3.py:694-745), the equivariant norm's balance_degree_weight (layer_norm.py), GaussianSmearing.offset
+    _CONST_BUFFER_SUFFIXES = ("to_grid_mat", "from_grid_mat", "expand_index", "balance_degree_weight",
+                              "distance_expansion.offset", "l_harmonic", "m_harmonic", "m_complex", "res_size", "m_size",
+                              "to_m")
+
     def load_state_dict(self, state_dict, strict: bool = True):
         """Reference checkpoints also carry constant buffers (S2 grid matrices, index tables, Gaussian offsets): they are
-        functions of the hyper-parameters and are rebuilt here, so only the parameters are taken."""
-        own = set(self.state_dict().keys())
-        kept = {k: v for k, v in state_dict.items() if k in own}
-        missing = sorted(own - set(kept) - {"atom_radii"})  # a constant table, not a learned tensor
-        if strict and missing:
-            raise RuntimeError(f"missing parameters in state_dict: {missing[:8]}{'...' if len(missing) > 8 else ''}")
-        return super().load_state_dict(kept, strict=False)
+        functions of the hyper-parameters and are rebuilt here, so exactly THOSE keys are ignored.  Under ``strict`` any
+        other unexpected key (a checkpoint of another configuration: more blocks, ``energy_embedding.*`` ...), any missing
+        parameter and any shape mismatch raises, like ``nn.Module.load_state_dict``.  ``atom_radii`` (a frozen Parameter
+        in the reference, equiformer_v2_denoising.py:165-169) is loaded when present and may be absent: it is a constant
+        table."""
+        own = self.state_dict()
+        const = {k for k in state_dict if k not in own and k.endswith(self._CONST_BUFFER_SUFFIXES)}
+        unexpected = sorted(k for k in state_dict if k not in own and k not in const)
+        missing = sorted(k for k in own if k not in state_dict and k != "atom_radii")
+        mismatched = sorted(k for k in own if k in state_dict and tuple(state_dict[k].shape) != tuple(own[k].shape))
+        if strict and (unexpected or missing or mismatched):
+            def head(v):
+                return f"{v[:6]}{'...' if len(v) > 6 else ''}"
+            raise RuntimeError("Error(s) in loading state_dict for EquiformerV2S_OC20_DenoisingPos: "
+                               + (f"unexpected keys {head(unexpected)}; " if unexpected else "")
+                               + (f"missing keys {head(missing)}; " if missing else "")
+                               + (f"size mismatch for {head(mismatched)}" if mismatched else ""))
+        kept = {k: v for k, v in state_dict.items() if k in own and k not in mismatched}
+        res = super().load_state_dict(kept, strict=False)
+        from torch.nn.modules.module import _IncompatibleKeys
+
+        return _IncompatibleKeys([k for k in res.missing_keys if k != "atom_radii"] + mismatched, unexpected)
 
     def engine(self, device=None):
         from .eqv2_engine import EqV2Engine

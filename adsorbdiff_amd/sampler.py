@@ -151,14 +151,19 @@ def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=
     ids = torch.arange(local.shape[0], dtype=torch.int32) if system_ids is None else torch.as_tensor(system_ids, dtype=torch.int32)
     if ids.numel() != local.shape[0]:
         raise ValueError("every rank must pass one id per local system")
-    packed = torch.full((Bmax, 1 + 3 * Amax), float("nan"), dtype=torch.float32, device=dev)
-    packed[:, 0] = torch.full((Bmax,), -1, dtype=torch.int32, device=dev).view(torch.float32)
-    packed[: local.shape[0], 0] = ids.to(dev).view(torch.float32)
-    packed[: local.shape[0], 1 : 1 + 3 * local.shape[1]] = local.reshape(local.shape[0], -1).to(torch.float32)
+    # The exchange buffer is INT32: ids as they are (-1 = padding), sites as their float32 bit patterns (a float -> int
+    # reinterpretation is lossless on every copy path, whereas ids stored as float bits would be denormals / NaN payloads
+    # that a flush-to-zero or NaN-canonicalising copy could alter).  Padding sites are NaN bit patterns.
+    nan_bits = int(torch.tensor([float("nan")], dtype=torch.float32).view(torch.int32)[0])
+    packed = torch.full((Bmax, 1 + 3 * Amax), nan_bits, dtype=torch.int32, device=dev)
+    packed[:, 0] = -1
+    packed[: local.shape[0], 0] = ids.to(dev)
+    packed[: local.shape[0], 1 : 1 + 3 * local.shape[1]] = (
+        local.reshape(local.shape[0], -1).to(torch.float32).contiguous().view(torch.int32))
     everything = all_gather(packed.contiguous())                       # the one exchange: [world, B_max, 1 + 3 A_max]
-    gid = everything[:, :, 0].contiguous().view(torch.int32)
+    gid = everything[:, :, 0]
     keep = gid >= 0
-    sites = everything[:, :, 1:].reshape(world, Bmax, Amax, 3)[keep].to(local.dtype)
+    sites = everything[:, :, 1:].contiguous().view(torch.float32).reshape(world, Bmax, Amax, 3)[keep].to(local.dtype)
     if system_ids is None:
         return sites                                                   # rank-major
     return sites[torch.argsort(gid[keep].to(torch.int64))]

@@ -114,29 +114,33 @@ class DenoisingTrainer:
         self.train_engine.zero_grad()
         loss = self.train_engine.loss_and_grad(batch, targets)
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        # NaN policy of the reference loop (sde_denoising_trainer.py:425-440): a step with a NaN loss is skipped (counted;
-        # more than 10 in a row stop the training), a loss above 1e6 stops it.  All ranks must take the same branch, so
-        # the flag is reduced over the ranks first (one scalar); the fused optimizer additionally turns an update with
-        # a non-finite gradient norm into a no-op on the device (csrc/train.hip: tr_adamw_kernel).
-        bad = (~torch.isfinite(loss.detach()).all()).to(torch.float32).reshape(1)
+        # NaN policy of the reference loop (sde_denoising_trainer.py:428-440), mirrored: a step whose loss is NaN is
+        # skipped (`continue`: warning, no update; the reference's `nan_count > 10` test sits behind the reset and can never
+        # fire, so there is no such stop here either); a loss above 1e6 - an Inf loss included, isnan() is False for it -
+        # logs a warning and STOPS the epoch loop (`break`): returned as "stop": True, never raised.  All ranks must take
+        # the same branch, so ONE two-element flag (NaN, too high) is MAX-reduced over the ranks and read back once; the
+        # fused optimizer additionally turns an update with a non-finite gradient norm into a no-op on the device
+        # (csrc/train.hip: tr_adamw_kernel).
+        l0 = loss.detach().reshape(-1)
+        flag = torch.stack([torch.isnan(l0).any(), l0[0] > 1e6]).to(torch.int32)
         if world > 1:
-            bad_r = bad if dist.get_backend() != "gloo" else bad.cpu()
-            dist.all_reduce(bad_r, op=dist.ReduceOp.MAX)
-            bad = bad_r.to(bad.device)
-        if bool(bad.item()):
+            flag = flag if dist.get_backend() != "gloo" else flag.cpu()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        is_nan, too_high = (bool(v) for v in flag.tolist())    # the step's single device-to-host read
+        if is_nan:
             logging.warning("NaN loss detected, skipping step")
             self.nan_count = getattr(self, "nan_count", 0) + 1
             self.train_engine.zero_grad()
-            if self.nan_count > 10:
-                raise FloatingPointError("Too many NaN losses, stopping training")
-            return {"loss": loss, "grad_norm": None, "skipped": True}
+            return {"loss": loss, "grad_norm": None, "skipped": True, "stop": False}
         self.nan_count = 0
-        if float(loss.detach().reshape(-1)[0]) > 1e6:
-            raise FloatingPointError(f"Loss too high: {float(loss.detach().reshape(-1)[0])}")
+        if too_high:
+            logging.warning("Loss too high: %s", float(l0[0]))
+            self.train_engine.zero_grad()
+            return {"loss": loss, "grad_norm": None, "skipped": True, "stop": True}
         allreduce_gradients(self._unwrapped_model, world)
         grad_norm = self.optimizer.step()
         self.step += 1
-        return {"loss": loss, "grad_norm": grad_norm, "skipped": False}
+        return {"loss": loss, "grad_norm": grad_norm, "skipped": False, "stop": False}
 
     # ---------------------------------------------------------------- checkpoint ingest
     def load_checkpoint(self, checkpoint_path: str) -> None:

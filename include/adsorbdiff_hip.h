@@ -132,8 +132,10 @@ int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32);
  * neighbour's, or its in-edge list / geometry, compared bit for bit with the previous build — changed since the row
  * was computed.  Every output is bit-identical to a full forward; the reference recomputes everything every step
  * (denoising_torch.py:498 -> painn_denoising.py:460-471).  Costs about 110 KB of HBM per atom (H=512, 6 layers).
- * An incremental forward reads the lengths of its recompute lists back once (52 bytes, one stream synchronisation);
- * with the feature off a forward is enqueued without any host round trip (what a hipGraph capture needs).
+ * The lengths of the recompute lists stay on the device: list-mode launches are sized for all N rows and every kernel
+ * of a layer reads its row count from device memory; the host sees the counts one forward late (pinned double buffer
+ * behind an event it polls without waiting) and uses them only to choose between the list and the all-rows form of a
+ * layer - an incremental forward synchronises nothing (ADF_INC_SYNC=1 restores a synchronous 52-byte read-back).
  * Calling this (with either value) drops the kept state and zeroes the counters adf_get_counters reports. */
 int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on);
 

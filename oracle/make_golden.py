@@ -574,6 +574,134 @@ def main_eqv2():
     print("EquiformerV2 goldens written to", GOLD)
 
 
+CFG4_KW = dict(max_neighbors=20, max_radius=12.0, max_num_elements=90, num_layers=8, sphere_channels=128,
+               attn_hidden_channels=64, num_heads=8, attn_alpha_channels=64, attn_value_channels=16,
+               ffn_hidden_channels=128, norm_type="layer_norm_sh", lmax_list=[6], mmax_list=[2], grid_resolution=18,
+               edge_channels=128, attn_activation="silu", ffn_activation="silu", use_s2_act_attn=False,
+               use_attn_renorm=True, use_gate_act=False, use_grid_mlp=True, use_sep_s2_act=True, alpha_drop=0.0,
+               drop_path_rate=0.0, proj_drop=0.0, weight_init="uniform", FOR_denoising=True)
+CFG4_EMB_SCALE = 300.0   # edge embeddings lifted from the 1e-3 initialisation to trained-like magnitudes
+CFG4_ATOM_STRIDE, CFG4_CH_STRIDE = 7, 8
+
+
+def main_eqv2_cfg4():
+    # ---------------------------------------------------------------- 7b. EquiformerV2 at the BASELINE config-4 width
+    # configs/denoising/eqv2_so3.yml:40-75 with lmax_list [6] (BASELINE.json config 4): C=128, 8 heads, hidden 64,
+    # alpha 64, value 16, ffn 128, edge channels 128, 8 blocks, K=20, 12 A.  One 200-atom synthetic system (the
+    # benchmark's shape; in-plane cell > cutoff, so no exactly tied self-images).  The 31 M weights are NOT stored: every
+    # parameter with two or more dimensions is refilled by tests/helpers.py::refill_parameters_by_name (a function of the
+    # parameter's name and shape only, magnitudes of the reference's `weight_init: uniform`; edge embeddings lifted to
+    # trained-like magnitudes); biases and norm gains keep their constructor constants, equal in the reference and the
+    # mirror class (asserted here).  Stored: inputs, the reference's edge list, (f1, f2), and for the node
+    # embedding after the edge-degree embedding and after every block a strided sample plus per-degree norms.
+    from oracle.refshim import e3nn_standin as E3
+
+    E3.install(sys.modules)
+    from adsorbdiff.models.equiformer_v2.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos as RefEqV2
+
+    from adsorbdiff_amd.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos as MyEqV2
+    from oracle import eqv2_oracle as Q
+
+    torch.set_num_threads(8)
+
+    from tests.helpers import refill_parameters_by_name
+
+    torch.manual_seed(0)
+    eq = refill_parameters_by_name(RefEqV2(None, None, None, **CFG4_KW).eval(), CFG4_EMB_SCALE)
+    torch.manual_seed(0)
+    mine = refill_parameters_by_name(MyEqV2(None, None, None, **CFG4_KW).eval(), CFG4_EMB_SCALE)
+    rp, mp = dict(eq.named_parameters()), dict(mine.named_parameters())
+    assert list(rp) == list(mp)
+    bad_names = [k for k in rp if k != "atom_radii" and not torch.equal(rp[k], mp[k])]
+    assert not bad_names, ("mirror weights differ from the reference's", bad_names[:5])
+    nparams = sum(p.numel() for p in eq.parameters())
+    b = make_batch(1, seed=9)
+    bad = set(torch.nonzero(torch.isnan(eq.atom_radii)).flatten().tolist())
+    z = b.atomic_numbers.clone()
+    for zb in bad:
+        z[z == zb] = 47.0
+    b.atomic_numbers = z
+    rec = {}
+    hooks = [eq.edge_degree_embedding.register_forward_hook(lambda m_, i_, o_: rec.__setitem__("ed", o_.embedding.detach().clone()))]
+    for bi_, blk_ in enumerate(eq.blocks):
+        hooks.append(blk_.register_forward_hook(lambda m_, i_, o_, bi_=bi_: rec.__setitem__(bi_, o_.embedding.detach().clone())))
+    import time as _t
+    t0 = _t.perf_counter()
+    torch.manual_seed(1)
+    with torch.no_grad():
+        f1, f2 = eq(b.clone())
+    print(f"[eqv2 cfg4] reference forward: {_t.perf_counter() - t0:.1f} s, {nparams} parameters")
+    for h_ in hooks:
+        h_.remove()
+    x0 = rec["ed"].clone()
+    x0[:, 0] = x0[:, 0] + eq.sphere_embedding(b.atomic_numbers.long()).detach()
+    xb = torch.stack([x0] + [rec[i] for i in range(CFG4_KW["num_layers"])])      # [9, N, 49, 128]
+    assert bool(torch.isfinite(f1).all()) and bool(torch.isfinite(xb).all())
+    gq = eq.generate_graph(b.clone(), enforce_max_neighbors_strictly=True)
+    # the oracle restatement at this width, on the reference's edge list
+    hp_q = dict(lmax=6, mmax=2, num_layers=8, sphere_channels=128, attn_hidden_channels=64, num_heads=8,
+                attn_alpha_channels=64, attn_value_channels=16, ffn_hidden_channels=128, grid_resolution=18,
+                max_radius=12.0, max_neighbors=20)
+    sd_q = {k: v.detach().clone() for k, v in eq.state_dict().items()}
+    with torch.no_grad():
+        q1, q2 = Q.eqv2_forward(sd_q, hp_q, b.pos, b.atomic_numbers, b.cell, b.natoms, graph=(gq[0], gq[2]))
+    e1, e2 = float((q1 - f1).norm() / f1.norm()), float((q2 - f2).norm() / f2.norm())
+    print(f"[eqv2 cfg4] oracle vs reference rel err {e1:.2e} / {e2:.2e}")
+    assert e1 < 1e-5 and e2 < 1e-5
+    # the oracle's own graph builder finds the same edges (no ties in this cell)
+    own = Q.radius_graph_pbc(b.pos, b.cell, b.natoms, 12.0, 20)
+    own_ei, own_d, _, _ = Q.pbc_distances(b.pos, own[0], b.cell, own[1], own[2])
+    key = lambda ei_, d_: sorted((int(a_), int(b_), round(float(c_), 4)) for a_, b_, c_ in zip(ei_[0], ei_[1], d_))
+    assert key(own_ei, own_d) == key(gq[0], gq[1])
+    L = 6
+    norms = torch.stack([torch.stack([xb[k, :, l * l:(l + 1) ** 2].double().norm() for l in range(L + 1)])
+                         for k in range(xb.shape[0])])
+    fx = dict(f1=f1, f2=f2, x_blocks_sample=xb[:, ::CFG4_ATOM_STRIDE, :, ::CFG4_CH_STRIDE].contiguous(),
+              x_blocks_degree_norms=norms, atom_stride=CFG4_ATOM_STRIDE, channel_stride=CFG4_CH_STRIDE,
+              emb_scale=CFG4_EMB_SCALE, lmax=6, mmax=2, n_params=nparams,
+              edge_index=gq[0], edge_vec=gq[2], **batch_inputs(b))
+    np.savez_compressed(GOLD / "eqv2_cfg4.npz", **npify(fx))
+    print(f"[eqv2 cfg4] |f1|max={f1.abs().max():.4e} |f2|max={f2.abs().max():.4e}; written")
+
+
+def main_painn_tagz():
+    # ---------------------------------------------------------------- 2c. tag_based_Z is a no-op
+    # painn_denoising.py:156-168 means to add 100 to the atomic numbers of C/N/O/H atoms of the slab (tags < 2) but
+    # `data.tags < 2 & (...)` parses as `tags < (2 & mask)`, i.e. all-False: the atomic numbers are unchanged.  This
+    # fixture puts H, C, N and O atoms INTO the slab (tags 0 and 1): the reference's own forward pins the no-op (a
+    # fired Z+100 would index past the 83-row embedding table).
+    torch.set_num_threads(8)
+    hp = dict(hidden_channels=128, num_layers=2, num_rbf=128, cutoff=6.0, max_neighbors=20)
+    scales = [1.0, 0.93]
+    torch.manual_seed(21)
+    ref = RefPaiNN(None, 50, 1, scale_file={"upd_out_scalar_scale_0": scales[0], "upd_out_scalar_scale_1": scales[1]},
+                   so3_denoising=True, **hp).eval()
+    b = make_batch(2, n_slab=24, n_ads=4, seed=31)
+    z = b.atomic_numbers.clone()
+    slab = torch.nonzero(b.tags < 2).flatten()
+    for j, zz in enumerate((1, 6, 7, 8, 1, 6, 7, 8)):          # four in the lower half (tag 0), four in the upper (tag 1)
+        cand = slab[b.tags[slab] == (j // 4)]
+        z[cand[(3 * j + 1) % len(cand)]] = float(zz)
+    b.atomic_numbers = z
+    n_light = int(((b.tags < 2) & ((z == 1) | (z == 6) | (z == 7) | (z == 8))).sum())
+    assert n_light >= 6, n_light
+    z_after = ref.tag_based_Z(b.clone()).atomic_numbers   # the reference's own method: unchanged atomic numbers
+    assert torch.equal(z_after, b.atomic_numbers)
+    with torch.no_grad():
+        f1, f2 = ref(b.clone())
+    sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+    o1, o2 = O.painn_forward(sd, b.pos, b.atomic_numbers, b.cell, b.natoms, scale_factors=scales, **hp)
+    d1, d2 = float((o1 - f1).abs().max()), float((o2 - f2).abs().max())
+    print(f"[painn tagz] {n_light} H/C/N/O slab atoms; oracle vs reference max abs diff {d1:.2e} / {d2:.2e}")
+    assert d1 < 1e-6 and d2 < 1e-6
+    fx = dict(f1=f1, f2=f2, n_light_slab_atoms=n_light, scale_factors=np.array(scales), **batch_inputs(b))
+    fx["z_after_tag_based_Z"] = z_after.detach().clone()
+    for k, v in hp.items():
+        fx["hp_" + k] = v
+    fx.update({"sd::" + k: v for k, v in sd.items() if k != "atom_radii"})
+    np.savez_compressed(GOLD / "painn_tagz.npz", **npify(fx))
+
+
 def main_handoff():
     # ---------------------------------------------------------------- 8. hand-off lift rule and input-side balancing
     # (SURVEY 8f-3 / 8f-4).  The lift block of scripts/create_lmdbs/pred_traj_to_lmdb.py (a script with module-level
@@ -800,7 +928,7 @@ def main_train_full():
 
 
 def main():
-    """ADF_GOLDEN_ONLY=eqv2 / painn / painn_scaled / handoff / train_full regenerates one family (all are deterministic)."""
+    """ADF_GOLDEN_ONLY=eqv2 / eqv2_cfg4 / painn / painn_scaled / painn_tagz / handoff / train_full regenerates one family (all are deterministic)."""
     only = os.environ.get("ADF_GOLDEN_ONLY")
     if only in (None, "", "painn"):
         main_painn()
@@ -808,6 +936,10 @@ def main():
         main_painn_scaled()
     if only in (None, "", "eqv2"):
         main_eqv2()
+    if only in (None, "", "eqv2", "eqv2_cfg4"):
+        main_eqv2_cfg4()
+    if only in (None, "", "painn", "painn_tagz"):
+        main_painn_tagz()
     if only in (None, "", "handoff"):
         main_handoff()
     if only in (None, "", "train_full"):

@@ -1,5 +1,6 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"; export TMPDIR=/tmp
 o=gpurun_out/eq_stats; rm -rf $o; mkdir -p $o
 rocprofv3 --kernel-trace --stats -d /tmp/eqs -o eq --output-format csv -- python3 bench.py --model eqv2 --systems 64 --steps 1 --warmup 0 --num-steps 10 --no-cpu-baseline > $o/log.txt 2>&1
 cp $(find /tmp/eqs -name "*kernel_stats.csv" | head -1) $o/kernel_stats.csv

@@ -1,6 +1,7 @@
 #!/bin/bash
 # per-kernel cost of the per-row lifts: kernel stats of 10 full-row reverse steps with and without them
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"; export TMPDIR=/tmp
 o=gpurun_out/lift_cost; rm -rf $o; mkdir -p $o
 for lift in 1 0; do
   ADF_LIFT=$lift rocprofv3 --kernel-trace --stats -d /tmp/lc_$lift -o lc --output-format csv -- python3 bench.py --no-cpu-baseline --no-secondary --no-incremental --steps 1 --warmup 0 --num-steps 10 > $o/log_$lift.txt 2>&1

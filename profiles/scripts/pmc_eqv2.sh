@@ -1,6 +1,7 @@
 #!/bin/bash
 # per-kernel memory-unit counters of one EquiformerV2 forward (64 systems); raw output stays in /tmp, summaries come back
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"; export TMPDIR=/tmp
 o=gpurun_out/pmc_eqv2; mkdir -p $o
 i=0
 for set in "MemUnitStalled WriteUnitStalled" "L2CacheHit VALUBusy" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round-3 profile set (run on the GPU box): bench lines, rocprofv3 kernel stats of the same commands, PMC passes
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"; export TMPDIR=/tmp
 o=gpurun_out/r03; rm -rf $o; mkdir -p $o
 python3 bench.py > $o/bench.json 2> $o/bench.err
 python3 bench.py --mode train > $o/bench_train.json 2> $o/bench_train.err

@@ -1,5 +1,6 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/trs -o tr --output-format csv -- python3 bench.py --mode train --steps 3 --warmup 1 > /tmp/trs.log 2>&1
 mkdir -p gpurun_out/train_stats; cp $(find /tmp/trs -name "*kernel_stats.csv" | head -1) gpurun_out/train_stats/tr_kernel_stats.csv
 python3 - <<'PY'

@@ -56,3 +56,29 @@ def max_abs_err_rel_to_max(a, b):
     """max |a - b| / max row norm of b: the per-atom heads bounded element-wise against the largest atom."""
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
     return float((a - b).abs().max() / b.reshape(b.shape[0], -1).norm(dim=1).max().clamp(min=1e-30))
+
+
+def refill_parameters_by_name(model, emb_scale=300.0):
+    """Deterministic weights that depend on (parameter name, shape) only — not on the order in which a class draws its
+    initial values — so that the reference model in oracle/make_golden.py and the mirror class in a test hold the SAME
+    31 M weights without storing them.  Magnitudes follow the reference's `weight_init: uniform`
+    (equiformer_v2_oc20.py `_uniform_init_linear_weights`: U(-1/sqrt(fan_in), 1/sqrt(fan_in))); the atom edge embeddings
+    (U(-1e-3, 1e-3) in the reference) are lifted by `emb_scale` to trained-like magnitudes; parameters with fewer than two
+    dimensions (biases, norm gains: constants in both classes) are left as constructed."""
+    import math
+    import zlib
+
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters()):
+            if p.dim() < 2 or name == "atom_radii":
+                continue
+            g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+            u = torch.rand(p.shape, generator=g, dtype=torch.float32) * 2.0 - 1.0
+            if name.endswith("source_embedding.weight") or name.endswith("target_embedding.weight"):
+                a = 1e-3 * emb_scale
+            elif name == "sphere_embedding.weight":
+                a = math.sqrt(3.0)
+            else:
+                a = 1.0 / math.sqrt(p.shape[-1])
+            p.copy_(u * a)
+    return model

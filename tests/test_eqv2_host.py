@@ -103,3 +103,44 @@ def test_mirror_has_the_reference_parameter_names():
                                         norm_type="rms_norm_sh", FOR_denoising=True)
     with pytest.raises(RuntimeError):  # no CPU fallback
         m(None if False else type("B", (), {"pos": torch.zeros(1, 3)})())
+
+
+def test_load_state_dict_is_strict_about_everything_but_the_constant_buffers():
+    """a checkpoint of another configuration must not load silently.  Ignored: only the reference's constant
+    buffers (grid matrices, index tables, Gaussian offsets); raised under strict: other unexpected keys, missing
+    parameters, shape mismatches."""
+    import pytest
+
+    from adsorbdiff_amd.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos as M
+
+    kw = dict(max_neighbors=20, max_radius=6.0, max_num_elements=90, num_layers=1, sphere_channels=8,
+              attn_hidden_channels=8, num_heads=2, attn_alpha_channels=4, attn_value_channels=4, ffn_hidden_channels=16,
+              norm_type="layer_norm_sh", lmax_list=[4], mmax_list=[2], grid_resolution=18, edge_channels=8,
+              num_distance_basis=16, attn_activation="silu", ffn_activation="silu", use_grid_mlp=True,
+              use_sep_s2_act=True, weight_init="uniform", FOR_denoising=True)
+    m = M(None, None, None, **kw)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    ok = dict(sd)
+    ok["SO3_grid.4.2.to_grid_mat"] = torch.zeros(3)            # constant buffers of the reference: ignored
+    ok["blocks.0.ga.so2_conv_1.mappingReduced.m_complex"] = torch.zeros(3)
+    ok["distance_expansion.offset"] = torch.zeros(16)
+    ok["blocks.0.ffn.so3_linear_1.expand_index"] = torch.zeros(25)
+    del ok["atom_radii"]                                        # a constant table: may be absent
+    res = m.load_state_dict(ok)
+    assert not res.missing_keys and not res.unexpected_keys
+    bad = dict(sd)
+    bad["blocks.1.ga.alpha_dot"] = torch.zeros(2, 4)            # a deeper checkpoint
+    with pytest.raises(RuntimeError, match="unexpected"):
+        m.load_state_dict(bad)
+    bad = dict(sd)
+    bad["energy_embedding.weight"] = torch.zeros(4, 4)          # a conditional checkpoint
+    with pytest.raises(RuntimeError, match="unexpected"):
+        m.load_state_dict(bad)
+    assert "energy_embedding.weight" in m.load_state_dict(bad, strict=False).unexpected_keys
+    bad = {k: v for k, v in sd.items() if k != "blocks.0.ga.alpha_dot"}
+    with pytest.raises(RuntimeError, match="missing"):
+        m.load_state_dict(bad)
+    bad = dict(sd)
+    bad["blocks.0.ga.alpha_dot"] = torch.zeros(3, 4)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict(bad)

@@ -278,6 +278,24 @@ def test_painn_trained_like_magnitudes_vs_reference_fixture(monkeypatch):
     assert lifted < REL_TOL
 
 
+def test_painn_tag_based_Z_no_op_vs_reference_fixture():
+    """PaiNN.tag_based_Z (painn_denoising.py:156-168) is a no-op by operator precedence.  The batch has
+    H, C, N and O atoms INSIDE the slab (tags 0 and 1); the reference's own forward on it is the fixture: the HIP path
+    must embed them with their plain atomic numbers (a "fixed" Z + 100 would leave the 83-row table)."""
+    fx = load_npz("painn_tagz.npz")
+    light = np.isin(fx["atomic_numbers"], [1, 6, 7, 8]) & (fx["tags"] < 2)
+    assert int(light.sum()) >= 6
+    m = small_model(fx)
+    b = batch_from_fixture(fx, device=DEV)
+    f1, f2 = m(b)
+    assert torch.equal(b.atomic_numbers.cpu(), torch.from_numpy(fx["atomic_numbers"]).float())  # not modified either
+    assert rel_err(f1.cpu(), fx["f1"]) < REL_TOL and rel_err(f2.cpu(), fx["f2"]) < REL_TOL
+    assert max_abs_err_rel_to_max(f1.cpu(), fx["f1"]) < REL_TOL and max_abs_err_rel_to_max(f2.cpu(), fx["f2"]) < REL_TOL
+    # the rows of the light slab atoms themselves
+    idx = torch.from_numpy(np.nonzero(light)[0])
+    assert rel_err(f1.cpu()[idx], fx["f1"][light]) < REL_TOL and rel_err(f2.cpu()[idx], fx["f2"][light]) < REL_TOL
+
+
 def test_painn_full_h512_vs_reference_fixture():
     fx = load_npz("painn_full.npz")
     torch.manual_seed(int(fx["seed"]))
