@@ -14,7 +14,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libadsorbdiff_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "graph.hip", "message.hip", "nodewise.hip", "stepper.hip", "peaks.hip", "collect.hip", "train.hip", "incremental.hip", "eqv2_kernels.hip", "eqv2_gemm16.hip", "eqv2_api.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "graph.hip", "message.hip", "message3.hip", "nodewise.hip", "stepper.hip", "peaks.hip", "collect.hip", "train.hip", "incremental.hip", "eqv2_kernels.hip", "eqv2_gemm16.hip", "eqv2_api.hip"]
 
 
 def _hipcc() -> str:
@@ -40,12 +40,14 @@ FLAGS = [
     # Packed f32 VALU math is also slower beside MFMAs (MI355X_MICROARCH.md, filler prices).
     "-fno-slp-vectorize",
 ]
+EXTRA_FLAGS = {}  # per-file additions to FLAGS
 OBJ_DIR = CSRC / "build"  # git-ignored
 
 
 def _compile_one(args):
     cc, src, obj = args
-    res = subprocess.run([cc, *FLAGS, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+    res = subprocess.run([cc, *FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)],
+                         capture_output=True, text=True)
     return src.name, res.returncode, res.stdout + res.stderr
 
 

@@ -38,39 +38,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
-#define MSG_THREADS 512
-#define MSG_WAVES 8
-#define MSG_COLS 192
-#define MSG_LDK 136  // halves per column row of the f16 weight image (128 + 8 pad: conflict-free b128 reads)
-
-struct MsgParams {
-    const float* rec;   // gather records [(N+1)][H/32][160] (gemm16.hip EPI 1 / adf_pack_records_kernel); row N zero
-    const float* vec;
-    const float* x;
-    float* x_out;
-    float* vec_out;
-    const int32_t* tlist;    // optional: targets to evaluate (ascending atom indices); outputs are then compact rows
-    int items;               // number of targets: N, or the length of tlist
-    const int32_t* items_dev;  // optional: the list length on the device (items is then its upper bound)
-    const int32_t* nptr;
-    const int32_t* e_src;
-    const float4* e_geom;
-    const float* wpack;      // f32 image  [slice][R][192]
-    const _Float16* wpack16; // f16 image  [slice][hi|lo][192][R]
-    const float* bpack;      // [slice][192] bias (f32 mode) or bias * scale (f16 mode)
-    const float* inv_scale;  // device scalar (f16 mode)
-    const float* mu;
-    int N, H, R, G, nslices;
-    float inv_cutoff, coeff, sarg, env_a, env_b, env_c;
-    float dmu2, dmusq, cstep;  // UNI: 2*dmu', dmu'^2, exp2(-2 dmu'^2) with dmu' = scaled spacing of the centres
-    int env_pi;
-    unsigned long long* kcount;  // optional: sum over 32-row blocks of the contracted k length (profiling)
-};
+#include "message.h"
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -569,6 +537,12 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
         SET_LDS(true, false, true); SET_LDS(true, true, true);
 #undef SET_LDS
     }
+    ADF_TRY(adf_message3_prepare());
+    {   // ADF_MSG_KERNEL=v3: the interleaved single-stream kernel of round 4 (message3.hip: correct, tested, currently
+        // SLOWER than this file's kernel - 9.4 vs 7.5 ms per full launch, see its header and DESIGN.md); default: this file's
+        const char* e = getenv("ADF_MSG_KERNEL");
+        h->msg_v3 = e && strcmp(e, "v3") == 0;
+    }
     return ADF_OK;
 }
 
@@ -614,6 +588,7 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
         const double d = sqrt(0.5 / (step * step) * 1.4426950408889634) * step;
         p.dmu2 = (float)(2.0 * d); p.dmusq = (float)(d * d); p.cstep = (float)exp2(-2.0 * d * d);
     }
+    if (f16 && h->rbf_uniform && h->msg_v3) return adf_message3_launch(p, h->num_cus, vec_is_zero, s);
     if (f16 && h->rbf_uniform) { if (vec_is_zero) LAUNCH_MSG(true, true, true); else LAUNCH_MSG(true, false, true); }
     else if (f16) { if (vec_is_zero) LAUNCH_MSG(true, true, false); else LAUNCH_MSG(true, false, false); }
     else { if (vec_is_zero) LAUNCH_MSG(false, true, false); else LAUNCH_MSG(false, false, false); }
