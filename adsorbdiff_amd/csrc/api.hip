@@ -969,13 +969,18 @@ extern "C" int32_t adf_sde_step_scheduled(adf_painn_t h, const adf_batch* b, flo
 // The whole reverse loop (denoising_torch.py:235-356) in one call: num_steps x (graph build + forward + step), all
 // on `stream`.  Host round trips: with poll_every > 0 the frozen flag is read back every poll_every steps and the loop
 // ends early, exactly like the reference's `break`; with incremental layers on, each forward reads its list lengths.
-extern "C" int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
-                              const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
-                              const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
-                              const int32_t* out_idx, int32_t n_out, float* f1, float* f2, void* stream) {
+struct adf_frames;
+int32_t adf_frames_push_impl(adf_frames* f, const float* src, hipStream_t s);
+
+static int32_t sample_impl(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                           const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
+                           const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
+                           const int32_t* out_idx, int32_t n_out, float* f1, float* f2, adf_frames* sink,
+                           int32_t frame_every, void* stream) {
     ADF_TRY(check_batch(h, b));
     if (num_steps <= 0 || !f1 || !f2 || !state || !coefs_dev || !pos || !tags) { adf_set_error("sample: bad argument"); return ADF_EINVAL; }
     if ((z_tr_all == nullptr) != (z_rot_all == nullptr)) { adf_set_error("sample: need both noise tables or none"); return ADF_EINVAL; }
+    if (sink && frame_every <= 0) { adf_set_error("sample: frame_every must be positive"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const size_t zs = (size_t)b->num_systems * 3;
     for (int t = 0; t < num_steps; ++t) {
@@ -983,6 +988,8 @@ extern "C" int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, con
         ADF_TRY(sde_step_common(h, b, pos, tags, fixed, f1, f2, nullptr, coefs_dev, num_steps,
                                 z_tr_all ? z_tr_all + t * zs : nullptr, z_rot_all ? z_rot_all + t * zs : nullptr,
                                 early_stop_count, state, nullptr, nullptr, stream));
+        // trajectory frame of this step: snapshot on this stream, copy-out on the sink's stream (frames.hip)
+        if (sink && ((t + 1) % frame_every == 0 || t + 1 == num_steps)) ADF_TRY(adf_frames_push_impl(sink, pos, s));
         if (early_stop_count > 0 && poll_every > 0 && (t % poll_every) == poll_every - 1 && t + 1 < num_steps) {
             int32_t frozen = 0;
             ADF_HIP_CHECK(hipMemcpyAsync(&frozen, state + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -991,6 +998,24 @@ extern "C" int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, con
         }
     }
     return ADF_OK;
+}
+
+extern "C" int32_t adf_sample(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                              const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
+                              const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
+                              const int32_t* out_idx, int32_t n_out, float* f1, float* f2, void* stream) {
+    return sample_impl(h, b, pos, tags, fixed, coefs_dev, num_steps, z_tr_all, z_rot_all, early_stop_count, poll_every, state,
+                       out_idx, n_out, f1, f2, nullptr, 0, stream);
+}
+
+extern "C" int32_t adf_sample_traj(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                                   const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
+                                   const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
+                                   const int32_t* out_idx, int32_t n_out, float* f1, float* f2, adf_frames_t sink,
+                                   int32_t frame_every, void* stream) {
+    if (!sink) { adf_set_error("sample_traj: null sink"); return ADF_EINVAL; }
+    return sample_impl(h, b, pos, tags, fixed, coefs_dev, num_steps, z_tr_all, z_rot_all, early_stop_count, poll_every, state,
+                       out_idx, n_out, f1, f2, sink, frame_every, stream);
 }
 
 extern "C" int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream) {

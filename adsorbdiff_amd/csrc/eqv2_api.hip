@@ -981,16 +981,21 @@ extern "C" int32_t adf_eqv2_sde_step(adf_eqv2_t h, const adf_batch* b, float* po
                             early_stop_count, state, dcom, drot, (hipStream_t)stream);
 }
 
-extern "C" int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
-                                   const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
-                                   const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
-                                   const int32_t* out_idx, int32_t n_out, float* f1, float* f2, void* stream) {
+struct adf_frames;
+int32_t adf_frames_push_impl(adf_frames* f, const float* src, hipStream_t s);
+
+static int32_t eq_sample_impl(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                              const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
+                              const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
+                              const int32_t* out_idx, int32_t n_out, float* f1, float* f2, adf_frames* sink,
+                              int32_t frame_every, void* stream) {
     ADF_TRY(eq_check_batch(h, b));
     if (num_steps <= 0 || !f1 || !f2 || !state || !coefs_dev || !pos || !tags || (out_idx && n_out < 0)) {
         adf_set_error("eqv2_sample: bad argument");
         return ADF_EINVAL;
     }
     if ((z_tr_all == nullptr) != (z_rot_all == nullptr)) { adf_set_error("eqv2_sample: need both noise tables or none"); return ADF_EINVAL; }
+    if (sink && frame_every <= 0) { adf_set_error("eqv2_sample: frame_every must be positive"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
     const size_t zs = (size_t)b->num_systems * 3;
     for (int t = 0; t < num_steps; ++t) {
@@ -998,6 +1003,7 @@ extern "C" int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos,
         ADF_TRY(adf_eqv2_sde_step(h, b, pos, tags, fixed, f1, f2, nullptr, coefs_dev, num_steps,
                                   z_tr_all ? z_tr_all + t * zs : nullptr, z_rot_all ? z_rot_all + t * zs : nullptr,
                                   early_stop_count, state, nullptr, nullptr, stream));
+        if (sink && ((t + 1) % frame_every == 0 || t + 1 == num_steps)) ADF_TRY(adf_frames_push_impl(sink, pos, s));
         if (early_stop_count > 0 && poll_every > 0 && (t % poll_every) == poll_every - 1 && t + 1 < num_steps) {
             int32_t frozen = 0;
             ADF_HIP_CHECK(hipMemcpyAsync(&frozen, state + 1, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1006,6 +1012,24 @@ extern "C" int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos,
         }
     }
     return ADF_OK;
+}
+
+extern "C" int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                                   const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all,
+                                   const float* z_rot_all, int32_t early_stop_count, int32_t poll_every, int32_t* state,
+                                   const int32_t* out_idx, int32_t n_out, float* f1, float* f2, void* stream) {
+    return eq_sample_impl(h, b, pos, tags, fixed, coefs_dev, num_steps, z_tr_all, z_rot_all, early_stop_count, poll_every,
+                          state, out_idx, n_out, f1, f2, nullptr, 0, stream);
+}
+
+extern "C" int32_t adf_eqv2_sample_traj(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags,
+                                        const int32_t* fixed, const adf_step_coef* coefs_dev, int32_t num_steps,
+                                        const float* z_tr_all, const float* z_rot_all, int32_t early_stop_count,
+                                        int32_t poll_every, int32_t* state, const int32_t* out_idx, int32_t n_out, float* f1,
+                                        float* f2, adf_frames_t sink, int32_t frame_every, void* stream) {
+    if (!sink) { adf_set_error("eqv2_sample_traj: null sink"); return ADF_EINVAL; }
+    return eq_sample_impl(h, b, pos, tags, fixed, coefs_dev, num_steps, z_tr_all, z_rot_all, early_stop_count, poll_every,
+                          state, out_idx, n_out, f1, f2, sink, frame_every, stream);
 }
 
 // Stand-alone C = act(A . W^T + b) through the dense-product kernels of this path (unit tests, micro-benchmarks).

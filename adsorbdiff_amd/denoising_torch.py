@@ -201,6 +201,7 @@ class Denoiser:
                     out_idx = torch.nonzero(prep.tags == 2).reshape(-1).to(torch.int32).contiguous()
                 state = torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
                 frames = [] if self.traj_dir else None
+                sink = writer = None
                 check_every = 1 if B <= 8 else 5
                 z_tr = z_rot = None
                 if not ode:
@@ -222,8 +223,17 @@ class Denoiser:
                 # Nothing to hand to the host between steps (no per-step frames, no host noise hook, no graph replay):
                 # the whole loop is one library call (adf_sample), polling the early-stop flag every `check_every` steps.
                 step_hook = params.get("step_hook")  # extension: callable(t) after every applied step (diagnostics)
-                fused_loop = ((not use_graph) and self.noise_fn is None and step_hook is None
-                              and (frames is None or not self.save_full))
+                fused_loop = (not use_graph) and self.noise_fn is None and step_hook is None
+                if fused_loop and frames is not None:
+                    # trajectory frames leave the device from inside the fused loop (csrc/frames.hip) and a host thread
+                    # writes them while the next steps compute (trajectory.py); frames = None: nothing is kept here
+                    from .trajectory import FrameSink, TrajectoryWriter
+
+                    frames = None
+                    sink = FrameSink(dev.index if dev.index is not None else torch.cuda.current_device(), N,
+                                     slots=int(params.get("trajectory_ring_slots", 8)))
+                    writer = TrajectoryWriter(sink, self.traj_dir, self._traj_meta(batch), T if self.save_full else 1)
+                    writer.start()
                 if fused_loop:
                     zt = zr = None
                     if not ode:  # device generator, drawn in the reference's order (:274-289): z_tr then z_rot, per step
@@ -232,8 +242,24 @@ class Denoiser:
                         for t_idx in range(T):
                             zt[t_idx].normal_()
                             zr[t_idx].normal_()
-                    eng.sample(prep, pos, f1, f2, coefs_dev, T, state, zt, zr, early_stop_count=early,
-                               poll_every=check_every if early else 0, out_idx=out_idx)
+                    try:
+                        eng.sample(prep, pos, f1, f2, coefs_dev, T, state, zt, zr, early_stop_count=early,
+                                   poll_every=check_every if early else 0, out_idx=out_idx,
+                                   sink=sink if (sink is not None and self.save_full) else None, frame_every=1)
+                        if sink is not None and not self.save_full:   # final frame only (reference :474-477 with save_full False)
+                            with torch.cuda.device(dev):
+                                _lib.check(eng.lib.adf_frames_push(sink.handle, pos.data_ptr(), eng._stream()))
+                        eng.check_flags()
+                    except BaseException:
+                        if writer is not None:   # a failed attempt (e.g. the f16x3 range was left): drop its frames
+                            writer.finish(0)
+                            writer.join()
+                            sink.close()
+                        raise
+                    if writer is not None:
+                        applied = int(state[3].item())
+                        writer.finish(max(applied, 1) if self.save_full else 1)
+                        self._pending = (writer, sink)
                 for t_idx in range(0 if fused_loop else T):  # per-step path
                     if not ode:
                         if self.noise_fn is not None:
@@ -283,6 +309,8 @@ class Denoiser:
                 # frames recorded after the break are identical copies; keep the applied ones
                 frames = frames[: max(self.steps_applied, 1)] if self.save_full else frames[-1:]
                 self._write_trajectories(batch, frames)
+            if getattr(self, "_pending", None) is not None and not params.get("trajectory_async", False):
+                self.wait_for_trajectories()   # like the reference: the files exist when run() returns
             B_ = B
             batch.y = torch.zeros(B_, device=dev)
             batch.force = torch.zeros(N, 3, device=dev)
@@ -295,6 +323,24 @@ class Denoiser:
                 ema.restore()
 
     # ------------------------------------------------------------------ trajectory sink
+    _pending = None
+
+    def wait_for_trajectories(self) -> None:
+        """Block until the writer thread of this run has written every file (``trajectory_async`` runs return earlier)."""
+        if self._pending is not None:
+            writer, sink = self._pending
+            self._pending = None
+            try:
+                writer.join_checked()
+            finally:
+                sink.close()
+
+    def _traj_meta(self, batch) -> dict:
+        tags = batch.tags.cpu().numpy()
+        return dict(numbers=batch.atomic_numbers.cpu().numpy(), tags=tags,
+                    fixed=batch.fixed.cpu().numpy() if hasattr(batch, "fixed") else np.zeros_like(tags),
+                    cell=batch.cell.cpu().numpy(), natoms=batch.natoms.cpu().numpy(), names=list(self.traj_names))
+
     def _write_trajectories(self, batch, frames) -> None:
         """One file per system, written once after the loop under a temporary name and then renamed (the reference's
         ``.traj_tmp`` -> ``.traj`` protocol, :66-82).  With ``ase`` importable: genuine ASE trajectories ``<name>.traj``;

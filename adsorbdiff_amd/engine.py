@@ -323,17 +323,21 @@ class PaiNNEngine:
 
     def sample(self, prep: PreparedBatch, pos, f1, f2, coefs_dev: torch.Tensor, num_steps: int, state,
                z_tr_all=None, z_rot_all=None, early_stop_count: int = 10, poll_every: int = 0,
-               out_idx: Optional[torch.Tensor] = None) -> None:
-        """The whole reverse loop in one library call (``adf_sample``)."""
+               out_idx: Optional[torch.Tensor] = None, sink=None, frame_every: int = 1) -> None:
+        """The whole reverse loop in one library call (``adf_sample``; with ``sink`` — a ``trajectory.FrameSink`` —
+        ``adf_sample_traj``: a frame of the positions leaves the device after every ``frame_every``-th step)."""
         desc = prep.desc(pos)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.adf_sample(
-                self.handle, C.byref(desc), pos.data_ptr(), prep.tags.data_ptr(),
+        args = [self.handle, C.byref(desc), pos.data_ptr(), prep.tags.data_ptr(),
                 prep.fixed.data_ptr() if prep.fixed is not None else None, coefs_dev.data_ptr(), num_steps,
                 z_tr_all.data_ptr() if z_tr_all is not None else None,
                 z_rot_all.data_ptr() if z_rot_all is not None else None, early_stop_count, poll_every,
                 state.data_ptr(), out_idx.data_ptr() if out_idx is not None else None,
-                int(out_idx.numel()) if out_idx is not None else 0, f1.data_ptr(), f2.data_ptr(), self._stream()))
+                int(out_idx.numel()) if out_idx is not None else 0, f1.data_ptr(), f2.data_ptr()]
+        with torch.cuda.device(self.device):
+            if sink is None:
+                _lib.check(self.lib.adf_sample(*args, self._stream()))
+            else:
+                _lib.check(self.lib.adf_sample_traj(*args, sink.handle, int(frame_every), self._stream()))
 
     def counters(self) -> _lib.Counters:
         c = _lib.Counters()

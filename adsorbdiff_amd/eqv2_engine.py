@@ -233,14 +233,18 @@ class EqV2Engine:
                 state.data_ptr(), None, None, self._stream()))
 
     def sample(self, prep: PreparedBatch, pos, f1, f2, coefs_dev: torch.Tensor, num_steps: int, state,
-               z_tr_all=None, z_rot_all=None, early_stop_count: int = 10, poll_every: int = 0, out_idx=None) -> None:
+               z_tr_all=None, z_rot_all=None, early_stop_count: int = 10, poll_every: int = 0, out_idx=None, sink=None,
+               frame_every: int = 1) -> None:
         desc = prep.desc(pos)
         opt = lambda t: t.data_ptr() if t is not None else None
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.adf_eqv2_sample(
-                self.handle, C.byref(desc), pos.data_ptr(), prep.tags.data_ptr(), opt(prep.fixed), coefs_dev.data_ptr(),
+        args = [self.handle, C.byref(desc), pos.data_ptr(), prep.tags.data_ptr(), opt(prep.fixed), coefs_dev.data_ptr(),
                 num_steps, opt(z_tr_all), opt(z_rot_all), early_stop_count, poll_every, state.data_ptr(), opt(out_idx),
-                int(out_idx.numel()) if out_idx is not None else 0, f1.data_ptr(), f2.data_ptr(), self._stream()))
+                int(out_idx.numel()) if out_idx is not None else 0, f1.data_ptr(), f2.data_ptr()]
+        with torch.cuda.device(self.device):
+            if sink is None:
+                _lib.check(self.lib.adf_eqv2_sample(*args, self._stream()))
+            else:
+                _lib.check(self.lib.adf_eqv2_sample_traj(*args, sink.handle, int(frame_every), self._stream()))
 
     def counters(self) -> _lib.EqV2Counters:
         c = _lib.EqV2Counters()

@@ -23,12 +23,14 @@ EXPORTS = (
     "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_graph_set_moving",
     "adf_check_flags", "adf_painn_set_arithmetic", "adf_painn_set_incremental",
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
-    "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
+    "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_sample_traj",
+    "adf_frames_create", "adf_frames_destroy", "adf_frames_push", "adf_frames_wait", "adf_frames_release", "adf_frames_pushed",
+    "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_lift_adsorbates", "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
     "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_bwd", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
     "adf_eqv2_create", "adf_eqv2_destroy", "adf_eqv2_set_constants", "adf_eqv2_set_weights", "adf_eqv2_set_arithmetic",
     "adf_eqv2_set_edges", "adf_eqv2_set_moving", "adf_eqv2_forward", "adf_eqv2_forward_subset", "adf_eqv2_check_flags", "adf_eqv2_init_placement",
-    "adf_eqv2_sde_step", "adf_eqv2_sample", "adf_eqv2_linear_forward", "adf_eqv2_get_counters", "adf_eqv2_profile_enable", "adf_eqv2_profile_read",
+    "adf_eqv2_sde_step", "adf_eqv2_sample", "adf_eqv2_sample_traj", "adf_eqv2_linear_forward", "adf_eqv2_get_counters", "adf_eqv2_profile_enable", "adf_eqv2_profile_read",
     "adf_last_error", "adf_version",
 )
 
@@ -173,6 +175,13 @@ def load():
         "adf_eqv2_profile_enable": [vp, i32],
         "adf_eqv2_profile_read": [vp, C.POINTER(C.c_float), C.POINTER(i64), vp],
         "adf_sample": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp],
+        "adf_sample_traj": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp],
+        "adf_eqv2_sample_traj": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp],
+        "adf_frames_create": [i32, i64, i32, C.POINTER(vp)],
+        "adf_frames_destroy": [vp],
+        "adf_frames_push": [vp, vp, vp],
+        "adf_frames_wait": [vp, i64, i32, C.POINTER(C.POINTER(C.c_float))],
+        "adf_frames_release": [vp, i64],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -180,6 +189,8 @@ def load():
         fn.restype = i32
     lib.adf_op_linear_bwd_scratch.argtypes = [i64, i32, i32]
     lib.adf_op_linear_bwd_scratch.restype = i64
+    lib.adf_frames_pushed.argtypes = [vp]
+    lib.adf_frames_pushed.restype = i64
     _LIB = lib
     return lib
 

@@ -387,7 +387,7 @@ def main():
 
     # Secondary measurement, N = 1 only, never `value`: the same pass with the model outputs evaluated on the
     # adsorbate atoms only (the stepper reads nothing else; sampled positions are bit-identical, checked here).
-    ads_only = exact_f32 = all_rows = small = None
+    ads_only = exact_f32 = all_rows = small = traj_sink = None
     if world == 1 and not args.no_secondary:
         one_pass({"incremental_layers": False})  # untimed: switching the feature off frees its 22 GB of kept state
         torch.cuda.synchronize(dev)
@@ -410,6 +410,36 @@ def main():
                     "note": "opt-in denoising_pos_params['scores_on_adsorbate_only']: last layer's message targets, its "
                             "update and the heads evaluated for tag-2 atoms only (adf_painn_forward_subset); one pass, "
                             "not part of `value`"}
+        # The reference's default call keeps every frame (ml_relaxation.py:134-149: save_full_traj=True + traj_dir): one pass
+        # with the asynchronous sink (csrc/frames.hip + trajectory.py), timed until run() returns (every file written).
+        import shutil
+        import tempfile
+
+        tdir = tempfile.mkdtemp(prefix="adf_traj_", dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            b = batch0.clone()
+            torch.manual_seed(0)
+            den = Denoiser(b, DiffTorchCalc(trainer), dict(params, placement_noise=placement, trajectory_async=True),
+                           device=str(dev), traj_dir=tdir, traj_names=[str(i) for i in my_ids], save_full_traj=True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            sites_tr = gather_sites(den.run(), 1)
+            torch.cuda.synchronize(dev)
+            dt_sample = time.perf_counter() - t1
+            den.wait_for_trajectories()
+            dt_all = time.perf_counter() - t1
+            nbytes = sum(f.stat().st_size for f in Path(tdir).iterdir())
+            traj_sink = {"value": total_systems / dt_sample, "unit": "sites/s", "ms_per_step": dt_sample * 1e3,
+                         "value_until_files_complete": total_systems / dt_all, "ms_until_files_complete": dt_all * 1e3,
+                         "frames": args.num_steps, "files": len(list(Path(tdir).iterdir())), "bytes_written": nbytes,
+                         "identical_sites": bool(torch.equal(sites_tr, sites)),
+                         "note": "save_full_traj=True + traj_dir: adf_sample_traj pushes the positions after every reverse "
+                                 "step through a pinned host ring to a writer thread (one batch file streamed during the "
+                                 "loop, then <sid>.npz per system); value = until the sampler returns (frames still being "
+                                 "written behind it), value_until_files_complete = until every file exists; one pass, not "
+                                 "part of `value`"}
+        finally:
+            shutil.rmtree(tdir, ignore_errors=True)
         # What one GPU of an 8-way strong-scaling run of the 1000-system batch sees: 125 systems (same generator).
         if args.systems >= 250:
             b125 = make_batch(125, seed=1000).to(dev)
@@ -581,6 +611,7 @@ def main():
             "recomputed_row_fraction_per_step": row_frac or None,  # warm-up pass: layer x atom rows recomputed / all rows
             "incremental_layers_off": all_rows,
             "value_at_125_systems": small,
+            "with_trajectory_sink": traj_sink,
             "scores_on_adsorbate_only": ads_only,
             "exact_f32": exact_f32,
         }

@@ -269,6 +269,27 @@ int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, int64_t* mess
  * register-resident loop on every CU with non-zero operands.  Measurement aid of bench.py, not on the sampling path. */
 int32_t adf_measure_peaks(float* out_host3, void* stream);
 
+/* ---- per-step trajectory frames.  Replaces Denoiser.write's blocking per-step host copy
+ * (relaxation/diffusers/denoising_torch.py:358-367, 469-477; relaxation/ase_utils.py:19-48): a frame = the [N,3] positions
+ * after a reverse step.  adf_frames_push snapshots `src` into one of two device staging buffers on `stream` and copies it
+ * into slot (index % slots) of a pinned host ring on the sink's own stream; frames are numbered in push order.  A host
+ * writer thread takes them with adf_frames_wait (blocks up to timeout_ms; *host_ptr = NULL on time-out) and gives the slot
+ * back with adf_frames_release; push blocks the enqueueing thread only while the slot it needs is still unreleased.
+ * adf_sample_traj / adf_eqv2_sample_traj = adf_sample / adf_eqv2_sample that push a frame after every `frame_every`-th
+ * applied step (and after the last one) without leaving the fused loop.  Not thread-safe per sink except
+ * wait / release / pushed against push. */
+typedef struct adf_frames* adf_frames_t;
+int32_t adf_frames_create(int32_t device, int64_t frame_floats, int32_t slots, adf_frames_t* out);
+int32_t adf_frames_destroy(adf_frames_t f);
+int32_t adf_frames_push(adf_frames_t f, const float* src, void* stream);
+int32_t adf_frames_wait(adf_frames_t f, int64_t index, int32_t timeout_ms, const float** host_ptr);
+int32_t adf_frames_release(adf_frames_t f, int64_t index);
+int64_t adf_frames_pushed(adf_frames_t f);
+int32_t adf_sample_traj(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                        const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
+                        int32_t early_stop_count, int32_t poll_every, int32_t* state, const int32_t* out_idx,
+                        int32_t n_out, float* f1, float* f2, adf_frames_t sink, int32_t frame_every, void* stream);
+
 /* Hand-off to the relaxation stage: the lift rule of scripts/create_lmdbs/pred_traj_to_lmdb.py:81-90 applied to the
  * sampled final frames on the device (in place).  lifted: optional [B] output = shift applied per system. */
 int32_t adf_lift_adsorbates(float* pos, const int32_t* tags, const int32_t* atom_offset, int32_t B, float min_gap,
@@ -420,6 +441,10 @@ int32_t adf_eqv2_sample(adf_eqv2_t h, const adf_batch* b, float* pos, const int3
                         const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
                         int32_t early_stop_count, int32_t poll_every, int32_t* state, const int32_t* out_idx, int32_t n_out,
                         float* f1, float* f2, void* stream);
+int32_t adf_eqv2_sample_traj(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
+                             const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
+                             int32_t early_stop_count, int32_t poll_every, int32_t* state, const int32_t* out_idx, int32_t n_out,
+                             float* f1, float* f2, adf_frames_t sink, int32_t frame_every, void* stream);
 
 /* Stand-alone torch.nn.functional.linear (+ optional SiLU, act = 2) through this path's dense-product kernels (unit tests
  * and micro-benchmarks of so2_ops.py:12-79,158-238 / so3.py:694-745 shapes).  A [M,K], W [N,K], bias [N] or NULL, C [M,N],

@@ -512,8 +512,9 @@ def test_denoiser_end_to_end_vs_reference_fixture(tmp_path):
     np.testing.assert_allclose(out.pos.cpu().numpy(), fx["pos_final"], rtol=0, atol=1e-4)
     files = sorted(p.name for p in tmp_path.iterdir())
     # written under a temporary name, renamed at the end; without the ase package the sink is <sid>.npz
-    assert files == sorted(f"{s}.npz" for s in out.sid)
-    z = np.load(tmp_path / files[0])
+    # plus the batch-level pair of the asynchronous sink (trajectory.py): all frames of the batch in one file + its index
+    assert files == sorted([f"{s}.npz" for s in out.sid] + [f"batch_{out.sid[0]}.frames.npy", f"batch_{out.sid[0]}.json"])
+    z = np.load(tmp_path / f"{out.sid[0]}.npz")
     assert z["positions"].shape[0] == 8
     assert float(out.y.abs().sum()) == 0.0 and out.force.shape == out.pos.shape  # reference side effects
 
@@ -932,23 +933,65 @@ def test_scores_on_adsorbate_only_gives_identical_samples():
 
 @pytest.mark.parametrize("ode", [True, False])
 def test_fused_loop_matches_per_step_loop(tmp_path, ode):
-    """adf_sample (whole loop in one call) vs the per-step host loop (taken when every frame is kept): identical
-    positions, ODE and SDE — the SDE noise is drawn from the device generator in the same order on both paths."""
+    """adf_sample (whole loop in one call), adf_sample_traj (the same with a frame leaving the device after every step,
+    csrc/frames.hip + trajectory.py's writer thread) and the per-step host loop (taken when a step hook is installed; it
+    clones the positions after every step): identical final positions, ODE and SDE (the SDE noise is drawn from the
+    device generator in the same order on all paths), and the two trajectory sinks write IDENTICAL files - per system
+    <sid>.npz with one frame per applied step, plus the batch file and its index."""
+    import json
+
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.trainer import DenoisingTrainer
 
     fx = load_npz("stepper_ode8.npz")
     tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
     outs = []
-    for per_step in (False, True):
+    for mode in ("fused", "fused_sink", "per_step"):
         b = batch_from_fixture(fx, pos_key="pos_in")
         torch.manual_seed(int(fx["seed"]))
         torch.cuda.manual_seed(1234)
-        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), ode=ode, early_stop=False), device=DEV,
-                       traj_dir=(tmp_path / f"p{int(per_step)}") if per_step else None, traj_names=b.sid)
+        extra = {"step_hook": (lambda t: None)} if mode == "per_step" else {}
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), ode=ode, early_stop=False, **extra), device=DEV,
+                       traj_dir=(tmp_path / mode) if mode != "fused" else None, traj_names=b.sid)
         outs.append(den.run().pos.clone())
         assert den.steps_applied == 8
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    for sid in batch_from_fixture(fx, pos_key="pos_in").sid:
+        a, c = np.load(tmp_path / "fused_sink" / f"{sid}.npz"), np.load(tmp_path / "per_step" / f"{sid}.npz")
+        assert a["positions"].shape[0] == 8
+        for k in ("positions", "numbers", "tags", "fixed", "cell"):
+            assert np.array_equal(a[k], c[k]), (sid, k)
+    idx = json.loads((tmp_path / "fused_sink" / f"batch_{b.sid[0]}.json").read_text())
+    frames = np.load(tmp_path / "fused_sink" / idx["frames_file"])
+    assert frames.shape == (8, outs[0].shape[0], 3) and idx["frames"] == 8 and idx["sids"] == list(b.sid)
+    assert np.array_equal(frames[-1], outs[1].cpu().numpy())
+    assert not list((tmp_path / "fused_sink").glob("*_tmp"))   # everything was renamed to its final name
+
+
+def test_trajectory_sink_early_stop_and_final_frame_only(tmp_path):
+    """The sink under the reference's early stop (cumulative count, break BEFORE applying: the frames pushed after the stop
+    are dropped, one frame per APPLIED step remains) and with save_full_traj=False (the final frame only), and a ring of 2
+    slots (the enqueueing thread has to wait for the writer)."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("stepper_ode_early.npz")
+    tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
+    res = {}
+    for mode, full in (("sink", True), ("per_step", True), ("last", False)):
+        b = batch_from_fixture(fx, pos_key="pos_in")
+        torch.manual_seed(int(fx["seed"]))
+        extra = {"step_hook": (lambda t: None)} if mode == "per_step" else {}
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), trajectory_ring_slots=2, **extra), device=DEV,
+                       traj_dir=tmp_path / mode, traj_names=b.sid, save_full_traj=full)
+        out = den.run()
+        res[mode] = (den.steps_applied, out.pos.cpu().numpy(), np.load(tmp_path / mode / f"{b.sid[0]}.npz")["positions"])
+    n = res["sink"][0]
+    assert n == res["per_step"][0] == 9 and n < int(fx["num_steps"])   # the reference applied 9 updates before its break
+    assert res["sink"][2].shape[0] == max(n, 1) and np.array_equal(res["sink"][2], res["per_step"][2])
+    assert res["last"][2].shape[0] == 1
+    na = res["last"][2].shape[1]
+    assert np.array_equal(res["last"][2][0], res["last"][1][:na])
 
 
 def test_static_promise_forward_is_bit_identical():

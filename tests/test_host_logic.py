@@ -311,3 +311,112 @@ def test_igso3_table_cache_is_atomic_and_validated(tmp_path, monkeypatch):
     assert S.Igso3Tables._load_cache() is None
     np.savez(cache, omegas=t["omegas"][:10], cdf=t["cdf"], score=t["score"], exp_score_norm=t["exp_score_norm"])
     assert S.Igso3Tables._load_cache() is None  # wrong shape
+
+
+class _FakeFrameSource:
+    """Stand-in for trajectory.FrameSink: frames appear from another thread, slots must be released."""
+
+    def __init__(self, frames, slots=3):
+        import threading
+
+        self.frames, self.slots = frames, slots
+        self.avail = 0
+        self.released = set()
+        self.cv = threading.Condition()
+
+    def push(self):
+        with self.cv:
+            # like adf_frames_push: blocks while the slot of frame (avail - slots) is unreleased
+            self.cv.wait_for(lambda: self.avail < self.slots or (self.avail - self.slots) in self.released, timeout=5)
+            assert self.avail < self.slots or (self.avail - self.slots) in self.released, "ring overrun"
+            self.avail += 1
+            self.cv.notify_all()
+
+    def pushed(self):
+        with self.cv:
+            return self.avail
+
+    def wait(self, index, timeout_ms):
+        with self.cv:
+            if not self.cv.wait_for(lambda: self.avail > index, timeout=timeout_ms / 1000.0):
+                return None
+        return self.frames[index]
+
+    def release(self, index):
+        with self.cv:
+            self.released.add(index)
+            self.cv.notify_all()
+
+
+def test_trajectory_writer_thread_streams_trims_and_renames(tmp_path):
+    """trajectory.TrajectoryWriter (asynchronous, batched sink) against a fake frame source with a 3-slot
+    ring: frames are taken while they are still being produced, the run's early stop trims them (pushed 7, applied 5),
+    the slots of the dropped frames are released, and the per-system files the resume rule reads (<sid>.npz) plus the batch
+    file and its index exist under their final names only."""
+    import json
+    import threading
+
+    from adsorbdiff_amd.trainer import check_traj_files
+    from adsorbdiff_amd.trajectory import TrajectoryWriter
+
+    rng = np.random.default_rng(0)
+    natoms = [5, 3, 4]
+    N, T = sum(natoms), 8
+    frames = rng.normal(size=(7, N, 3)).astype(np.float32)
+    meta = dict(numbers=rng.integers(1, 80, N), tags=rng.integers(0, 3, N), fixed=rng.integers(0, 2, N),
+                cell=rng.normal(size=(3, 3, 3)).astype(np.float32), natoms=np.array(natoms), names=["a_1", "b_2", "c_3"])
+    src = _FakeFrameSource(frames)
+    w = TrajectoryWriter(src, tmp_path, meta, max_frames=T)
+    w.start()
+
+    def produce():
+        for _ in range(7):
+            src.push()
+
+    t = threading.Thread(target=produce)
+    t.start()
+    t.join(10)
+    assert not t.is_alive(), "producer blocked: the writer does not release ring slots"
+    w.finish(5)
+    w.join_checked(10)
+    assert src.released >= set(range(7))
+    start = 0
+    for b, (n, name) in enumerate(zip(natoms, meta["names"])):
+        z = np.load(tmp_path / f"{name}.npz")
+        assert np.array_equal(z["positions"], frames[:5, start:start + n])
+        assert np.array_equal(z["numbers"], meta["numbers"][start:start + n]) and np.array_equal(z["cell"], meta["cell"][b])
+        start += n
+    idx = json.loads((tmp_path / "batch_a_1.json").read_text())
+    assert idx["frames"] == 5 and idx["sids"] == meta["names"] and idx["atom_offsets"] == [0, 5, 8, 12]
+    assert np.array_equal(np.load(tmp_path / idx["frames_file"]), frames[:5])
+    assert not list(tmp_path.glob("*_tmp"))
+
+    class B:
+        sid = meta["names"]
+
+    assert check_traj_files(B, tmp_path)
+    # final frame only (save_full_traj=False): one frame kept
+    w2 = TrajectoryWriter(_FakeFrameSource(frames[:1]), tmp_path / "last", meta, max_frames=1)
+    w2.source.push()
+    w2.start()
+    w2.finish(1)
+    w2.join_checked(10)
+    assert np.load(tmp_path / "last" / "b_2.npz")["positions"].shape == (1, 3, 3)
+
+
+def test_npz_to_ase_traj_converter(tmp_path):
+    """The sink's format is .npz (ase is not installable in the build image); where ase IS importable the converter must
+    reproduce the reference's <sid>.traj content (relaxation/ase_utils.py:19-48)."""
+    ase_io = pytest.importorskip("ase.io")
+    from adsorbdiff_amd.trajectory import npz_to_ase_traj
+
+    rng = np.random.default_rng(1)
+    pos = rng.normal(size=(3, 6, 3)).astype(np.float32)
+    np.savez(tmp_path / "s_0.npz", positions=pos, numbers=np.array([78, 78, 78, 6, 8, 1]), tags=np.array([0, 1, 1, 2, 2, 2]),
+             fixed=np.array([1, 0, 0, 0, 0, 0]), cell=np.diag([10.0, 11.0, 30.0]).astype(np.float32))
+    out = npz_to_ase_traj(tmp_path / "s_0.npz")
+    frames = ase_io.read(str(out), index=":")
+    assert len(frames) == 3
+    np.testing.assert_allclose(frames[-1].get_positions(), pos[-1], atol=1e-6)
+    assert list(frames[0].get_tags()) == [0, 1, 1, 2, 2, 2] and list(frames[0].numbers) == [78, 78, 78, 6, 8, 1]
+    assert list(frames[0].constraints[0].get_indices()) == [0]
