@@ -249,6 +249,151 @@ __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restric
     if (colsum) bpart[(size_t)split * N + n0 + tid] = bs;
 }
 
+// The same 128 x 128 contraction on the f16-rate matrix cores, fp32-class accuracy without any scaling pass: both operands
+// are split into THREE bf16 terms (a = a1 + a2 + a3: 3 x 8 = 24 significant bits, the fp32 exponent range - weight-gradient
+// operands span ~1e-9 ... 1e2 and are contracted along their ROWS, so the per-row lifts of the forward's f16x3 split do not
+// apply and per-column lifts would cost one more pass over the 30 GB of d(rbfh)) and the six products of order <= 2^-16 are
+// issued: a3 b1, a2 b2, a1 b3, a2 b1, a1 b2, a1 b1 (dropped: <= 2^-24 relative).  v_mfma_f32_32x32x16_bf16 runs at 16x the
+// rate of v_mfma_f32_32x32x2_f32, so the six products cost 3/8 of the exact-f32 kernel's matrix time.  The chunk's rows
+// are staged ROW-major as bf16 (what the coalesced loads give) and read with ds_read_b64_tr_b16 (gfx950's transposing LDS
+// read: 4 rows x 16 columns per 16-lane group, delivered column-major = the K-contiguous operand layout of the 32x32x16
+// instruction); image (b) of the CDNA4 guide's T10 (256-byte rows, 16-byte chunks XOR-swizzled) keeps both the 8-byte
+// stores and the transposed reads conflict-free.  Zero-block skipping and the bias column sums as in tr_wgrad128_kernel.
+typedef __fp16 tr_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __bf16 tr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tr_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned int tr_swz(int row) { return (unsigned int)(((row & 3) << 2) | ((row >> 2) & 3)); }
+
+__global__ __launch_bounds__(256) void tr_wgrad_bf16x6_kernel(const float* __restrict__ dC, int ldc, const float* __restrict__ A,
+                                                              int lda, float* __restrict__ part, int M, int N, int K,
+                                                              int rows_per_split, int tiles_k, float* __restrict__ bpart) {
+    // [operand C / A][term 1..3][32 rows][256 B]
+    __shared__ __attribute__((aligned(16))) unsigned char img[2][3][32 * 256];
+    __shared__ float csum[8][128];
+    __shared__ unsigned int nzblk[2][4];
+    if (threadIdx.x < 8) nzblk[threadIdx.x >> 2][threadIdx.x & 3] = 0u;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = (wave >> 1) * 64, kb = wave & 1;
+    const int mbeg = split * rows_per_split, mend = min(M, mbeg + rows_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool colsum = bpart && k0 == 0;
+    float bs = 0.f;
+    const int lr = tid >> 5, lc = (tid & 31) * 4;  // staging: 8 rows x 32 float4 per pass, 4 passes
+    // transposed-read addressing of this lane (see the header): 16-lane group g, lane 4q + p of the group
+    const int g = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int kg = g >> 1;            // k half of the MFMA operand (lanes 32..63)
+    const int cgrp = g & 1;           // 16-column half of the 32-column block
+    int par = 0;
+    for (int m0 = mbeg; m0 < mend; m0 += 32, par ^= 1) {
+        float4 c4[4], a4[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = m0 + lr + 8 * ps;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            c4[ps] = m < mend ? *reinterpret_cast<const float4*>(dC + (size_t)m * ldc + n0 + lc) : z;
+            a4[ps] = m < mend ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k0 + lc) : z;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = lr + 8 * ps;
+            const unsigned int off = 256u * row + 16u * ((unsigned int)(lc >> 3) ^ tr_swz(row)) + 8u * ((lc >> 2) & 1);
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {
+                const float4 v = op == 0 ? c4[ps] : a4[ps];
+                float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    tr_bf16x4 b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { b[e] = (__bf16)r[e]; r[e] -= (float)b[e]; }   // exact residuals
+                    *reinterpret_cast<tr_bf16x4*>(&img[op][t][off]) = b;
+                }
+            }
+        }
+        {
+            bool nz = false;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) nz = nz || a4[ps].x != 0.f || a4[ps].y != 0.f || a4[ps].z != 0.f || a4[ps].w != 0.f;
+            if (nz) nzblk[par][lc >> 5] = 1u;
+            if (tid < 4) nzblk[par ^ 1][tid] = 0u;
+        }
+        if (colsum) {   // this thread's four rows of its four columns, rows in order; the 8 row groups are summed in order below
+            float4 sum = c4[0];
+#pragma unroll
+            for (int ps = 1; ps < 4; ++ps) { sum.x += c4[ps].x; sum.y += c4[ps].y; sum.z += c4[ps].z; sum.w += c4[ps].w; }
+            *reinterpret_cast<float4*>(&csum[lr][lc]) = sum;
+        }
+        __syncthreads();
+        if (colsum && tid < 128) {
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) bs += csum[r8][tid];
+        }
+        const bool do0 = nzblk[par][kb] != 0u, do1 = nzblk[par][kb + 2] != 0u;  // wave-uniform
+        if (do0 || do1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // operand fragment: rows 16 ks + 8 kg + (0..7) of the 16 columns c16 .. c16 + 15 that hold this lane's column
+                auto frag = [&](int op, int t, int c32) -> tr_bf16x8 {
+                    const int col = c32 + 16 * cgrp + 4 * tp;           // first of the 4 columns this lane addresses
+                    union { tr_fp16x4 h[2]; tr_bf16x8 b; } u;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int row = 16 * ks + 8 * kg + 4 * hh + tq;
+                        const unsigned int off = 256u * row + 16u * ((unsigned int)(col >> 3) ^ tr_swz(row)) + 8u * ((col >> 2) & 1);
+                        u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                            (__attribute__((address_space(3))) tr_fp16x4*)(&img[op][t][off]));
+                    }
+                    return u.b;
+                };
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    tr_bf16x8 a[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) a[t] = frag(0, t, wn + 32 * i);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (j == 0 ? !do0 : !do1) continue;
+                        tr_bf16x8 b[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) b[t] = frag(1, t, 32 * (kb + 2 * j));
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+                }
+            }
+        }
+    }
+    float* out = part + (size_t)split * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = k0 + 32 * (kb + 2 * j) + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(size_t)row * K + col] = acc[i][j][r];
+            }
+        }
+    if (colsum && tid < 128) bpart[(size_t)split * N + n0 + tid] = bs;
+}
+
 // dst[i] (+)= sum_s part[s][i] in a fixed order (run-to-run reproducible gradients)
 __global__ void tr_reduce_splits_kernel(const float* __restrict__ part, long long stride, float* __restrict__ dst,
                                         long long n, int splits, int accumulate) {
@@ -347,8 +492,14 @@ extern "C" int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W
         float* bp = db ? part + (size_t)splits * N * K : (float*)nullptr;
         if (N % 128 == 0 && K % 128 == 0 && (lda & 3) == 0 && (ldc & 3) == 0 &&
             ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(dC)) & 15) == 0) {
-            hipLaunchKernelGGL(tr_wgrad128_kernel, dim3((N / 128) * (K / 128), splits), dim3(256), 0, s, dC, ldc, A, lda, part,
-                               (int)M, N, K, rows, K / 128, bp);
+            // ADF_WGRAD=f32: the exact-f32 matrix-core kernel (v_mfma_f32_32x32x2_f32); default: three-term bf16 split
+            static const bool wgrad_f32 = [] { const char* e = getenv("ADF_WGRAD"); return e && strcmp(e, "f32") == 0; }();
+            if (wgrad_f32)
+                hipLaunchKernelGGL(tr_wgrad128_kernel, dim3((N / 128) * (K / 128), splits), dim3(256), 0, s, dC, ldc, A, lda, part,
+                                   (int)M, N, K, rows, K / 128, bp);
+            else
+                hipLaunchKernelGGL(tr_wgrad_bf16x6_kernel, dim3((N / 128) * (K / 128), splits), dim3(256), 0, s, dC, ldc, A, lda,
+                                   part, (int)M, N, K, rows, K / 128, bp);
         } else {
             const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
             hipLaunchKernelGGL(tr_wgrad_kernel, dim3(tiles_n * tiles_k, splits), dim3(256), 0, s, dC, ldc, A, lda, part, (int)M,
