@@ -100,11 +100,12 @@ class PaiNNTrainStep:
                 p.grad.zero_()
 
     # ------------------------------------------------------------------ the step
-    def loss_and_grad(self, batch, targets: dict) -> torch.Tensor:
+    def loss_and_grad(self, batch, targets: dict, grads_ready=None) -> torch.Tensor:
         """``batch``: noised batch on the device (pos, atomic_numbers, tags, batch, natoms, cell); ``targets``: tr_sigma
         [B,1], rot_sigma [B,1], tr_score [B,3], rot_score [B,3] (what tr_so3_schedule attaches to the batch).
         Accumulates into ``param.grad`` (call zero_grad first, like optimizer.zero_grad) and returns the device tensor
-        (loss, translation term, rotation term)."""
+        (loss, translation term, rotation term).  ``grads_ready(names)`` (optional) is called as soon as the gradients of a
+        group of parameters are final: both heads, then each layer from the last to the first, then the embedding."""
         m, ops, lib = self.model, self.ops, self.lib
         P = self._params()
         H, L, R = m.hidden_channels, m.num_layers, m.num_rbf
@@ -233,6 +234,8 @@ class PaiNNTrainStep:
                 if blk == 1:
                     dxs, dv = dxs_in, dv_in
 
+        if grads_ready is not None:
+            grads_ready(["out_forces.", "out_forces2."])
         # ---------------- backward: layers, last to first
         for l in range(L - 1, -1, -1):
             a = saved[l]
@@ -279,8 +282,12 @@ class PaiNNTrainStep:
             _lib.check(lib.adf_op_copy_rows(dlw.data_ptr(), H, G[mp + "x_layernorm.weight"].data_ptr(), H, 1, H, 1, s()))
             _lib.check(lib.adf_op_copy_rows(dlb.data_ptr(), H, G[mp + "x_layernorm.bias"].data_ptr(), H, 1, H, 1, s()))
             dx, dvec = dx_in, dvec_in
+            if grads_ready is not None:
+                grads_ready([mp, up])
         _lib.check(lib.adf_op_embed_bwd(dx.data_ptr(), prep.atomic_numbers.data_ptr(),
                                         G["atom_emb.embeddings.weight"].data_ptr(), N, H, s()))
+        if grads_ready is not None:
+            grads_ready(["atom_emb."])
         self.last_outputs = (f1, f2)
         return loss
 
@@ -339,35 +346,74 @@ class FusedAdamW:
         return self.sqnorm.sqrt()
 
 
-def allreduce_gradients(model, world_size: int, bucket_mb: float = 64.0) -> None:
-    """DDP step: average ``param.grad`` over the ranks in flat buckets (RCCL all-reduce over xGMI under backend nccl).
-    Parameters without a gradient on any rank (out_energy.*: the reference runs DDP with find_unused_parameters=True,
-    base_trainer.py:442-447) are skipped consistently: their .grad stays zero everywhere."""
-    if world_size <= 1:
-        return
-    import torch.distributed as dist
+class GradientReducer:
+    """Bucketed gradient all-reduce ISSUED FROM the backward pass (DDP over RCCL / xGMI, the reference's
+    ``DistributedDataParallel(find_unused_parameters=True)``, base_trainer.py:442-447): ``ready(names)`` is called by
+    ``PaiNNTrainStep.loss_and_grad`` as soon as the gradients of a group of parameters are final - the two heads first, then
+    layer L-1 ... 0, the embedding last - and starts that bucket's all-reduce asynchronously (backend nccl = RCCL: the
+    collective runs on the process group's own stream behind the kernels already enqueued, the remaining backward kernels
+    keep the compute stream busy); ``finish()`` waits for the buckets, divides by the world size and writes the averages back.
+    Parameters without a gradient on any rank (out_energy.*) are skipped consistently.  Buckets are one group each unless
+    ``bucket_mb`` is smaller than a group (then the group is cut): a layer of the H = 512 model is 14.7 MB of gradients."""
 
-    grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
-    bucket, size, limit = [], 0, int(bucket_mb * 2**20 / 4)
-    def flush():
-        if not bucket:
-            return
-        flat = torch.cat([g.reshape(-1) for g in bucket])
+    def __init__(self, model, world_size: int, bucket_mb: float = 64.0):
+        self.world = int(world_size)
+        self.limit = max(1, int(bucket_mb * 2**20 / 4))
+        self.named = {k: p for k, p in model.named_parameters() if p.requires_grad}
+        self.pending = []
+        self.done_names = set()
+
+    def _launch(self, grads) -> None:
+        import torch.distributed as dist
+
+        flat = torch.cat([g.reshape(-1) for g in grads])
         if dist.get_backend() == "gloo" and flat.is_cuda:  # test configuration: several ranks on one GPU
             host = flat.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            flat.copy_(host)
+            work = dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True)
+            self.pending.append((work, host, flat, grads))
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world_size)
-        o = 0
-        for g in bucket:
-            g.copy_(flat[o : o + g.numel()].view_as(g))
-            o += g.numel()
-    for g in grads:
-        bucket.append(g)
-        size += g.numel()
-        if size >= limit:
-            flush()
-            bucket, size = [], 0
-    flush()
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            self.pending.append((work, flat, flat, grads))
+
+    def ready(self, names) -> None:
+        """The gradients of the parameters ``names`` (exact names or prefixes) are final."""
+        if self.world <= 1:
+            return
+        sel = [k for k in self.named if k not in self.done_names and any(k == n or k.startswith(n) for n in names)]
+        self.done_names.update(sel)
+        bucket, size = [], 0
+        for k in sel:
+            g = self.named[k].grad
+            if g is None:
+                continue
+            bucket.append(g)
+            size += g.numel()
+            if size >= self.limit:
+                self._launch(bucket)
+                bucket, size = [], 0
+        if bucket:
+            self._launch(bucket)
+
+    def finish(self) -> None:
+        if self.world <= 1:
+            return
+        self.ready([""])   # whatever was not announced (a caller without hooks): everything that is left
+        for work, red, flat, grads in self.pending:
+            work.wait()
+            if red is not flat:
+                flat.copy_(red)
+            flat.div_(self.world)
+            o = 0
+            for g in grads:
+                g.copy_(flat[o : o + g.numel()].view_as(g))
+                o += g.numel()
+        self.pending = []
+        self.done_names = set()
+
+
+def allreduce_gradients(model, world_size: int, bucket_mb: float = 64.0) -> None:
+    """DDP step after a finished backward: average ``param.grad`` over the ranks in flat buckets (RCCL all-reduce over xGMI
+    under backend nccl).  The training step itself overlaps the buckets with the backward (``GradientReducer``)."""
+    if world_size <= 1:
+        return
+    GradientReducer(model, world_size, bucket_mb).finish()

@@ -102,7 +102,7 @@ class DenoisingTrainer:
         import torch.distributed as dist
 
         from .noising import tr_so3_schedule
-        from .train_step import allreduce_gradients
+        from .train_step import GradientReducer
 
         self.model.train()
         batch = batch.to(self.device)
@@ -112,8 +112,10 @@ class DenoisingTrainer:
             batch = tr_so3_schedule(batch, self.denoising_pos_params, self.train_engine.igso3)
         targets = {k: getattr(batch, k) for k in ("tr_sigma", "rot_sigma", "tr_score", "rot_score")}
         self.train_engine.zero_grad()
-        loss = self.train_engine.loss_and_grad(batch, targets)
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # the buckets' all-reduces are issued from inside the backward (heads, then layer by layer) and overlap with it
+        reducer = GradientReducer(self._unwrapped_model, world)
+        loss = self.train_engine.loss_and_grad(batch, targets, grads_ready=reducer.ready if world > 1 else None)
         # NaN policy of the reference loop (sde_denoising_trainer.py:428-440), mirrored: a step whose loss is NaN is
         # skipped (`continue`: warning, no update; the reference's `nan_count > 10` test sits behind the reset and can never
         # fire, so there is no such stop here either); a loss above 1e6 - an Inf loss included, isnan() is False for it -
@@ -130,14 +132,23 @@ class DenoisingTrainer:
         if is_nan:
             logging.warning("NaN loss detected, skipping step")
             self.nan_count = getattr(self, "nan_count", 0) + 1
+            reducer.finish()   # every rank takes this branch: drain the buckets already in flight
             self.train_engine.zero_grad()
             return {"loss": loss, "grad_norm": None, "skipped": True, "stop": False}
         self.nan_count = 0
         if too_high:
             logging.warning("Loss too high: %s", float(l0[0]))
+            reducer.finish()
             self.train_engine.zero_grad()
             return {"loss": loss, "grad_norm": None, "skipped": True, "stop": True}
-        allreduce_gradients(self._unwrapped_model, world)
+        if world > 1 and loss.is_cuda:   # what the backward did not hide: time spent waiting for the last buckets
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reducer.finish()
+            e1.record()
+            self.allreduce_wait_events = getattr(self, "allreduce_wait_events", [])[-63:] + [(e0, e1)]
+        else:
+            reducer.finish()
         grad_norm = self.optimizer.step()
         self.step += 1
         return {"loss": loss, "grad_norm": grad_norm, "skipped": False, "stop": False}

@@ -106,3 +106,63 @@ def test_two_rank_gradient_allreduce(tmp_path):
             assert a is None and b is None
         else:
             assert torch.equal(a, b) and torch.allclose(a, torch.full_like(a, 1.5 * (i + 1)))
+
+
+def _reducer_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from adsorbdiff_amd.train_step import GradientReducer
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.atom_emb = torch.nn.Linear(4, 4)
+            self.message_layers = torch.nn.ModuleList([torch.nn.Linear(4, 4) for _ in range(2)])
+            self.update_layers = torch.nn.ModuleList([torch.nn.Linear(4, 4) for _ in range(2)])
+            self.out_forces = torch.nn.Linear(4, 2)
+            self.out_energy = torch.nn.Linear(4, 1)   # never gets a gradient (find_unused_parameters semantics)
+
+    torch.manual_seed(0)
+    net = Net()
+    for i, (k, p) in enumerate(net.named_parameters()):
+        p.grad = None if k.startswith("out_energy") else torch.full_like(p, float(rank + 1) * (i + 1))
+    red = GradientReducer(net, world, bucket_mb=1e-5)   # a bucket per tensor: many collectives in flight at once
+    calls = []
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return orig(t, *a, **k)
+
+    dist.all_reduce = counting
+    # the order the backward announces its groups in (train_step.loss_and_grad): heads, layers from the last, embedding
+    red.ready(["out_forces.", "out_forces2."])
+    n_heads = len(calls)
+    for l in (1, 0):
+        red.ready([f"message_layers.{l}.", f"update_layers.{l}."])
+    n_layers = len(calls)
+    red.finish()                                         # picks up what was never announced (atom_emb)
+    dist.all_reduce = orig
+    torch.save({"grads": [None if p.grad is None else p.grad.clone() for p in net.parameters()],
+                "calls": (n_heads, n_layers, len(calls))}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_issues_buckets_from_the_backward_hooks(tmp_path):
+    """train_step.GradientReducer (the all-reduce overlapped with the backward): the buckets of a group are
+    started when the group is announced, what is never announced goes out at finish(), every gradient ends up as the
+    average over the ranks and gradient-less parameters are skipped on every rank."""
+    world = 2
+    mp.spawn(_reducer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert r0["calls"] == r1["calls"] == (2, 10, 12)     # heads: 2 tensors; + 4 layers x 2; + embedding 2 at finish
+    n = 0
+    for i, (a, b) in enumerate(zip(r0["grads"], r1["grads"])):
+        if a is None:
+            assert b is None
+            n += 1
+        else:
+            assert torch.equal(a, b) and torch.allclose(a, torch.full_like(a, 1.5 * (i + 1)))
+    assert n == 2
