@@ -35,7 +35,9 @@
 #define M3_THREADS 512
 #define M3_WAVES 8
 #define M3_ULIM 44.0f  // a block takes rows while u <= u_first + 44 (u = (R-1) d / rc): window <= 64 after alignment
-#define M3_D 4         // gathered rows requested ahead of the consumed one
+#define M3_D 4         // (P0,P1,P2,xa) pieces: rows requested ahead of the consumed one
+#define M3_DC 8        // xc pieces (2 registers per row): deeper - the first 8 rows of P1 then only wait for loads that are
+                       // OLDER than the block's streaming loads (edge rows of block t+2, residual rows), see body()
 #ifndef M3_EXP
 #define M3_EXP 0       // timing experiments only (wrong results): 1 no edge-row / residual loads in the loop; 2 also no gathers;
 #endif                 // 3 every gather reads the all-zero record (L1 hits)
@@ -54,7 +56,7 @@ struct M3Block {  // wave-uniform
 template <bool VZ>
 __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // carve: weight image (hi rows, lo rows) | [128] mu | [8 waves][2 buffers][32 rows][4] row meta
+    // carve: weight image (hi rows, lo rows) | [128] mu | [8 waves][3 buffers][32 rows][4] row meta
     _Float16* Wh = reinterpret_cast<_Float16*>(lds);
     float* Mu = lds + (2 * MSG_COLS * MSG_LDK) / 2;
     float* Meta = Mu + 128;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
     const _Float16* whq = Wh + (size_t)q * MSG_LDK + 8 * hi;            // + klo + cb*32*LDK + 16 ks
     const _Float16* wlq = whq + (size_t)MSG_COLS * MSG_LDK;
     const _Float16* wbias = Wh + (size_t)q * MSG_LDK + 128;             // + cb*32*LDK
-    float* meta_w = Meta + wave * 2 * 32 * 4;                           // [buffer][row][4]
+    float* meta_w = Meta + wave * 3 * 32 * 4;                           // [buffer][row][4]: blocks t-1, t, t+1
     const float* mu_h = Mu + 8 * hi;
 
     // ---- static work assignment: item it = wave, wave + 4, ... of this workgroup's sequence
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
     float gza[16], gzb[16];    // ring of gathered xc pieces (j = 0, 1)
     float sx0 = 0.f, sx1 = 0.f, sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f, sc0 = 0.f, sc1 = 0.f;
     float ra0 = 0.f, ra1 = 0.f, rb0 = 0.f, rb1 = 0.f, rc0 = 0.f, rc1 = 0.f;
-    float res[4] = {0.f, 0.f, 0.f, 0.f};   // residual rows of the current block's target
+    float resP[4] = {0.f, 0.f, 0.f, 0.f}, resC[4] = {0.f, 0.f, 0.f, 0.f};   // residual rows of the previous / current block's target
     float xsqC = 0.f, envC = 0.f, xsqN = 0.f, envN = 0.f;
     float4 geoR = make_float4(0.f, 0.f, 0.f, 0.f);   // rows of the block requested last (R stage)
     int srcR = 0;
@@ -353,10 +355,10 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
     };
 
     // prologue: block 0 through its W stage, its first A operands and requests; block 1 requested
-    {   // meta buffer 1 = the (non-existent) block before the first one: every row points at the all-zero record
+    {   // meta buffer 2 = the (non-existent) block before the first one: every row points at the all-zero record
         float4 m;
         m.x = __uint_as_float((unsigned int)p.N * row_bytes); m.y = 0.f; m.z = 0.f; m.w = 0.f;
-        *reinterpret_cast<float4*>(meta_w + 128 + q * 4) = m;
+        *reinterpret_cast<float4*>(meta_w + 2 * 128 + q * 4) = m;
     }
     request_rows(cur.eb, cur.e1);
     window_stage(cur, 0, xsqC, envC);
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[4][i] = 0.f; acc[5][i] = 0.f; }
     prv = cur; prv.have = 0; prv.last = 0;
-    int par = 0;   // meta buffer of the current block
+    int par = 0;   // meta buffer of the current block (previous: (par + 2) % 3, next: (par + 1) % 3)
     frag_load(0, cur.klo);
     frag_load(1, cur.klo);
 
@@ -378,38 +380,50 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
     auto body = [&]() {
         const int nk = cur.nk;
         const int klo = cur.klo;
+        const int pprev = par == 0 ? 2 : par - 1, pnext = par == 2 ? 0 : par + 1;
         // Request sequence of a block t (each request uses the offset read one step before it):
-        //   P1 rows r:      xc(t-1) row r + D   [meta par ^ 1]      ... last D rows: x4a(t) rows 0..D-1 [meta par]
-        //   P2 rows r:      x4a(t) row r + D                          ... after the loop: x4b(t) rows 0..D-1
-        //   P3 rows r:      x4b(t) row r + D                          ... last D rows: xc(t) rows 0..D-1
-        // ---- P1: a0, b0 of t  ||  consume c0, c1 of t-1 (meta buffer par ^ 1), A operand of k-steps 2, 3 of t
+        //   P1 rows r:      xc(t-1) row r + DC  [meta pprev]        ... last D rows: x4a(t) rows 0..D-1 [meta par]
+        //   P2 rows r:      x4a(t) row r + D                          ... last D rows: x4b(t) rows 0..D-1
+        //   P3 rows r:      x4b(t) row r + D                          ... last DC rows: xc(t) rows 0..DC-1
+        // The block's STREAMING loads (edge rows of block t+2, residual rows of this target: first touches, served by
+        // HBM / Infinity Cache) are issued at the start of P1: vmcnt retires in order, so every younger gather waits for them -
+        // the xc pieces of the first DC rows of P1 are older (requested in P3 of the previous block), the younger requests are
+        // needed half a phase later.  (Issued in P2, between the x4 ring's requests, they cost 13 % of the launch.)
+        // ---- P1: a0, b0 of t  ||  W(t+1), R(t+2), residual rows; consume c0, c1 of t-1; A operand of k-steps 2, 3 of t
+        M3Block req;
         {
-            constexpr int W = 10 + 16;
-            float4 mnext = meta_row(par ^ 1, 0);
-            ro_next = meta_roff(par ^ 1, M3_D);
+            constexpr int W = 3 + 10 + 16;
+            float4 mnext = meta_row(pprev, 0);
+            ro_next = meta_roff(pprev, M3_DC);
 #pragma unroll
             for (int s = 0; s < 26; ++s) {
                 mfma_slot(s, klo);
 #pragma unroll
                 for (int w = s * W / 26; w < (s + 1) * W / 26; ++w) {
-                    if (w < 10) {   // the A operand first: k-step 2 is contracted from tick 7 on
-                        if (nk > 2 + w / 5) {
-                            gen_a_part(w % 5, klo + 32 + 16 * (w / 5), xsqC, envC, Ah[2 + w / 5], Al[2 + w / 5]);
-                        } else if (w % 5 == 4) {
+                    if (w == 0) window_stage(nxt, pnext, xsqN, envN);
+                    else if (w == 1) { next_request(nxt, req); if (M3_EXP == 0 || M3_EXP == 3) request_rows(req.eb, req.e1); }
+                    else if (w == 2) { if (M3_EXP == 0 || M3_EXP == 3) load_res(cur.n, resC); }
+                    else if (w < 13) {   // the A operand: k-step 2 is contracted from tick 7 on
+                        const int v = w - 3;
+                        if (nk > 2 + v / 5) {
+                            gen_a_part(v % 5, klo + 32 + 16 * (v / 5), xsqC, envC, Ah[2 + v / 5], Al[2 + v / 5]);
+                        } else if (v % 5 == 4) {
                             const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                            Ah[2 + w / 5] = z8; Al[2 + w / 5] = z8;
+                            Ah[2 + v / 5] = z8; Al[2 + v / 5] = z8;
                         }
                     } else {
-                        const int r = w - 10;
-                        if (r + M3_D < 16) {
-                            request_xc(r + M3_D);
-                            ro_next = r + M3_D + 1 < 16 ? meta_roff(par ^ 1, r + M3_D + 1) : meta_roff(par, 0);
-                        } else {
+                        const int r = w - 13;
+                        if (r + M3_DC < 16) {
+                            request_xc(r + M3_DC);
+                            ro_next = meta_roff(pprev, r + M3_DC + 1 < 16 ? r + M3_DC + 1 : 15);
+                        }
+                        if (r == 16 - M3_D - 1) ro_next = meta_roff(par, 0);
+                        if (r >= 16 - M3_D) {
                             request_x4(r - (16 - M3_D), 0);   // rows 0.. of this block's j = 0 pieces
                             ro_next = meta_roff(par, r - (16 - M3_D) + 1);
                         }
                         const float4 m = mnext;
-                        if (r + 1 < 16) mnext = meta_row(par ^ 1, r + 1);
+                        if (r + 1 < 16) mnext = meta_row(pprev, r + 1);
                         const float t3 = gza[r] * acc[4][r];
                         ra0 += t3 * m.y; rb0 += t3 * m.z; rc0 += t3 * m.w;
                         const float u3 = gzb[r] * acc[5][r];
@@ -419,31 +433,23 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
                 M3_TICK_END();
             }
         }
-        if (prv.have && prv.last) finish_target(prv.orow, res);
-        // ---- P2: a1, b1 of t  ||  W(t+1), R(t+2), residual rows, consume a0, b0 of t          [ro_next = offset of row D]
-        M3Block req;
+        if (prv.have && prv.last) finish_target(prv.orow, resP);
+        // ---- P2: a1, b1 of t  ||  consume a0, b0 of t                                        [ro_next = offset of row D]
         {
-            constexpr int W = 3 + 16;
 #pragma unroll
             for (int s = 0; s < 26; ++s) {
                 mfma_slot(26 + s, klo);
 #pragma unroll
-                for (int w = s * W / 26; w < (s + 1) * W / 26; ++w) {
-                    if (w == 0) window_stage(nxt, par ^ 1, xsqN, envN);
-                    else if (w == 1) { next_request(nxt, req); if (M3_EXP == 0 || M3_EXP == 3) request_rows(req.eb, req.e1); }
-                    else if (w == 2) { if (M3_EXP == 0 || M3_EXP == 3) load_res(cur.n, res); }
-                    else {
-                        const int r = w - 3;
-                        if (r + M3_D < 16) {
-                            request_x4(r + M3_D, 0);
-                            ro_next = r + M3_D + 1 < 16 ? meta_roff(par, r + M3_D + 1) : meta_roff(par, 0);
-                        } else {
-                            request_x4(r + M3_D - 16, 640);   // rows 0.. of the j = 1 pieces: their registers were consumed D rows ago
-                            ro_next = meta_roff(par, r + M3_D - 16 + 1);
-                        }
-                        sx0 += g4[r].w * acc[0][r];
-                        if (!VZ) { sa0 += g4[r].x * acc[2][r]; sb0 += g4[r].y * acc[2][r]; sc0 += g4[r].z * acc[2][r]; }
+                for (int r = s * 16 / 26; r < (s + 1) * 16 / 26; ++r) {
+                    if (r + M3_D < 16) {
+                        request_x4(r + M3_D, 0);
+                        ro_next = r + M3_D + 1 < 16 ? meta_roff(par, r + M3_D + 1) : meta_roff(par, 0);
+                    } else {
+                        request_x4(r + M3_D - 16, 640);   // rows 0.. of the j = 1 pieces: their registers were consumed D rows ago
+                        ro_next = meta_roff(par, r + M3_D - 16 + 1);
                     }
+                    sx0 += g4[r].w * acc[0][r];
+                    if (!VZ) { sa0 += g4[r].x * acc[2][r]; sb0 += g4[r].y * acc[2][r]; sc0 += g4[r].z * acc[2][r]; }
                 }
                 M3_TICK_END();
             }
@@ -461,10 +467,12 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
                 for (int r = s * 16 / 26; r < (s + 1) * 16 / 26; ++r) {
                     if (r + M3_D < 16) {
                         request_x4(r + M3_D, 640);
-                        ro_next = r + M3_D + 1 < 16 ? meta_roff(par, r + M3_D + 1) : meta_roff(par, 0);
-                    } else {
-                        request_xc(r + M3_D - 16);   // rows 0.. of this block's xc pieces (consumed in the next P1)
-                        ro_next = meta_roff(par, r + M3_D - 16 + 1);
+                        ro_next = meta_roff(par, r + M3_D + 1 < 16 ? r + M3_D + 1 : 15);
+                    }
+                    if (r >= 16 - M3_DC) {   // rows 0.. of this block's xc pieces (consumed in the next P1); their offset is read here
+                        ro_next = meta_roff(par, r - (16 - M3_DC));
+                        request_xc(r - (16 - M3_DC));
+                        if (r + M3_D + 1 < 16) ro_next = meta_roff(par, r + M3_D + 1);
                     }
                     sx1 += g4[r].w * acc[1][r];
                     if (!VZ) { sa1 += g4[r].x * acc[3][r]; sb1 += g4[r].y * acc[3][r]; sc1 += g4[r].z * acc[3][r]; }
@@ -476,29 +484,32 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
         // rotate
         prv = cur; cur = nxt; nxt = req;
         xsqC = xsqN; envC = envN;
-        par ^= 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) resP[i] = resC[i];
+        par = pnext;
     };
 
     while (cur.have) body();
     // drain: column blocks c0, c1 of the last block, then its target
     {
+        const int pprev = par == 0 ? 2 : par - 1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (r + M3_D < 16) { ro_next = meta_roff(par ^ 1, r + M3_D); request_xc(r + M3_D); }
-            const float4 m = meta_row(par ^ 1, r);
+            if (r + M3_DC < 16) { ro_next = meta_roff(pprev, r + M3_DC); request_xc(r + M3_DC); }
+            const float4 m = meta_row(pprev, r);
             const float t3 = gza[r] * acc[4][r];
             ra0 += t3 * m.y; rb0 += t3 * m.z; rc0 += t3 * m.w;
             const float u3 = gzb[r] * acc[5][r];
             ra1 += u3 * m.y; rb1 += u3 * m.z; rc1 += u3 * m.w;
         }
     }
-    if (prv.have) finish_target(prv.orow, res);
+    if (prv.have) finish_target(prv.orow, resP);
     if (p.kcount && lane == 0) atomicAdd(p.kcount, (unsigned long long)ksteps);
 #undef M3_ROW
 }
 
 static size_t m3_lds_bytes() {
-    return (size_t)2 * MSG_COLS * MSG_LDK * 2 + sizeof(float) * (128 + M3_WAVES * 2 * 32 * 4);
+    return (size_t)2 * MSG_COLS * MSG_LDK * 2 + sizeof(float) * (128 + M3_WAVES * 3 * 32 * 4);
 }
 
 int32_t adf_message3_prepare() {
