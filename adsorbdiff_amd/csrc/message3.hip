@@ -8,9 +8,11 @@
 // gfx950 that does not overlap (profiles/r02/r02_issue_rates.txt: "split roles" 118 cycles per MFMA against 44 for the same
 // mix issued from ONE stream), so its launch time is MFMA time + VALU time (MfmaUtil 38 %, VALUBusy 47 %, adding up).
 // What does overlap is a wave's own stream with ~6 vector instructions between two MFMAs.  Hence, per block t:
-//     P1: MFMA chains a0, b0 of t   ||  consume c0, c1 of t-1   (xc pieces, r_hat)      + A operand of k-steps 2, 3 of t
-//     P2: MFMA chains a1, b1 of t   ||  consume a0, b0 of t     ((P0,P1,P2,xa) of j=0)  + W stage of t+1, A k-step 0 of t+1
-//     P3: MFMA chains c0, c1 of t   ||  consume a1, b1 of t     ((P0,P1,P2,xa) of j=1)  + A k-step 1 of t+1
+//     P1: MFMA chains a0, b0 of t   ||  consume c0, c1 of t-1   (xc pieces, r_hat)      + W stage of t+1, R stage of t+2,
+//                                                                                          A operand of k-steps 2, 3 of t
+//     P2: MFMA chains a1, b1 of t   ||  consume a0, b0 of t     ((P0,P1,P2,xa) of j=0)
+//     P3: MFMA chains c0, c1 of t   ||  consume a1, b1 of t     ((P0,P1,P2,xa) of j=1)  + A operand of k-steps 0, 1 of t+1
+//                                                                                          (in place, behind their last use)
 // (j = the lane's channel c0+q / c0+32+q; a/b/c = the three H-wide parts of rbf_proj.)  The A operand of all k-steps of a
 // block is held in registers, an accumulator pair is consumed while the next pair is contracted (4 accumulators live
 // instead of 6), and a gathered record piece is needed by ONE phase only, so it is requested a few rows ahead of its
