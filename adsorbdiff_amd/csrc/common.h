@@ -242,6 +242,7 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
                          const int32_t* tlist = nullptr, int n_targets = 0, const float* rec = nullptr,
                          const int32_t* n_targets_dev = nullptr);  // n_targets_dev: the list length lives on the device
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s);
+int32_t adf_pack_rbf_layer(adf_painn* h, int l, hipStream_t s);
 int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec, bool vec_is_zero, hipStream_t s,
                          float* rec = nullptr);
 int32_t adf_nodewise_embed(adf_painn* h, const int32_t* Z, int N, float* x, hipStream_t s);

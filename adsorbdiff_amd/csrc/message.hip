@@ -502,6 +502,28 @@ static size_t msg_lds_bytes(int R, bool f16) {
     return w + sizeof(float) * (MSG_COLS + 128 + MSG_WAVES * 32 * 8) + 16;
 }
 
+// The message kernel's images of ONE layer's rbf_proj (f32 image, fp16 hi/lo image, bias images, scale) from the weight
+// tensors the handle is bound to.  adf_pack_rbf calls it for every layer at adf_painn_set_weights; the training step calls
+// it per layer and step (the optimizer updates the bound tensors in place).
+int32_t adf_pack_rbf_layer(adf_painn* h, int l, hipStream_t s) {
+    const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
+    const size_t per_layer = (size_t)(H / ADF_SLICE_CH) * R * MSG_COLS;
+    const size_t per_layer_b = (size_t)(H / ADF_SLICE_CH) * MSG_COLS;
+    hipLaunchKernelGGL(adf_pack_rbf_kernel, dim3(256), dim3(256), 0, s, h->layer[l].rbf_w, h->layer[l].rbf_b,
+                       h->rbf_pack + l * per_layer, h->rbf_bias_pack + l * per_layer_b, H, R);
+    ADF_HIP_CHECK(hipMemsetAsync(h->w16_scratch, 0, sizeof(unsigned int), s));
+    hipLaunchKernelGGL(adf_absmax_kernel, dim3(64), dim3(256), 0, s, h->layer[l].rbf_w, (long long)3 * H * R,
+                       h->w16_scratch);
+    // the bias shares the scale (it enters the same accumulators through the matrix core)
+    hipLaunchKernelGGL(adf_absmax_kernel, dim3(8), dim3(256), 0, s, h->layer[l].rbf_b, (long long)3 * H,
+                       h->w16_scratch);
+    hipLaunchKernelGGL(adf_pack_rbf16_kernel, dim3(256), dim3(256), 0, s, h->layer[l].rbf_w, h->layer[l].rbf_b,
+                       h->w16_scratch, reinterpret_cast<_Float16*>(h->rbf_pack16) + l * 2 * per_layer,
+                       h->rbf_bias_pack16 + l * per_layer_b, h->rbf_scales + l, H, R);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
 int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
     {   // are the Gaussian centres the linspace(0, 1, R) of GaussianSmearing?  (a buffer, but a checkpoint may carry another)
@@ -513,21 +535,7 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
         const char* e = getenv("ADF_MSG_RBF");
         h->rbf_uniform = uni && !(e && strcmp(e, "direct") == 0);
     }
-    const size_t per_layer = (size_t)(H / ADF_SLICE_CH) * R * MSG_COLS;
-    const size_t per_layer_b = (size_t)(H / ADF_SLICE_CH) * MSG_COLS;
-    for (int l = 0; l < h->hp.num_layers; ++l) {
-        hipLaunchKernelGGL(adf_pack_rbf_kernel, dim3(256), dim3(256), 0, s, h->layer[l].rbf_w, h->layer[l].rbf_b,
-                           h->rbf_pack + l * per_layer, h->rbf_bias_pack + l * per_layer_b, H, R);
-        ADF_HIP_CHECK(hipMemsetAsync(h->w16_scratch, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL(adf_absmax_kernel, dim3(64), dim3(256), 0, s, h->layer[l].rbf_w, (long long)3 * H * R,
-                           h->w16_scratch);
-        // the bias shares the scale (it enters the same accumulators through the matrix core)
-        hipLaunchKernelGGL(adf_absmax_kernel, dim3(8), dim3(256), 0, s, h->layer[l].rbf_b, (long long)3 * H,
-                           h->w16_scratch);
-        hipLaunchKernelGGL(adf_pack_rbf16_kernel, dim3(256), dim3(256), 0, s, h->layer[l].rbf_w, h->layer[l].rbf_b,
-                           h->w16_scratch, reinterpret_cast<_Float16*>(h->rbf_pack16) + l * 2 * per_layer,
-                           h->rbf_bias_pack16 + l * per_layer_b, h->rbf_scales + l, H, R);
-    }
+    for (int l = 0; l < h->hp.num_layers; ++l) ADF_TRY(adf_pack_rbf_layer(h, l, s));
     ADF_HIP_CHECK(hipGetLastError());
     {   // per device (a function attribute is per device; set_weights is rare, so no caching)
 #define SET_LDS(F16_, VZ_, UNI_)                                                                              \

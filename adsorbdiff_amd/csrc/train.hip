@@ -749,6 +749,24 @@ extern "C" int32_t adf_op_message_fwd(adf_painn_t h, const float* xh, const floa
     TR_CHECK_LAUNCH();
     return ADF_OK;
 }
+// The same forward through the SAMPLER's fused kernel (message.hip: radial-basis projection on the matrix cores inside the
+// kernel, no [E,3H] read): the layer's rbf_proj images are rebuilt from the current parameter values first.  The backward
+// still reads the materialised rbfh (adf_op_linear_fwd of the training step writes it for that purpose).
+extern "C" int32_t adf_op_message_fwd_fused(adf_painn_t h, int32_t layer, const float* xh, const float* vec, const float* x,
+                                            float* x1, float* vec1, int32_t vec_is_zero, void* stream) {
+    if (!h || h->lastN <= 0 || !h->weights_set || layer < 0 || layer >= h->hp.num_layers || !xh || !x || !x1 || !vec1 ||
+        (!vec && !vec_is_zero)) {
+        adf_set_error("message_fwd_fused: bad argument or no graph");
+        return ADF_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int N = (int)h->lastN, H = h->hp.hidden_channels;
+    const size_t row = (size_t)(H / 32) * 160;
+    ADF_TRY(adf_pack_rbf_layer(h, layer, s));
+    ADF_HIP_CHECK(hipMemsetAsync(h->rec + (size_t)N * row, 0, sizeof(float) * row, s));   // padded edge rows gather record N
+    ADF_TRY(adf_pack_records(h, N, xh, vec, vec_is_zero != 0, s));
+    return adf_message_impl(h, layer, N, x, xh, vec, x1, vec1, vec_is_zero != 0, s);
+}
 extern "C" int32_t adf_op_message_bwd(adf_painn_t h, const float* xh, const float* vec, const float* rbfh, const float* gx1,
                                       const float* gv1, float* dxh, float* drbfh, float* dvec, float* dx,
                                       int32_t vec_is_zero, void* stream) {

@@ -17,6 +17,8 @@ against the reference's own autograd (tests/golden/train_small.npz: loss + gradi
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from typing import Dict, List, Optional
@@ -79,6 +81,8 @@ class PaiNNTrainStep:
         self.ops = _Ops(self.dev)
         self.lib = self.ops.lib
         self.igso3 = igso3 or Igso3Tables.shared()
+        # forward of the message block through the sampler's fused kernel (ADF_TRAIN_MSG=plain: the rbfh-reading kernel)
+        self.fused_message_forward = os.environ.get("ADF_TRAIN_MSG", "fused") != "plain"
 
     # ------------------------------------------------------------------ helpers
     def _params(self) -> Dict[str, torch.nn.Parameter]:
@@ -144,9 +148,15 @@ class PaiNNTrainStep:
             a["xh"] = ops.linear(a["c"], P[mp + "x_proj.2.weight"], P[mp + "x_proj.2.bias"], N, 3 * H, H)
             a["rbfh"] = ops.linear(rbf, P[mp + "rbf_proj.weight"], P[mp + "rbf_proj.bias"], E, 3 * H, R)
             a["x1"], a["vec1"] = ops.new(N, H), ops.new(N, 3, H)
-            _lib.check(lib.adf_op_message_fwd(h, a["xh"].data_ptr(), vec.data_ptr() if vec is not None else None,
-                                              a["rbfh"].data_ptr(), x.data_ptr(), a["x1"].data_ptr(), a["vec1"].data_ptr(),
-                                              1 if vec is None else 0, s()))
+            if self.fused_message_forward:
+                # the sampler's fused kernel (no read of the 6 KB-per-edge rbfh; it stays materialised for the backward)
+                _lib.check(lib.adf_op_message_fwd_fused(h, l, a["xh"].data_ptr(), vec.data_ptr() if vec is not None else None,
+                                                        x.data_ptr(), a["x1"].data_ptr(), a["vec1"].data_ptr(),
+                                                        1 if vec is None else 0, s()))
+            else:
+                _lib.check(lib.adf_op_message_fwd(h, a["xh"].data_ptr(), vec.data_ptr() if vec is not None else None,
+                                                  a["rbfh"].data_ptr(), x.data_ptr(), a["x1"].data_ptr(), a["vec1"].data_ptr(),
+                                                  1 if vec is None else 0, s()))
             a["vv"] = ops.linear(a["vec1"], P[up + "vec_proj.weight"], None, 3 * N, 2 * H, H)
             a["cat"], a["dot"] = ops.new(N, 2 * H), ops.new(N, H)
             _lib.check(lib.adf_op_copy_rows(a["x1"].data_ptr(), H, a["cat"].data_ptr(), 2 * H, N, H, 0, s()))

@@ -333,6 +333,11 @@ int32_t adf_op_embed_bwd(const float* dx, const int32_t* Z, float* demb, int32_t
 int32_t adf_op_rbf(adf_painn_t h, float* rbf, void* stream);
 int32_t adf_op_message_fwd(adf_painn_t h, const float* xh, const float* vec, const float* rbfh, const float* x, float* x1,
                            float* vec1, int32_t vec_is_zero, void* stream);
+/* The same forward through the sampler's fused message kernel (no [E,3H] operand: the radial-basis projection runs inside the
+ * kernel on the matrix cores, painn_denoising.py:530-567); the layer's rbf_proj images are rebuilt from the bound weight
+ * tensors first (the optimizer updates them in place).  Outputs agree with adf_op_message_fwd to ~1e-6 relative. */
+int32_t adf_op_message_fwd_fused(adf_painn_t h, int32_t layer, const float* xh, const float* vec, const float* x, float* x1,
+                                 float* vec1, int32_t vec_is_zero, void* stream);
 int32_t adf_op_message_bwd(adf_painn_t h, const float* xh, const float* vec, const float* rbfh, const float* gx1,
                            const float* gv1, float* dxh, float* drbfh, float* dvec, float* dx, int32_t vec_is_zero,
                            void* stream);
