@@ -40,6 +40,10 @@
 
 #include "message.h"
 
+#ifndef MSG_EXP_NOXC
+#define MSG_EXP_NOXC 0   // timing experiment only (wrong results): no xc gathers
+#endif
+
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -232,8 +236,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
     float4 ga0##r, ga1##r;                                     /* P0 P1 P2 xa of channel j = 0, 1 */ \
     float gz0##r, gz1##r;                                      /* xc */                               \
+    if (MSG_EXP_NOXC) { gz0##r = 1.0f; gz1##r = 2.0f; } else {                                 \
     gz0##r = *reinterpret_cast<const float*>(recP + o##r);                                      \
-    gz1##r = *reinterpret_cast<const float*>(recP + o##r + 640);                                \
+    gz1##r = *reinterpret_cast<const float*>(recP + o##r + 640); }                              \
     if (!VZ) {                                                                                  \
         ga0##r = *reinterpret_cast<const float4*>(recA + o##r);                                 \
         ga1##r = *reinterpret_cast<const float4*>(recA + o##r + 640);                           \

@@ -37,9 +37,13 @@
 #define M3_THREADS 512
 #define M3_WAVES 8
 #define M3_ULIM 44.0f  // a block takes rows while u <= u_first + 44 (u = (R-1) d / rc): window <= 64 after alignment
+#ifndef M3_D
 #define M3_D 4         // (P0,P1,P2,xa) pieces: rows requested ahead of the consumed one
+#endif
+#ifndef M3_DC
 #define M3_DC 8        // xc pieces (2 registers per row): deeper - the first 8 rows of P1 then only wait for loads that are
                        // OLDER than the block's streaming loads (edge rows of block t+2, residual rows), see body()
+#endif
 #ifndef M3_EXP
 #define M3_EXP 0       // timing experiments only (wrong results): 1 no edge-row / residual loads in the loop; 2 also no gathers;
 #endif                 // 3 every gather reads the all-zero record (L1 hits)
@@ -49,7 +53,10 @@ typedef __fp16 m3_h2 __attribute__((ext_vector_type(2)));
 // End of one issue slot ("tick": one MFMA + its share of the phase's vector work).  Nothing but LDS reads and scalar
 // instructions may be moved across it: the MFMA / VALU / vector-memory interleave is the one written in the source
 // (hipcc otherwise issues the dependent MFMAs of a chain back to back and the vector work behind them - no overlap).
-#define M3_TICK_END() __builtin_amdgcn_sched_barrier(0x104)
+#ifndef M3_TICK_MASK
+#define M3_TICK_MASK 0x104
+#endif
+#define M3_TICK_END() __builtin_amdgcn_sched_barrier(M3_TICK_MASK)
 
 struct M3Block {  // wave-uniform
     int n, orow, eb, e1, nrows, last, klo, nk, have;
