@@ -32,7 +32,7 @@ struct MsgParams {
     float inv_cutoff, coeff, sarg, env_a, env_b, env_c;
     float dmu2, dmusq, cstep;  // UNI: 2*dmu', dmu'^2, exp2(-2 dmu'^2) with dmu' = scaled spacing of the centres
     int env_pi;
-    unsigned long long* kcount;  // optional: sum over 32-row blocks of the contracted k length (profiling)
+    unsigned long long* kcount;  // optional: sum over 32-row blocks of contracted k length x 32-column blocks run (profiling)
 };
 
 

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             }
             klo = __builtin_amdgcn_readfirstlane(klo);
             khi = __builtin_amdgcn_readfirstlane(khi);
-            ksteps += khi - klo;
+            ksteps += (khi - klo) * (VZ && F16 ? 4 : 6);  // contracted k length x 32-column blocks that run (profiling)
 
             // Gather addresses of the 16 accumulator rows of this lane (32-bit byte offsets).
 #define ROW_OF(r) ((r & 3) + 8 * (r >> 2) + 4 * hi)
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                 const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int b = 0; b < 6; ++b) {
+                    if (VZ && (b == 2 || b == 3)) continue;
                     const half8 bb = *reinterpret_cast<const half8*>(Wh + (size_t)(b * 32 + q) * MSG_LDK + 128);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aone, bb, zero16, 0, 0, 0);
                 }
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                     const _Float16* wl = Wlo + (size_t)q * MSG_LDK + k0 + 8 * hi;
 #pragma unroll
                     for (int b = 0; b < 6; ++b) {
+                        if (VZ && (b == 2 || b == 3)) continue;   // vec == 0: the xb columns multiply P = vec * xb = 0
                         const half8 bh = *reinterpret_cast<const half8*>(wh + b * 32 * MSG_LDK);
                         const half8 bl = *reinterpret_cast<const half8*>(wl + b * 32 * MSG_LDK);
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(M3_THREADS, 2) void adf_message3_kernel(MsgParams p
                 M3_TICK_END();
             }
         }
-        ksteps += 64;   // what the matrix cores execute (4 k-steps per block)
+        ksteps += 64 * (VZ ? 4 : 6);   // what the matrix cores execute: 4 k-steps x the column blocks that run
         // rotate
         prv = cur; cur = nxt; nxt = req;
         xsqC = xsqN; envC = envN;

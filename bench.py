@@ -510,7 +510,9 @@ def main():
         E_launch = counters.inc_msg_edges / counters.inc_msg_launches if inc_on else float(E)
         T_launch = counters.inc_rows / counters.inc_msg_launches if inc_on else float(N_atoms)
         dense_flops_per_launch = 2.0 * R * 3 * H * E_launch
-        issued_flops_per_launch = prof["message_ksteps"] * 32 * 192 * 2.0 * products / max(msg_launches, 1)
+        # message_ksteps = sum over 32-edge blocks of (contracted k length x 32-column blocks that ran: 6, or 4 in the vec == 0
+        # launches of layer 0, whose xb columns are skipped)
+        issued_flops_per_launch = prof["message_ksteps"] * 32 * 32 * 2.0 * products / max(msg_launches, 1)
         avg_s = msg_ms * 1e-3 / max(msg_launches, 1)
         issued = issued_flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
         dense_equiv = dense_flops_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
@@ -596,8 +598,8 @@ def main():
                 "l2_gather_tbps": gathered_bytes / avg_s / 1e12 if avg_s > 0 else 0.0,
                 "hbm_algorithmic_gbps": hbm_alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0,
                 "hbm_algorithmic_frac": (hbm_alg_bytes / avg_s / 1e9) / PEAK_HBM_GBS if avg_s > 0 else 0.0,
-                "note": "achieved = matrix-core flops the kernel issues (k-window x 32 x 192 x 2 per 32-edge row "
-                        "block, padded rows and the 3 split products included) / launch time from HIP events on the "
+                "note": "achieved = matrix-core flops the kernel issues (k-window x 32 rows x the 32-column blocks that run x 2 "
+                        "per 32-edge row block, padded rows and the 3 split products included) / launch time from HIP events on the "
                         "launch stream. This is the conservative count: the algorithm's dense contraction (SURVEY 8d: "
                         "2*R*3H*E per layer, x3 products in this arithmetic = algorithmic_f16x3_tflops) is ~1.9x larger, "
                         "the k-window skips Gaussian terms below 1.5e-8 of the leading one. Timed on the "

@@ -258,8 +258,9 @@ int32_t adf_get_counters(adf_painn_t h, adf_counters* out, void* stream);
  * 2 node-side dense blocks (LayerNorm + GEMMs + update), 3 output heads, 4 stepper.
  * adf_profile_read synchronises, returns summed milliseconds and number of timed groups per
  * category (arrays of 5) and resets the log.  *message_ksteps (optional) = sum over all 32-edge
- * row blocks of all message launches of the k-window length actually contracted; executed MFMA
- * flops of the message kernel = message_ksteps * 32 * 192 * 2. */
+ * row blocks of all message launches of (k-window length actually contracted x 32-column blocks that ran: 6, or 4 in
+ * the vec == 0 launches of the first layer); executed MFMA flops of the message kernel = message_ksteps * 32 * 32 * 2
+ * (x 3 products in the f16x3 arithmetic). */
 #define ADF_PROF_NCAT 5
 int32_t adf_profile_enable(adf_painn_t h, int32_t on);
 int32_t adf_profile_read(adf_painn_t h, float* ms, int64_t* count, int64_t* message_ksteps, void* stream);
