@@ -405,3 +405,30 @@ def test_eqv2_config4_width_vs_oracle():
     assert e1 < REL_TOL and e2 < REL_TOL
     for got, ref in ((f1.cpu(), r1), (f2.cpu(), r2)):
         assert float((got - ref).abs().max()) < REL_TOL * float(ref.norm(dim=1).max())
+
+
+def test_eqv2_sampling_with_trajectory_sink(tmp_path):
+    """adf_eqv2_sample_traj: the EquiformerV2 sampler with the asynchronous trajectory sink (csrc/frames.hip + trajectory.py)
+    ends at the same positions as without it and writes one frame per applied step, the last one equal to the result."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    m = make_model(4, 2, C=8, hidden=8, heads=2, alpha=4, value=4, ffn=16, ec=8, layers=1, cutoff=12.0)
+    m.so3_denoising = True
+    b = safe_batch(2, 196, seed=21)
+    params = dict(num_steps=4, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True, early_stop=False)
+    torch.manual_seed(5)
+    noise = torch.rand(2, 3)
+    trainer = DenoisingTrainer(m.to(DEV), device=DEV)
+    outs = []
+    for traj in (None, tmp_path):
+        den = Denoiser(b.clone().to(DEV), DiffTorchCalc(trainer), dict(params, placement_noise=noise), device=DEV,
+                       traj_dir=traj, traj_names=[str(s) for s in b.sid], save_full_traj=True)
+        outs.append(den.run().pos.cpu())
+        assert den.steps_applied == 4
+    assert torch.equal(outs[0], outs[1])
+    n0 = int(b.natoms[0])
+    z = np.load(tmp_path / f"{b.sid[0]}.npz")
+    assert z["positions"].shape == (4, n0, 3)
+    assert np.array_equal(z["positions"][-1], outs[1][:n0].numpy())
+    assert np.array_equal(np.load(tmp_path / f"batch_{b.sid[0]}.frames.npy")[-1], outs[1].numpy())
