@@ -36,8 +36,9 @@ extern "C" int32_t adf_frames_create(int32_t device, int64_t frame_floats, int32
     ADF_HIP_CHECK(hipSetDevice(device));
     adf_frames* f = new adf_frames();
     f->device = device; f->frame_floats = frame_floats; f->slots = slots; f->pushed = 0;
-    f->stage[0] = f->stage[1] = nullptr; f->ring = nullptr;
-    f->landed = new std::vector<hipEvent_t>(slots);
+    f->stage[0] = f->stage[1] = nullptr; f->ring = nullptr; f->copy_stream = nullptr;
+    f->staged[0] = f->staged[1] = f->drained[0] = f->drained[1] = nullptr;
+    f->landed = new std::vector<hipEvent_t>(slots, (hipEvent_t) nullptr);
     f->slot_frame = new std::vector<int64_t>(slots, -1);
     f->mu = new std::mutex(); f->cv = new std::condition_variable();
     f->drained_live[0] = f->drained_live[1] = false;
@@ -53,7 +54,19 @@ extern "C" int32_t adf_frames_create(int32_t device, int64_t frame_floats, int32
     for (int s = 0; s < slots && e == hipSuccess; ++s) e = hipEventCreateWithFlags(&(*f->landed)[s], hipEventDisableTiming);
     if (e != hipSuccess) {
         adf_set_error("frames_create: %s", hipGetErrorString(e));
-        *out = nullptr;   // (partially built sink: freed by the process; creation fails once, at start-up)
+        (void)hipGetLastError();
+        // release whatever was created (null / zero handles are skipped)
+        for (int k = 0; k < 2; ++k) {
+            if (f->stage[k]) (void)hipFree(f->stage[k]);
+            if (f->staged[k]) (void)hipEventDestroy(f->staged[k]);
+            if (f->drained[k]) (void)hipEventDestroy(f->drained[k]);
+        }
+        for (hipEvent_t ev : *f->landed) if (ev) (void)hipEventDestroy(ev);
+        if (f->ring) (void)hipHostFree(f->ring);
+        if (f->copy_stream) (void)hipStreamDestroy(f->copy_stream);
+        delete f->landed; delete f->slot_frame; delete f->mu; delete f->cv;
+        delete f;
+        *out = nullptr;
         return e == hipErrorOutOfMemory ? ADF_EOOM : ADF_EHIP;
     }
     *out = f;
