@@ -1187,3 +1187,28 @@ def test_interleaved_message_kernel_agrees_with_the_default(monkeypatch):
     m = small_model(fx)
     f1, f2 = m(batch_from_fixture(fx, device=DEV))
     assert rel_err(f1.cpu(), fx["f1"]) < REL_TOL and rel_err(f2.cpu(), fx["f2"]) < REL_TOL
+
+
+def test_interleaved_message_kernel_in_the_sampling_loop(monkeypatch):
+    """ADF_MSG_KERNEL=v3 through the whole sampler (target lists of the incremental layers, compact output rows, the
+    vec == 0 first layer, adsorbate-only outputs): the sampled positions agree with the default kernel's run at the size of
+    the two kernels' arithmetic difference (1e-6 per forward; 8 well-conditioned steps), and a v3 run with incremental
+    layers equals a v3 run without them bit for bit."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    fx = load_npz("stepper_ode8.npz")
+    res = {}
+    for kernel, extra in (("v1", {}), ("v3", {}), ("v3", {"incremental_layers": False}), ("v3", {"scores_on_adsorbate_only": True})):
+        monkeypatch.setenv("ADF_MSG_KERNEL", kernel)
+        tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
+        b = batch_from_fixture(fx, pos_key="pos_in")
+        torch.manual_seed(int(fx["seed"]))
+        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), early_stop=False, **extra), device=DEV)
+        res[(kernel, tuple(extra))] = den.run().pos.cpu()
+        tr._unwrapped_model.engine().close()
+    ref = res[("v1", ())]
+    assert float((res[("v3", ())] - ref).abs().max()) < 2e-4
+    np.testing.assert_allclose(res[("v3", ())].numpy(), fx["pos_final"], rtol=0, atol=2e-4)
+    assert torch.equal(res[("v3", ())], res[("v3", ("incremental_layers",))])
+    assert torch.equal(res[("v3", ())], res[("v3", ("scores_on_adsorbate_only",))])
