@@ -41,7 +41,7 @@
 #include "message.h"
 
 #ifndef MSG_EXP_NOXC
-#define MSG_EXP_NOXC 0   // timing experiment only (wrong results): no xc gathers
+#define MSG_EXP_NOXC 0   // timing experiments only (wrong results): 1 no xc gathers; 2 no record gathers at all
 #endif
 
 __device__ __forceinline__ float wave_min(float v) {
@@ -239,7 +239,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     if (MSG_EXP_NOXC) { gz0##r = 1.0f; gz1##r = 2.0f; } else {                                 \
     gz0##r = *reinterpret_cast<const float*>(recP + o##r);                                      \
     gz1##r = *reinterpret_cast<const float*>(recP + o##r + 640); }                              \
-    if (!VZ) {                                                                                  \
+    if (MSG_EXP_NOXC == 2) { ga0##r = make_float4(1.f, 2.f, 3.f, 4.f); ga1##r = ga0##r; }      \
+    else if (!VZ) {                                                                             \
         ga0##r = *reinterpret_cast<const float4*>(recA + o##r);                                 \
         ga1##r = *reinterpret_cast<const float4*>(recA + o##r + 640);                           \
     } else {                                                                                    \
