@@ -117,6 +117,20 @@ struct adf_eqv2 {
     void *gtab_to, *gtab_from; int g_npb, g_nkst; float g_inv_sT, g_inv_sF;  // likewise for to_full / from_full
     float* rs; int64_t rs_cap;   // per-row magnitudes max|a| of the A operand of an f16x3 product (-> power-of-two lift)
     int64_t lastN;
+    // incremental blocks (adf_eqv2_set_incremental): the embedding and every block's output are kept across the forwards
+    // of a static-atom run and a block recomputes only the rows whose inputs changed (eq_launch_inc_lists)
+    bool inc_on, inc_valid;
+    int64_t inc_N, inc_capN, inc_capE;
+    int inc_nl;
+    float* inc_x[EQ_MAX_LAYERS + 1];   // [capN, S, C] each: embedding, then the blocks' outputs
+    float* inc_xg;                     // the rows being recomputed, compact
+    int32_t *inc_peptr, *inc_psrc; float* inc_pvec;   // the previous forward's graph
+    unsigned char* inc_dirty;          // [2][capN]
+    int32_t *inc_idx, *inc_cnt;        // [nl][capN] ascending row lists, [nl] their lengths
+    void* inc_sel_tmp; size_t inc_sel_bytes;
+    int64_t inc_rows, inc_rows_full;   // block rows recomputed / block rows of full forwards since set_incremental
+    int64_t last_block_rows;           // block rows the last forward computed (all blocks: layers x N)
+    int64_t prof_block_rows, prof_forwards;   // the same summed over the forwards since adf_eqv2_profile_enable(1)
     // HIP-event timing per kernel group (bench.py roofline)
     bool prof_on;
     std::vector<hipEvent_t>* prof_ev;
@@ -166,6 +180,12 @@ int32_t eq_launch_force_out(const adf_eqv2* h, const eq_attn* at, const float* a
 // CSR + edge arrays of the listed targets only (sub_* of the handle); then rows of f_sub scattered to rows out_idx of f
 int32_t eq_launch_subset_graph(adf_eqv2* h, const int32_t* out_idx, int n_out, hipStream_t s);
 int32_t eq_launch_scatter_rows3(const float* f_sub, const int32_t* out_idx, int n_out, float* f, hipStream_t s);
+// incremental blocks: recompute lists of blocks 0..nl-1 from a bit-for-bit comparison with the kept graph; keep the graph
+size_t eq_inc_select_bytes(int N);
+int32_t eq_launch_inc_lists(adf_eqv2* h, int N, int nl, hipStream_t s);
+int32_t eq_launch_inc_keep(adf_eqv2* h, int N, hipStream_t s);
+int32_t eq_launch_gather_rows(const float* src, const int32_t* idx, int n, int row_floats, float* dst, hipStream_t s);
+int32_t eq_launch_scatter_rows(const float* src, const int32_t* idx, int n, int row_floats, float* dst, hipStream_t s);
 int32_t eq_gemm_f32(const float* A, int lda, const eq_rowmap* amap, const float* W, const float* bias, float* Cm, int ldc,
                     const eq_rowmap* cmap, long long M, int N, int K, int act, bool accumulate, hipStream_t s);
 int32_t eq_launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);

@@ -135,7 +135,17 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     return ADF_OK;
 }
 
+static void eq_inc_free(adf_eqv2* h) {
+    for (int i = 0; i <= EQ_MAX_LAYERS; ++i) eq_free(h->inc_x[i]);
+    eq_free(h->inc_xg); eq_free(h->inc_peptr); eq_free(h->inc_psrc); eq_free(h->inc_pvec); eq_free(h->inc_dirty);
+    eq_free(h->inc_idx); eq_free(h->inc_cnt);
+    if (h->inc_sel_tmp) { (void)hipFree(h->inc_sel_tmp); h->inc_sel_tmp = nullptr; }
+    h->inc_capN = h->inc_capE = 0; h->inc_nl = 0; h->inc_sel_bytes = 0;
+    h->inc_valid = false;
+}
+
 static void eq_free_workspaces(adf_eqv2* h) {
+    eq_inc_free(h);
     eq_free(h->nbr_cnt); eq_free(h->nbr_src); eq_free(h->nbr_shift); eq_free(h->img_cnt); eq_free(h->eptr);
     eq_free(h->e_src); eq_free(h->e_dst); eq_free(h->e_vec); eq_free(h->wig);
     eq_free(h->sub_eptr); eq_free(h->sub_src); eq_free(h->sub_dst); eq_free(h->sub_vec); eq_free(h->sub_wig); eq_free(h->sub_f);
@@ -524,12 +534,14 @@ extern "C" int32_t adf_eqv2_set_weights(adf_eqv2_t h, int32_t n_weights, const v
         for (int i = 0; i < h->hp.num_layers; ++i) h->blk[i].ffn.l2f[0] = h->blk[i].ffn.l2[0];  // l = 0 comes from the gate
     ADF_TRY(eq_radial_static(h, rads, k, s));
     h->weights_set = true;
+    h->inc_valid = false;
     return ADF_OK;
 }
 
 extern "C" int32_t adf_eqv2_set_arithmetic(adf_eqv2_t h, int32_t exact_f32) {
     if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
     h->exact_f32 = exact_f32 != 0;
+    h->inc_valid = false;
     return ADF_OK;
 }
 
@@ -600,6 +612,7 @@ extern "C" int32_t adf_eqv2_set_edges(adf_eqv2_t h, int64_t num_edges, const int
                                       const float* vec, int32_t max_in_degree, void* stream) {
     if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
+    h->inc_valid = false;
     if (num_edges <= 0) { h->ext_graph = false; h->E_ext = 0; return ADF_OK; }
     if (!src || !dst || !vec || max_in_degree < 1 || max_in_degree > 128) { adf_set_error("eqv2_set_edges: bad argument"); return ADF_EINVAL; }
     // private copy; the forward moves it into the (possibly re-allocated) graph workspaces
@@ -622,7 +635,49 @@ extern "C" int32_t adf_eqv2_set_moving(adf_eqv2_t h, const int32_t* moving, cons
     if (moving && (!mov_idx || !mov_off)) { adf_set_error("eqv2_set_moving: need mov_idx and mov_off"); return ADF_EINVAL; }
     h->moving = moving; h->mov_idx = moving ? mov_idx : nullptr; h->mov_off = moving ? mov_off : nullptr;
     h->cache_valid = false;
+    h->inc_valid = false;
     return ADF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- incremental blocks
+extern "C" int32_t adf_eqv2_set_incremental(adf_eqv2_t h, int32_t on) {
+    if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
+    h->inc_on = on != 0;
+    h->inc_valid = false;
+    h->inc_rows = h->inc_rows_full = 0;
+    if (!h->inc_on && h->inc_capN) { ADF_HIP_CHECK(hipDeviceSynchronize()); eq_inc_free(h); }
+    return ADF_OK;
+}
+
+// kept state for the handle's current capacity; an allocation failure switches the mode off instead of failing the forward
+static bool eq_inc_ensure(adf_eqv2* h) {
+    const eq_dims& d = h->d;
+    const int nl = h->hp.num_layers;
+    if (h->inc_capN == h->capN && h->inc_capE == h->capE && h->inc_nl == nl) return true;
+    (void)hipDeviceSynchronize();
+    eq_inc_free(h);
+    const size_t row = (size_t)d.S * d.C, cN = (size_t)h->capN;
+    int32_t st = ADF_OK;
+    for (int i = 0; i <= nl && st == ADF_OK; ++i) st = eq_alloc(&h->inc_x[i], cN * row);
+    if (st == ADF_OK) st = eq_alloc(&h->inc_xg, cN * row);
+    if (st == ADF_OK) st = eq_alloc(&h->inc_peptr, cN + 2);
+    if (st == ADF_OK) st = eq_alloc(&h->inc_psrc, (size_t)h->capE);
+    if (st == ADF_OK) st = eq_alloc(&h->inc_pvec, (size_t)h->capE * 3);
+    if (st == ADF_OK) st = eq_alloc(&h->inc_dirty, 2 * cN);
+    if (st == ADF_OK) st = eq_alloc(&h->inc_idx, (size_t)nl * cN);
+    if (st == ADF_OK) st = eq_alloc(&h->inc_cnt, (size_t)nl + 1);
+    if (st == ADF_OK) {
+        h->inc_sel_bytes = eq_inc_select_bytes((int)cN);
+        if (hipMalloc(&h->inc_sel_tmp, h->inc_sel_bytes ? h->inc_sel_bytes : 16) != hipSuccess) st = ADF_EOOM;
+    }
+    if (st != ADF_OK) {
+        (void)hipGetLastError();
+        eq_inc_free(h);
+        h->inc_on = false;
+        return false;
+    }
+    h->inc_capN = h->capN; h->inc_capE = h->capE; h->inc_nl = nl;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------- dense product dispatch
@@ -814,6 +869,60 @@ static int32_t eq_ensure_subset(adf_eqv2* h, int64_t n_out) {
     return ADF_OK;
 }
 
+// the graph the attention kernels read (through the handle): the full one or the compact copy of a target subset
+struct eq_graph_view { int32_t *eptr, *src, *dst; float *vec, *wig; };
+static eq_graph_view eq_graph_use_subset(adf_eqv2* h) {
+    const eq_graph_view full = {h->eptr, h->e_src, h->e_dst, h->e_vec, h->wig};
+    h->eptr = h->sub_eptr; h->e_src = h->sub_src; h->e_dst = h->sub_dst; h->e_vec = h->sub_vec; h->wig = h->sub_wig;
+    return full;
+}
+static void eq_graph_restore(adf_eqv2* h, const eq_graph_view& v) {
+    h->eptr = v.eptr; h->e_src = v.src; h->e_dst = v.dst; h->e_vec = v.vec; h->wig = v.wig;
+}
+
+// node side of a block on rows [0, n) of X (h->agg holds their aggregated messages):
+// X += proj(agg); X += ffn(norm_2(X))   (transformer_block.py:650-700, 375-531)
+static int32_t eq_block_nodes(adf_eqv2* h, const eq_block& bk, float* X, int n, hipStream_t s) {
+    const eq_dims& d = h->d;
+    { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_so3_linear(h, bk.ga.proj_l, h->agg, d.HV, X, d.C, n, true, s)); }
+    { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &bk.n2, X, h->y, n, s)); }
+    eq_prof_scope ps(h, EQ_PROF_FFN, s);
+    const eq_ffn& f = bk.ffn;
+    // scalar gate from the l = 0 row of every node (row stride S*C)
+    ADF_TRY(eq_gemm(h, h->y, d.S * d.C, nullptr, &f.scalar, true, h->gate, d.F, nullptr, n, 2, false, s));
+    const bool fold = h->folded && !h->exact_f32;
+    ADF_TRY(eq_so3_linear(h, fold ? f.l1f : f.l1, h->y, d.C, h->h1, d.F, n, false, s));
+    for (int n0 = 0; n0 < n; n0 += (int)h->chunk_nodes) {
+        const int n1 = (int)((n0 + h->chunk_nodes < n) ? n0 + h->chunk_nodes : n);
+        const long long rows = (long long)(n1 - n0) * d.G;
+        float* ga = h->garena;
+        float* gb = h->garena + (size_t)h->chunk_nodes * d.G * d.F;
+        if (fold) {  // silu(to_grid(.)) -> one product + SiLU -> from_grid
+            // the product's row lifts: one per NODE (the largest grid value of its tile, left by to_grid) - from_grid
+            // sums a node's rows with comparable weights, so a row far below the node's largest carries no weight
+            bool em = false;
+            const bool want = eq_uses_mfma(h, ga, d.F, &f.g2, gb, d.F) && (n1 - n0) <= h->rs_cap;
+            ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, true, s, want ? h->rs : nullptr, &em));
+            ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g2, false, gb, d.F, nullptr, rows, 2, false, s, em ? h->rs : nullptr,
+                            nullptr, d.G));
+            ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
+            continue;
+        }
+        ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, false, s));
+        // the first product measures its operand rows itself; the next two get them from the producer's epilogue
+        const bool chain = eq_uses_mfma(h, ga, d.F, &f.g0, gb, d.F) && eq_uses_mfma(h, gb, d.F, &f.g2, ga, d.F) &&
+                           eq_uses_mfma(h, ga, d.F, &f.g4, gb, d.F) && 3 * rows <= h->rs_cap;
+        float* m1 = chain ? h->rs + rows : nullptr;
+        float* m2 = chain ? h->rs + 2 * rows : nullptr;
+        ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g0, false, gb, d.F, nullptr, rows, 2, false, s, nullptr, m1));
+        ADF_TRY(eq_gemm(h, gb, d.F, nullptr, &f.g2, false, ga, d.F, nullptr, rows, 2, false, s, m1, m2));
+        ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g4, false, gb, d.F, nullptr, rows, 0, false, s, m2, nullptr));
+        ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
+    }
+    ADF_TRY(eq_so3_linear(h, fold ? f.l2f : f.l2, h->h2, d.F, X, d.C, n, true, s));
+    return ADF_OK;
+}
+
 // out_idx != null: the two force blocks (all that reads the last embedding) run for the listed target atoms only, on a
 // compacted copy of their incoming edges; rows out_idx[*] of f1 / f2 are written, bit-identical to the full forward's
 // (every row of every product, the softmax of a target and its aggregation depend on that target's edges alone).
@@ -838,6 +947,26 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
     }
     h->lastN = N;
     const size_t xs = (size_t)N * d.S * d.C;
+    const int nl = h->hp.num_layers;
+    // incremental blocks: only while the static-atom promise is in force (the same batch, only flagged atoms move)
+    const bool inc = h->inc_on && h->moving && nl > 0 && eq_inc_ensure(h);
+    bool lists = false;
+    int32_t cnt[EQ_MAX_LAYERS];
+    if (inc) {
+        eq_prof_scope ps(h, EQ_PROF_GRAPH, s);
+        if (h->inc_valid && h->inc_N == N) {
+            ADF_TRY(eq_launch_inc_lists(h, N, nl, s));
+            // the list lengths size the launches of this forward: one read-back (the forward is ~10^5 times longer)
+            ADF_HIP_CHECK(hipMemcpyAsync(cnt, h->inc_cnt, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, s));
+            ADF_HIP_CHECK(hipStreamSynchronize(s));
+            lists = true;
+        }
+        ADF_TRY(eq_launch_inc_keep(h, N, s));
+        h->inc_valid = false;  // until this forward has filled every kept array
+        // a block's listed targets can be nearly all of them: size the compact edge arrays once
+        ADF_TRY(eq_ensure_subset(h, N));
+    }
+    float* X = inc ? h->inc_x[0] : h->x;
     // node embedding + edge-degree embedding (equiformer_v2_denoising.py:232-285)
     for (int n0 = 0; n0 < N; n0 += (int)h->chunk_nodes) {
         const int n1 = (int)((n0 + h->chunk_nodes < N) ? n0 + h->chunk_nodes : N);
@@ -847,56 +976,52 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
         const bool tab = h->rad_static && h->ed_rad.table;
         if (!tab) ADF_TRY(eq_radial(h, &h->ed_rad, h->ed_src_emb, h->ed_dst_emb, Z, n0, n1, Eub, &cb, cb.rad, N, s));
         eq_prof_scope ps(h, EQ_PROF_ROTATE, s);
-        ADF_TRY(eq_launch_edge_degree(h, tab ? h->ed_rad.table : cb.rad, Z, tab ? h->hp.max_num_elements : 0, n0, n1, h->x, s));
+        ADF_TRY(eq_launch_edge_degree(h, tab ? h->ed_rad.table : cb.rad, Z, tab ? h->hp.max_num_elements : 0, n0, n1, X, s));
     }
-    if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks, h->x, xs * 4, hipMemcpyDeviceToDevice, s));
-    for (int i = 0; i < h->hp.num_layers; ++i) {
+    if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks, X, xs * 4, hipMemcpyDeviceToDevice, s));
+    h->last_block_rows = 0;
+    for (int i = 0; i < nl; ++i) {
         const eq_block& bk = h->blk[i];
-        // x = x + ga(norm_1(x))   (transformer_block.py:650-700; drop path / dropout are identity in eval mode)
-        { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &bk.n1, h->x, h->y, N, s)); }
-        ADF_TRY(eq_attention(h, &bk.ga, h->y, Z, N, h->agg, false, s));
-        { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_so3_linear(h, bk.ga.proj_l, h->agg, d.HV, h->x, d.C, N, true, s)); }
-        // x = x + ffn(norm_2(x))
-        { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &bk.n2, h->x, h->y, N, s)); }
-        {
-            eq_prof_scope ps(h, EQ_PROF_FFN, s);
-            const eq_ffn& f = bk.ffn;
-            // scalar gate from the l = 0 row of every node (row stride S*C)
-            ADF_TRY(eq_gemm(h, h->y, d.S * d.C, nullptr, &f.scalar, true, h->gate, d.F, nullptr, N, 2, false, s));
-            const bool fold = h->folded && !h->exact_f32;
-            ADF_TRY(eq_so3_linear(h, fold ? f.l1f : f.l1, h->y, d.C, h->h1, d.F, N, false, s));
-            for (int n0 = 0; n0 < N; n0 += (int)h->chunk_nodes) {
-                const int n1 = (int)((n0 + h->chunk_nodes < N) ? n0 + h->chunk_nodes : N);
-                const long long rows = (long long)(n1 - n0) * d.G;
-                float* ga = h->garena;
-                float* gb = h->garena + (size_t)h->chunk_nodes * d.G * d.F;
-                if (fold) {  // silu(to_grid(.)) -> one product + SiLU -> from_grid
-                    // the product's row lifts: one per NODE (the largest grid value of its tile, left by to_grid) - from_grid
-                    // sums a node's rows with comparable weights, so a row far below the node's largest carries no weight
-                    bool em = false;
-                    const bool want = eq_uses_mfma(h, ga, d.F, &f.g2, gb, d.F) && (n1 - n0) <= h->rs_cap;
-                    ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, true, s, want ? h->rs : nullptr, &em));
-                    ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g2, false, gb, d.F, nullptr, rows, 2, false, s, em ? h->rs : nullptr,
-                                    nullptr, d.G));
-                    ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
-                    continue;
-                }
-                ADF_TRY(eq_launch_to_grid(h, h->h1, n0, n1, ga, false, s));
-                // the first product measures its operand rows itself; the next two get them from the producer's epilogue
-                const bool chain = eq_uses_mfma(h, ga, d.F, &f.g0, gb, d.F) && eq_uses_mfma(h, gb, d.F, &f.g2, ga, d.F) &&
-                                   eq_uses_mfma(h, ga, d.F, &f.g4, gb, d.F) && 3 * rows <= h->rs_cap;
-                float* m1 = chain ? h->rs + rows : nullptr;
-                float* m2 = chain ? h->rs + 2 * rows : nullptr;
-                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g0, false, gb, d.F, nullptr, rows, 2, false, s, nullptr, m1));
-                ADF_TRY(eq_gemm(h, gb, d.F, nullptr, &f.g2, false, ga, d.F, nullptr, rows, 2, false, s, m1, m2));
-                ADF_TRY(eq_gemm(h, ga, d.F, nullptr, &f.g4, false, gb, d.F, nullptr, rows, 0, false, s, m2, nullptr));
-                ADF_TRY(eq_launch_from_grid(h, gb, h->gate, n0, n1, h->h2, s));
+        int n = N;             // rows this block computes
+        bool listed = false;   // ... as a compact list (the rest keep the rows of the forward that last computed them)
+        if (inc) {
+            float* Xout = h->inc_x[i + 1];
+            if (lists) {
+                n = cnt[i] < 0 ? 0 : (cnt[i] > N ? N : cnt[i]);
+                listed = (long long)n * 10 <= (long long)N * 9;  // above 90 % the all-rows form is as fast
+                if (!listed) n = N;
             }
-            ADF_TRY(eq_so3_linear(h, fold ? f.l2f : f.l2, h->h2, d.F, h->x, d.C, N, true, s));
+            if (!listed) ADF_HIP_CHECK(hipMemcpyAsync(Xout, X, xs * 4, hipMemcpyDeviceToDevice, s));
+            if (listed && n > 0) {
+                const int32_t* idx = h->inc_idx + (size_t)i * h->inc_capN;
+                // x = x + ga(norm_1(x)) + ffn(norm_2(.)) on the listed rows: sources are read from every row of the block below
+                { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &bk.n1, X, h->y, N, s)); }
+                { eq_prof_scope ps(h, EQ_PROF_GRAPH, s); ADF_TRY(eq_launch_subset_graph(h, idx, n, s)); }
+                const eq_graph_view full = eq_graph_use_subset(h);
+                int32_t st = eq_attention(h, &bk.ga, h->y, Z, n, h->agg, false, s);
+                eq_graph_restore(h, full);
+                ADF_TRY(st);
+                { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_gather_rows(X, idx, n, d.S * d.C, h->inc_xg, s)); }
+                ADF_TRY(eq_block_nodes(h, bk, h->inc_xg, n, s));
+                { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_scatter_rows(h->inc_xg, idx, n, d.S * d.C, Xout, s)); }
+            }
+            X = Xout;
         }
-        if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks + (size_t)(i + 1) * xs, h->x, xs * 4, hipMemcpyDeviceToDevice, s));
+        if (!listed) {
+            // x = x + ga(norm_1(x))   (transformer_block.py:650-700; drop path / dropout are identity in eval mode)
+            { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &bk.n1, X, h->y, N, s)); }
+            ADF_TRY(eq_attention(h, &bk.ga, h->y, Z, N, h->agg, false, s));
+            ADF_TRY(eq_block_nodes(h, bk, X, N, s));
+        }
+        h->last_block_rows += n;
+        if (x_blocks) ADF_HIP_CHECK(hipMemcpyAsync(x_blocks + (size_t)(i + 1) * xs, X, xs * 4, hipMemcpyDeviceToDevice, s));
     }
-    { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &h->final_norm, h->x, h->y, N, s)); }
+    h->prof_block_rows += h->last_block_rows; h->prof_forwards += 1;
+    if (inc) {
+        h->inc_valid = true; h->inc_N = N;
+        h->inc_rows += h->last_block_rows; h->inc_rows_full += (int64_t)nl * N;
+    }
+    { eq_prof_scope ps(h, EQ_PROF_NODE, s); ADF_TRY(eq_launch_norm(h, &h->final_norm, X, h->y, N, s)); }
     h->last_subset = out_idx ? n_out : -1;
     if (out_idx) {
         if (n_out <= 0) return ADF_OK;
@@ -904,9 +1029,7 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
         ADF_TRY(eq_ensure_subset(h, n_out));
         { eq_prof_scope ps(h, EQ_PROF_GRAPH, s); ADF_TRY(eq_launch_subset_graph(h, out_idx, n_out, s)); }
         // the attention kernels read the graph through the handle: point it at the compact arrays for the force blocks
-        int32_t *k_eptr = h->eptr, *k_src = h->e_src, *k_dst = h->e_dst;
-        float *k_vec = h->e_vec, *k_wig = h->wig;
-        h->eptr = h->sub_eptr; h->e_src = h->sub_src; h->e_dst = h->sub_dst; h->e_vec = h->sub_vec; h->wig = h->sub_wig;
+        const eq_graph_view full = eq_graph_use_subset(h);
         int32_t st = ADF_OK;
         for (int k = 0; k < 2 && st == ADF_OK; ++k) {
             float* f = k == 0 ? f1 : f2;
@@ -916,7 +1039,7 @@ static int32_t eq_forward_impl(adf_eqv2* h, const adf_batch* b, float* f1, float
             if (st == ADF_OK) st = eq_launch_force_out(h, &h->force[k], h->agg, n_out, h->sub_f, s);
             if (st == ADF_OK) st = eq_launch_scatter_rows3(h->sub_f, out_idx, n_out, f, s);
         }
-        h->eptr = k_eptr; h->e_src = k_src; h->e_dst = k_dst; h->e_vec = k_vec; h->wig = k_wig;
+        eq_graph_restore(h, full);
         return st;
     }
     for (int k = 0; k < 2; ++k) {
@@ -1096,7 +1219,12 @@ extern "C" int32_t adf_eqv2_get_counters(adf_eqv2_t h, adf_eqv2_counters* out, v
     const bool compact = d.M >= 1 && d.L >= 1 && !h->no_compact;
     const int64_t conv2f = compact ? (int64_t)(d.L + 1) * d.Hd * d.HV + 2 * ((int64_t)d.L * d.Hd) * (2 * d.HV) : conv2;
     const int64_t Ef = h->last_subset >= 0 ? E * h->last_subset / (N > 0 ? N : 1) : E;
-    out->conv_flops = 2 * (E * (conv1 + conv2) * blocks + Ef * (conv1 + conv2f) * 2);
+    // incremental blocks: a block's convolutions run on the edges of its listed targets only (estimated as E rows / N)
+    const int64_t Eb = N > 0 ? E * h->last_block_rows / N : E * blocks;
+    out->conv_flops = 2 * (Eb * (conv1 + conv2) + Ef * (conv1 + conv2f) * 2);
+    out->inc_rows = h->inc_rows; out->inc_rows_full = h->inc_rows_full;
+    out->forwards_total = h->prof_forwards;
+    out->conv_flops_total = 2 * ((N > 0 ? E * h->prof_block_rows / N : 0) * (conv1 + conv2) + Ef * (conv1 + conv2f) * 2 * h->prof_forwards);
     return ADF_OK;
 }
 
@@ -1105,6 +1233,7 @@ extern "C" int32_t adf_eqv2_profile_enable(adf_eqv2_t h, int32_t on) {
     h->prof_on = on != 0;
     h->prof_used = 0;
     h->prof_cat->clear();
+    if (on) h->prof_block_rows = h->prof_forwards = 0;
     return ADF_OK;
 }
 

@@ -1083,6 +1083,106 @@ int32_t eq_launch_scatter_rows3(const float* f_sub, const int32_t* out_idx, int 
     return ADF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ incremental blocks
+// Which rows a block has to recompute (adf_eqv2_set_incremental).  The embedding of atom t reads t's incoming edges (who,
+// where); block i reads, for target t, row t and the rows of t's sources in the block below plus t's edge geometry
+// (transformer_block.py:650-700).  With G = the targets whose in-edge list differs bit for bit from the previous forward's,
+// block i therefore recomputes P^(i+1)(G), P(D) = D + the targets with a source in D.  Everything else is unchanged since
+// the forward that last computed it.
+__global__ void eq_inc_compare_kernel(const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src,
+                                      const float* __restrict__ e_vec, const int32_t* __restrict__ peptr,
+                                      const int32_t* __restrict__ psrc, const float* __restrict__ pvec, int N,
+                                      unsigned char* __restrict__ dirty) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const int c0 = eptr[t], c1 = eptr[t + 1], p0 = peptr[t], p1 = peptr[t + 1];
+    bool d = (c1 - c0) != (p1 - p0);
+    for (int k = 0; !d && k < c1 - c0; ++k) {
+        d = e_src[c0 + k] != psrc[p0 + k];
+        for (int c = 0; c < 3; ++c)
+            d = d || __float_as_uint(e_vec[3 * (size_t)(c0 + k) + c]) != __float_as_uint(pvec[3 * (size_t)(p0 + k) + c]);
+    }
+    dirty[t] = d ? 1 : 0;
+}
+
+__global__ void eq_inc_propagate_kernel(const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src, int N,
+                                        const unsigned char* __restrict__ in, unsigned char* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    bool d = in[t] != 0;
+    for (int e = eptr[t]; !d && e < eptr[t + 1]; ++e) d = in[e_src[e]] != 0;
+    out[t] = d ? 1 : 0;
+}
+
+size_t eq_inc_select_bytes(int N) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceSelect::Flagged(nullptr, bytes, hipcub::CountingInputIterator<int32_t>(0), (unsigned char*)nullptr,
+                                        (int32_t*)nullptr, (int32_t*)nullptr, N);
+    return bytes;
+}
+
+// lists[l] (ascending rows, stride capN) and counts[l] for blocks l = 0..nl-1, against the graph kept by eq_launch_inc_keep
+int32_t eq_launch_inc_lists(adf_eqv2* h, int N, int nl, hipStream_t s) {
+    const dim3 grid((N + 255) / 256), block(256);
+    unsigned char* f0 = h->inc_dirty;
+    unsigned char* f1 = h->inc_dirty + h->inc_capN;
+    hipLaunchKernelGGL(eq_inc_compare_kernel, grid, block, 0, s, h->eptr, h->e_src, h->e_vec, h->inc_peptr, h->inc_psrc,
+                       h->inc_pvec, N, f0);
+    for (int l = 0; l < nl; ++l) {
+        hipLaunchKernelGGL(eq_inc_propagate_kernel, grid, block, 0, s, h->eptr, h->e_src, N, f0, f1);
+        size_t bytes = h->inc_sel_bytes;
+        ADF_HIP_CHECK(hipcub::DeviceSelect::Flagged(h->inc_sel_tmp, bytes, hipcub::CountingInputIterator<int32_t>(0), f1,
+                                                    h->inc_idx + (size_t)l * h->inc_capN, h->inc_cnt + l, N, s));
+        unsigned char* t = f0; f0 = f1; f1 = t;
+    }
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// keep this forward's graph for the next comparison
+int32_t eq_launch_inc_keep(adf_eqv2* h, int N, hipStream_t s) {
+    int64_t E = (int64_t)N * (h->ext_graph ? h->maxdeg : h->hp.max_neighbors);
+    if (h->ext_graph && h->E_ext < E) E = h->E_ext;
+    if (E > h->inc_capE) E = h->inc_capE;
+    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_peptr, h->eptr, sizeof(int32_t) * ((size_t)N + 1), hipMemcpyDeviceToDevice, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_psrc, h->e_src, sizeof(int32_t) * (size_t)E, hipMemcpyDeviceToDevice, s));
+    ADF_HIP_CHECK(hipMemcpyAsync(h->inc_pvec, h->e_vec, sizeof(float) * 3 * (size_t)E, hipMemcpyDeviceToDevice, s));
+    return ADF_OK;
+}
+
+// rows idx[i] of a [*, row4 float4] array <-> a compact [n, row4] array
+__global__ void eq_gather_rows_kernel(const float4* __restrict__ src, const int32_t* __restrict__ idx, int row4,
+                                      float4* __restrict__ dst) {
+    const float4* a = src + (size_t)idx[blockIdx.x] * row4;
+    float4* b = dst + (size_t)blockIdx.x * row4;
+    for (int t = threadIdx.x; t < row4; t += blockDim.x) b[t] = a[t];
+}
+
+__global__ void eq_scatter_rows_kernel(const float4* __restrict__ src, const int32_t* __restrict__ idx, int row4,
+                                       float4* __restrict__ dst) {
+    const float4* a = src + (size_t)blockIdx.x * row4;
+    float4* b = dst + (size_t)idx[blockIdx.x] * row4;
+    for (int t = threadIdx.x; t < row4; t += blockDim.x) b[t] = a[t];
+}
+
+int32_t eq_launch_gather_rows(const float* src, const int32_t* idx, int n, int row_floats, float* dst, hipStream_t s) {
+    if (n <= 0) return ADF_OK;
+    if (row_floats & 3) { adf_set_error("eqv2: row length must be a multiple of 4"); return ADF_EINVAL; }
+    hipLaunchKernelGGL(eq_gather_rows_kernel, dim3(n), dim3(256), 0, s, reinterpret_cast<const float4*>(src), idx, row_floats / 4,
+                       reinterpret_cast<float4*>(dst));
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+int32_t eq_launch_scatter_rows(const float* src, const int32_t* idx, int n, int row_floats, float* dst, hipStream_t s) {
+    if (n <= 0) return ADF_OK;
+    if (row_floats & 3) { adf_set_error("eqv2: row length must be a multiple of 4"); return ADF_EINVAL; }
+    hipLaunchKernelGGL(eq_scatter_rows_kernel, dim3(n), dim3(256), 0, s, reinterpret_cast<const float4*>(src), idx, row_floats / 4,
+                       reinterpret_cast<float4*>(dst));
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ S2 grid of the feed-forward
 // transformer_block.py:497-531: SO3 features -> res^2 grid points (to_full), point-wise MLP (dense products elsewhere),
 // grid -> SO3 (from_full), l = 0 replaced by the scalar gate.  One workgroup per node, thread = hidden channel.

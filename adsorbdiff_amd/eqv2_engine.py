@@ -204,7 +204,9 @@ class EqV2Engine:
         self.exact_f32 = bool(exact_f32)
 
     def set_incremental(self, on: bool = True) -> None:
-        """No kept per-layer state on this path (every forward evaluates every row)."""
+        """Incremental blocks (adf_eqv2_set_incremental): keep every block's output across the forwards of a
+        static-atom run and recompute only the rows whose inputs changed (bit-identical results)."""
+        _lib.check(self.lib.adf_eqv2_set_incremental(self.handle, 1 if on else 0))
 
     def init_placement(self, prep: PreparedBatch, pos: torch.Tensor, noise: torch.Tensor) -> None:
         desc = prep.desc(pos)

@@ -29,7 +29,7 @@ EXPORTS = (
     "adf_lift_adsorbates", "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
     "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_fwd_fused", "adf_op_message_bwd", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
     "adf_eqv2_create", "adf_eqv2_destroy", "adf_eqv2_set_constants", "adf_eqv2_set_weights", "adf_eqv2_set_arithmetic",
-    "adf_eqv2_set_edges", "adf_eqv2_set_moving", "adf_eqv2_forward", "adf_eqv2_forward_subset", "adf_eqv2_check_flags", "adf_eqv2_init_placement",
+    "adf_eqv2_set_edges", "adf_eqv2_set_moving", "adf_eqv2_set_incremental", "adf_eqv2_forward", "adf_eqv2_forward_subset", "adf_eqv2_check_flags", "adf_eqv2_init_placement",
     "adf_eqv2_sde_step", "adf_eqv2_sample", "adf_eqv2_sample_traj", "adf_eqv2_linear_forward", "adf_eqv2_get_counters", "adf_eqv2_profile_enable", "adf_eqv2_profile_read",
     "adf_last_error", "adf_version",
 )
@@ -54,7 +54,9 @@ class EqV2Hparams(C.Structure):
 
 
 class EqV2Counters(C.Structure):
-    _fields_ = [("num_edges", C.c_int64), ("num_atoms", C.c_int64), ("dense_flops", C.c_int64), ("conv_flops", C.c_int64)]
+    _fields_ = [("num_edges", C.c_int64), ("num_atoms", C.c_int64), ("dense_flops", C.c_int64), ("conv_flops", C.c_int64),
+                ("inc_rows", C.c_int64), ("inc_rows_full", C.c_int64), ("forwards_total", C.c_int64),
+                ("conv_flops_total", C.c_int64)]
 
 
 class BatchDesc(C.Structure):
@@ -165,6 +167,7 @@ def load():
         "adf_eqv2_set_arithmetic": [vp, i32],
         "adf_eqv2_set_edges": [vp, i64, vp, vp, vp, i32, vp],
         "adf_eqv2_set_moving": [vp, vp, vp, vp],
+        "adf_eqv2_set_incremental": [vp, i32],
         "adf_eqv2_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp, vp],
         "adf_eqv2_forward_subset": [vp, C.POINTER(BatchDesc), vp, i32, vp, vp, vp],
         "adf_eqv2_check_flags": [vp, vp],

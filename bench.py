@@ -828,6 +828,14 @@ def main_eqv2(args, rank, world, dev, emit=True):
         sites_ads = one_pass({"scores_on_adsorbate_only": True})
         fence()
         ads_s = time.perf_counter() - t0
+    # secondary (one pass): every row of every block recomputed at every step, as the reference does
+    sites_full, full_s = None, 0.0
+    if not args.no_secondary:
+        fence()
+        t0 = time.perf_counter()
+        sites_full = one_pass({"incremental_layers": False})
+        fence()
+        full_s = time.perf_counter() - t0
     eng.profile_enable(True)
     fence()
     t0 = time.perf_counter()
@@ -849,7 +857,10 @@ def main_eqv2(args, rank, world, dev, emit=True):
         f16 = os.environ.get("ADF_GEMM") != "f32"
         products = 3 if f16 else 1
         conv_s = conv_ms * 1e-3
-        issued = c.conv_flops * forwards * products / conv_s / 1e12 if conv_s > 0 else 0.0
+        # summed by the library over the profiled forwards (incremental blocks: a forward's convolutions run on the edges of
+        # the targets it recomputes, which differs from forward to forward)
+        assert c.forwards_total == forwards, (c.forwards_total, forwards)
+        issued = c.conv_flops_total * products / conv_s / 1e12 if conv_s > 0 else 0.0
         from adsorbdiff_amd.engine import PaiNNEngine  # noqa: F401  (peaks come from the library, any handle)
         import ctypes as C
 
@@ -897,6 +908,7 @@ def main_eqv2(args, rank, world, dev, emit=True):
             "system_steps_per_s": total_systems * forwards / elapsed,
             "dense_tflops_f32_equivalent": c.dense_flops * forwards / elapsed / 1e12,
             "gpu_ms_per_pass": gpu_ms,
+            "recomputed_block_rows_fraction": round(c.inc_rows / c.inc_rows_full, 4) if c.inc_rows_full else 1.0,
             "roofline": {
                 "kernel": "eq_gemm16_kernel (SO(2) convolution products of the %d attention blocks, f16x3 split)"
                           % (EQV2_HP["num_layers"] + 2),
@@ -906,7 +918,7 @@ def main_eqv2(args, rank, world, dev, emit=True):
                 "measured_peak": measured["mfma_f16_tflops"] if f16 else measured["mfma_f32_tflops"],
                 "traffic": conv_traffic,
                 "traffic_source": conv_traffic_src,
-                "flops_per_forward": c.conv_flops * products,
+                "flops_per_forward": c.conv_flops_total * products / max(forwards, 1),
                 "share_of_gpu_time": conv_s / total_gpu_s if total_gpu_s > 0 else None,
                 "note": "achieved = 2 x multiply-adds of the SO(2) convolutions (5.83 M + 2.40 M per edge and block at this "
                         "configuration) x 3 split products / HIP-event time of the convolution launches on the launch "
@@ -919,6 +931,12 @@ def main_eqv2(args, rank, world, dev, emit=True):
                 "value": total_systems / ads_s, "unit": "sites/s", "identical_sites": bool(torch.equal(sites_ads, sites)),
                 "note": "opt-in denoising_pos_params['scores_on_adsorbate_only']: the two force blocks run for the tag-2 "
                         "target atoms only (adf_eqv2_forward_subset); one pass, this rank's clock",
+            }
+        if sites_full is not None:
+            out["incremental_layers_off"] = {
+                "value": total_systems / full_s, "unit": "sites/s", "identical_sites": bool(torch.equal(sites_full, sites)),
+                "note": "denoising_pos_params['incremental_layers']=False: every block recomputes every row at every step, as "
+                        "the reference does; one pass, this rank's clock",
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = eqv2_cpu_baseline(model, params)

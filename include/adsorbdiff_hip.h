@@ -437,6 +437,17 @@ int32_t adf_eqv2_check_flags(adf_eqv2_t h, void* stream);
 
 /* Reverse-diffusion stepper on an EquiformerV2 handle: same contracts as adf_sde_init_placement,
  * adf_sde_step_scheduled and adf_sample above. */
+/* Incremental blocks (off until switched on; the host mirror switches it on for a sampling run, denoising_pos_params
+ * ["incremental_layers"], default True).  While a static-atom promise is in force (adf_eqv2_set_moving: same batch, only
+ * flagged atoms move) the handle keeps the embedding and every transformer block's output; a forward compares every
+ * target's incoming edge list (sources and vectors, bit for bit) with the previous forward's and block i recomputes only
+ * the targets within i + 1 hops of a changed one - on a compacted copy of their edges, as adf_eqv2_forward_subset does for
+ * the force blocks.  Every output is bit-identical to a full forward; the reference recomputes every row at every step
+ * (denoising_torch.py:498 -> equiformer_v2_denoising.py:232-318).  Costs (num_layers + 2) x S x C x 4 bytes per atom
+ * (250 KB at config 4) and one 4 x num_layers-byte read-back (a stream synchronisation) per forward, which sizes the
+ * launches.  Calling this (with either value) drops the kept state and zeroes the inc_* counters. */
+int32_t adf_eqv2_set_incremental(adf_eqv2_t h, int32_t on);
+
 int32_t adf_eqv2_init_placement(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const float* noise,
                                 void* stream);
 int32_t adf_eqv2_sde_step(adf_eqv2_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
@@ -468,7 +479,12 @@ typedef struct {
     int64_t num_edges, num_atoms;
     int64_t dense_flops;       /* 2 x multiply-adds of every dense product of the REFERENCE's forward (f32-equivalent work) */
     int64_t conv_flops;        /* 2 x multiply-adds the SO(2)-convolution kernels of the last forward executed (force blocks:
-                                * l = 1 columns only; subset forward: the listed targets' edges only, estimated) */
+                                * l = 1 columns only; subset forward / incremental blocks: the listed targets' edges only,
+                                * estimated) */
+    int64_t inc_rows, inc_rows_full;  /* incremental blocks, totals since adf_eqv2_set_incremental: block rows recomputed /
+                                       * block rows full forwards would have computed (blocks x atoms) */
+    int64_t forwards_total, conv_flops_total;  /* forwards since adf_eqv2_profile_enable(1) and conv_flops summed over them
+                                                * (on the last forward's edge count) */
 } adf_eqv2_counters;
 int32_t adf_eqv2_get_counters(adf_eqv2_t h, adf_eqv2_counters* out, void* stream);
 int32_t adf_eqv2_profile_enable(adf_eqv2_t h, int32_t on);

@@ -234,6 +234,99 @@ def test_eqv2_subset_forward_rows_are_bit_identical():
     assert bool((g1[rest] == 7.0).all()) and bool((g2[rest] == 7.0).all())
 
 
+def test_eqv2_incremental_blocks_are_bit_identical():
+    """adf_eqv2_set_incremental: with the static-atom promise in force a forward recomputes, in block i, only the targets
+    within i + 1 hops of a changed in-edge list.  Every block's output and both force outputs equal, bit for bit, a full
+    forward at the same positions (an engine that keeps nothing); a forward at unchanged positions recomputes no row."""
+    m = make_model(4, 2, C=32, hidden=32, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=4, cutoff=12.0).to(DEV)
+    b = safe_batch(2, 196, seed=31).to(DEV)
+    N = int(b.pos.shape[0])
+    S, C_ = 25, 32
+    ads = (b.tags == 2)
+
+    def drop_engine():
+        if m._engine is not None:
+            m._engine.close()
+        m._engine = None
+
+    def full_forward(pos):
+        drop_engine()  # a fresh handle: nothing kept
+        eng = m.engine()
+        prep = eng.prepare(b)
+        f1, f2 = torch.empty(N, 3, device=DEV), torch.empty(N, 3, device=DEV)
+        xb = torch.empty(5, N, S, C_, device=DEV)
+        eng.forward_prepared(prep, pos, f1, f2, x_blocks=xb)
+        eng.check_flags()
+        return f1, f2, xb
+
+    pos0 = b.pos.float().contiguous()
+    gen = torch.Generator().manual_seed(5)
+    moves = [torch.zeros(N, 3, device=DEV) for _ in range(3)]
+    moves[0][ads] = (0.3 * torch.randn(int(ads.sum()), 3, generator=gen)).to(DEV)
+    moves[1][ads] = (0.05 * torch.randn(int(ads.sum()), 3, generator=gen)).to(DEV)
+    positions = [pos0, pos0 + moves[0], pos0 + moves[0] + moves[1], pos0 + moves[0] + moves[1]]
+    want = [full_forward(p) for p in positions]
+
+    drop_engine()
+    eng = m.engine()
+    prep = eng.prepare(b)
+    eng.set_moving_atoms(prep, ads)
+    eng.set_incremental(True)
+    rows = []
+    for p, (w1, w2, wx) in zip(positions, want):
+        f1, f2 = torch.empty(N, 3, device=DEV), torch.empty(N, 3, device=DEV)
+        xb = torch.empty(5, N, S, C_, device=DEV)
+        eng.forward_prepared(prep, p, f1, f2, x_blocks=xb)
+        eng.check_flags()
+        for i in range(5):
+            assert torch.equal(xb[i], wx[i]), f"block {i}"
+        assert torch.equal(f1, w1) and torch.equal(f2, w2)
+        c = eng.counters()
+        rows.append((int(c.inc_rows), int(c.inc_rows_full)))
+    assert rows[0] == (4 * N, 4 * N)                      # nothing kept yet
+    assert rows[1][1] == 8 * N and rows[1][0] < 8 * N - N // 4   # block 0 (and 1) recompute a part of the slab only
+    assert rows[3][0] == rows[2][0]                       # unchanged positions: no row recomputed
+    # the adsorbate-only subset forward uses the same kept state
+    idx = torch.nonzero(ads).reshape(-1).to(torch.int32).contiguous()
+    g1, g2 = torch.zeros(N, 3, device=DEV), torch.zeros(N, 3, device=DEV)
+    p = positions[1]
+    eng.forward_prepared(prep, p, g1, g2, out_idx=idx)
+    eng.check_flags()
+    assert torch.equal(g1[idx.long()], want[1][0][idx.long()]) and torch.equal(g2[idx.long()], want[1][1][idx.long()])
+    # dropping the promise drops the kept state: the next forward is a full one
+    eng.set_moving_atoms(None, None)
+    eng.forward_prepared(prep, positions[0], g1, g2)
+    eng.check_flags()
+    assert torch.equal(g1, want[0][0])
+
+
+def test_eqv2_sampling_with_and_without_incremental_blocks_gives_identical_sites():
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    m = make_model(4, 2, C=32, hidden=32, heads=2, alpha=16, value=16, ffn=32, ec=32, layers=3, cutoff=12.0)
+    m.so3_denoising = True
+    m = m.to(DEV)
+    params = dict(num_steps=4, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+                  early_stop=False)
+    placement = torch.rand(2, 3, generator=torch.Generator().manual_seed(4))
+    outs = []
+    for inc in (False, True):
+        b = safe_batch(2, 196, seed=23)
+        trainer = DenoisingTrainer(m, device=DEV)
+        den = Denoiser(b.clone().to(DEV), DiffTorchCalc(trainer),
+                       dict(params, placement_noise=placement, incremental_layers=inc), device=DEV)
+        out = den.run()
+        assert den.steps_applied == 4
+        outs.append(out.pos.cpu())
+        c = m.engine().counters()
+        if inc:
+            assert 0 < int(c.inc_rows) < int(c.inc_rows_full)
+        else:
+            assert int(c.inc_rows_full) == 0
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_eqv2_sampling_on_adsorbate_scores_only_gives_identical_sites():
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.trainer import DenoisingTrainer
