@@ -83,6 +83,11 @@ class PaiNNTrainStep:
         self.igso3 = igso3 or Igso3Tables.shared()
         # forward of the message block through the sampler's fused kernel (ADF_TRAIN_MSG=plain: the rbfh-reading kernel)
         self.fused_message_forward = os.environ.get("ADF_TRAIN_MSG", "fused") != "plain"
+        # backward of the message block with rbfh regenerated inside the kernel (message_bwd.hip) instead of kept from the
+        # forward: needs the fused forward (it builds the layer's rbf_proj images) and the f16x3 arithmetic;
+        # ADF_TRAIN_MSG_BWD=plain: the rbfh-reading kernel
+        self.fused_message_backward = self.fused_message_forward and os.environ.get("ADF_TRAIN_MSG_BWD", "fused") != "plain"
+        self._bwd_perm = None
 
     # ------------------------------------------------------------------ helpers
     def _params(self) -> Dict[str, torch.nn.Parameter]:
@@ -126,6 +131,11 @@ class PaiNNTrainStep:
             if g is None:
                 raise RuntimeError("call zero_grad() before loss_and_grad()")
         scales = m.scale_factors()
+        fused_bwd = self.fused_message_backward and bool(lib.adf_op_message_bwd_fused_supported(h))
+        if fused_bwd and self._bwd_perm is None:
+            perm = (C.c_int32 * (3 * H))()
+            _lib.check(lib.adf_op_message_bwd_perm(h, perm, 3 * H))
+            self._bwd_perm = torch.tensor(list(perm), dtype=torch.long, device=self.dev)
 
         # ---------------- forward with saved activations
         x = ops.new(N, H)
@@ -146,7 +156,8 @@ class PaiNNTrainStep:
             a["c"] = ops.new(N, H)
             _lib.check(lib.adf_op_ssilu_fwd(a["h0"].data_ptr(), a["c"].data_ptr(), N * H, s()))
             a["xh"] = ops.linear(a["c"], P[mp + "x_proj.2.weight"], P[mp + "x_proj.2.bias"], N, 3 * H, H)
-            a["rbfh"] = ops.linear(rbf, P[mp + "rbf_proj.weight"], P[mp + "rbf_proj.bias"], E, 3 * H, R)
+            if not fused_bwd:  # kept for the rbfh-reading backward (6 KB per edge and layer)
+                a["rbfh"] = ops.linear(rbf, P[mp + "rbf_proj.weight"], P[mp + "rbf_proj.bias"], E, 3 * H, R)
             a["x1"], a["vec1"] = ops.new(N, H), ops.new(N, 3, H)
             if self.fused_message_forward:
                 # the sampler's fused kernel (no read of the 6 KB-per-edge rbfh; it stays materialised for the backward)
@@ -270,15 +281,28 @@ class PaiNNTrainStep:
                            dA=dvec1, acc_dA=True)
             # message block
             first = a["vec"] is None
-            dxh, drbfh = ops.new(N, 3 * H), ops.new(E, 3 * H)
+            dxh, drbfh = ops.new(N, 3 * H), ops.new(E + 1, 3 * H)  # (+1: the fused kernel's spare row)
             dvec_in = None if first else ops.new(N, 3, H)
             dx_in = ops.new(N, H)
-            _lib.check(lib.adf_op_message_bwd(h, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
-                                              a["rbfh"].data_ptr(), dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(),
-                                              drbfh.data_ptr(), dvec_in.data_ptr() if not first else None, dx_in.data_ptr(),
-                                              1 if first else 0, s()))
-            ops.linear_bwd(rbf, P[mp + "rbf_proj.weight"], drbfh, E, 3 * H, R, G[mp + "rbf_proj.weight"],
-                           G[mp + "rbf_proj.bias"], want_dA=False)
+            if fused_bwd:
+                # drbfh comes back with its columns in the kernel's lane order: the weight gradient is formed on that order
+                # and its rows are permuted back (3H x R, tiny)
+                _lib.check(lib.adf_op_message_bwd_fused(h, l, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
+                                                        dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(), drbfh.data_ptr(), E,
+                                                        dvec_in.data_ptr() if not first else None, dx_in.data_ptr(),
+                                                        1 if first else 0, s()))
+                dwp = torch.zeros(3 * H, R, dtype=torch.float32, device=self.dev)
+                dbp = torch.zeros(3 * H, dtype=torch.float32, device=self.dev)
+                ops.linear_bwd(rbf, P[mp + "rbf_proj.weight"], drbfh, E, 3 * H, R, dwp, dbp, want_dA=False)
+                G[mp + "rbf_proj.weight"].index_add_(0, self._bwd_perm, dwp)
+                G[mp + "rbf_proj.bias"].index_add_(0, self._bwd_perm, dbp)
+            else:
+                _lib.check(lib.adf_op_message_bwd(h, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
+                                                  a["rbfh"].data_ptr(), dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(),
+                                                  drbfh.data_ptr(), dvec_in.data_ptr() if not first else None,
+                                                  dx_in.data_ptr(), 1 if first else 0, s()))
+                ops.linear_bwd(rbf, P[mp + "rbf_proj.weight"], drbfh, E, 3 * H, R, G[mp + "rbf_proj.weight"],
+                               G[mp + "rbf_proj.bias"], want_dA=False)
             dc = ops.linear_bwd(a["c"], P[mp + "x_proj.2.weight"], dxh, N, 3 * H, H, G[mp + "x_proj.2.weight"],
                                 G[mp + "x_proj.2.bias"])
             dh0 = ops.new(N, H)

@@ -342,6 +342,19 @@ int32_t adf_op_message_fwd_fused(adf_painn_t h, int32_t layer, const float* xh, 
 int32_t adf_op_message_bwd(adf_painn_t h, const float* xh, const float* vec, const float* rbfh, const float* gx1,
                            const float* gv1, float* dxh, float* drbfh, float* dvec, float* dx, int32_t vec_is_zero,
                            void* stream);
+/* The same backward with rbfh REGENERATED inside the kernel on the matrix cores (message_bwd.hip; autograd through
+ * painn_denoising.py:530-567): no [E,3H] operand is kept from the forward or recomputed by a dense product.  drbfh is written
+ * ([num_edges + 1, 3H]: one spare row that the kernel's padded edge rows write) with its 3H columns in the kernel's lane
+ * order; adf_op_message_bwd_perm fills perm[c'] = the column of rbf_proj's output
+ * that lane-order column c' holds (host array of 3H entries), so that the weight-gradient product of rbf_proj can run on it
+ * and its rows be permuted back.  Needs the f16x3 arithmetic and equally spaced Gaussian centres
+ * (adf_op_message_bwd_fused_supported returns 1) and the layer's rbf_proj images of this step (adf_op_message_fwd_fused
+ * builds them).  Gradients agree with adf_op_message_bwd to ~1e-6 relative. */
+int32_t adf_op_message_bwd_fused_supported(adf_painn_t h);
+int32_t adf_op_message_bwd_perm(adf_painn_t h, int32_t* perm_host, int32_t n);
+int32_t adf_op_message_bwd_fused(adf_painn_t h, int32_t layer, const float* xh, const float* vec, const float* gx1,
+                                 const float* gv1, float* dxh, float* drbfh_lane_order, int64_t num_edges, float* dvec,
+                                 float* dx, int32_t vec_is_zero, void* stream);
 int32_t adf_op_vdot_fwd(const float* vv, float* dot, float* nrm, int32_t ldn, int64_t N, int32_t C, float eps, void* stream);
 int32_t adf_op_vdot_bwd(const float* vv, const float* nrm, int32_t ldn, const float* ddot, const float* dnrm, int32_t lddn,
                         const float* dv1, float* dvv, int64_t N, int32_t C, void* stream);

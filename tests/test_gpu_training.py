@@ -133,6 +133,26 @@ def test_gradients_are_reproducible_and_accumulate():
     assert rel_err(dict(m.named_parameters())[k].grad, 2 * g1[k]) < 1e-6
 
 
+def test_fused_message_backward_agrees_with_the_rbfh_reading_backward(monkeypatch):
+    """message_bwd.hip regenerates rbfh on the matrix cores (f16x3) and writes drbfh in its lane order; the step permutes
+    the rbf_proj gradient back.  Every gradient agrees with the backward that reads a materialised rbfh (exact f32)."""
+    fx, m, b, targets, tables = _setup()
+    grads = {}
+    for mode in ("plain", "fused"):
+        monkeypatch.setenv("ADF_TRAIN_MSG_BWD", mode)
+        step = PaiNNTrainStep(m, DEV, igso3=tables)
+        assert step.fused_message_backward == (mode == "fused")
+        step.zero_grad()
+        step.loss_and_grad(b, targets)
+        grads[mode] = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+    assert set(grads["plain"]) == set(grads["fused"])
+    for k, g in grads["plain"].items():
+        if float(g.norm()) == 0.0:
+            assert float(grads["fused"][k].norm()) == 0.0, k
+            continue
+        assert rel_err(grads["fused"][k], g) < 2e-5, (k, rel_err(grads["fused"][k], g))
+
+
 def test_fused_adamw_matches_torch_adamw_clip_ema():
     """AdamW + clip_grad_norm_ + EMA in one kernel per tensor == torch.optim.AdamW, torch clip and the EMA mirror."""
     from adsorbdiff_amd.exponential_moving_average import ExponentialMovingAverage
