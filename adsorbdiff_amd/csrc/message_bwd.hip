@@ -34,6 +34,9 @@ struct MsgBwdParams {
 };
 
 #define MSGB_WAVES_PER_SIMD 2
+#ifndef MSGB_AHEAD
+#define MSGB_AHEAD 2   // gather rows requested ahead of the row being consumed (4: as the forward kernel)
+#endif
 
 template <bool VZ>
 __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_bwd_kernel(MsgBwdParams pb) {
@@ -251,6 +254,15 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
                     k0 += 16;
                 } while (k0 < khi);
             }
+#if MSGB_AHEAD == 4
+            GATHER(4) GATHER(5) GATHER(6) GATHER(7)
+            CONSUME(0) CONSUME(1) CONSUME(2) CONSUME(3)
+            GATHER(8) GATHER(9) GATHER(10) GATHER(11)
+            CONSUME(4) CONSUME(5) CONSUME(6) CONSUME(7)
+            GATHER(12) GATHER(13) GATHER(14) GATHER(15)
+            CONSUME(8) CONSUME(9) CONSUME(10) CONSUME(11)
+            CONSUME(12) CONSUME(13) CONSUME(14) CONSUME(15)
+#else
             // (two rows ahead: the backward holds 24 per-atom constants and sums beside the 96 accumulators)
             GATHER(4) GATHER(5)
             CONSUME(0) CONSUME(1)
@@ -265,6 +277,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
             GATHER(14) GATHER(15)
             CONSUME(10) CONSUME(11)
             CONSUME(12) CONSUME(13) CONSUME(14) CONSUME(15)
+#endif
 #undef GATHER
 #undef CONSUME
 #undef ROW_OF
