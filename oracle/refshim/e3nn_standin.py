@@ -10,9 +10,12 @@ What this file CAN check, and does in ``self_check()``:
   * the real spherical harmonics implied by (sha, shb) transform under the reference's own VENDORED Wigner-D
     (wigner.py + Jd.pt):  Y(R x) = D(R) Y(x)  for l <= 6 — this pins the basis up to one sign per degree l;
   * FromS2Grid o ToS2Grid = identity on band-limited coefficients (normalisation constants are mutually consistent).
-What it CANNOT check: the absolute normalisation constant of ToS2Grid ("component": sqrt(4 pi) / sqrt(2l+1) /
-sqrt(lmax+1)) — it changes the amplitude seen by the point-wise non-linearity of the S2 activation — and the per-l
-sign (harmless on an inversion-symmetric grid such as the shipped 18 x 18 one).
+And, in tests/test_oracle_golden.py::test_e3nn_standin_harmonics_equal_scipy_orthonormal_harmonics: the harmonics built
+from (_legendre, _sh_alpha) equal scipy's orthonormal spherical harmonics for every (l, m), l <= 6, up to one sign per
+(l, m) - the amplitude of the Legendre factor is pinned against an independent implementation.
+What it CANNOT check: e3nn's own constant for normalization="component" (sqrt(4 pi) / sqrt(2l+1) / sqrt(lmax+1) on the
+way to the grid, restated from its published source) — it changes the amplitude seen by the point-wise non-linearity of
+the S2 activation — and the per-l sign (harmless on an inversion-symmetric grid such as the shipped 18 x 18 one).
 """
 from __future__ import annotations
 

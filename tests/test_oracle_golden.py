@@ -171,6 +171,38 @@ def test_noising_mirror_vs_reference_fixture():
         np.testing.assert_allclose(getattr(nb, key).numpy(), fx[fkey], rtol=2e-5, atol=2e-5, err_msg=key)
 
 
+def test_e3nn_standin_harmonics_equal_scipy_orthonormal_harmonics():
+    """The amplitude of the stand-in's Legendre factor, pinned against an INDEPENDENT implementation: the real harmonics
+    built from (_legendre, _sh_alpha) - the two factors ToS2Grid / FromS2Grid are made of - equal scipy's orthonormal
+    ("integral"-normalised) spherical harmonics at random directions for every (l, m), l <= 6, up to one sign per (l, m)
+    (e3nn drops the Condon-Shortley phase; the sign per degree is what the Wigner-D self-check of the stand-in fixes).
+    What stays unpinned without e3nn itself: its published constants for normalization="component" (restated, not run)."""
+    import math
+
+    from scipy import special
+
+    from oracle.refshim import e3nn_standin as E
+
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.randn(300, 3, generator=g, dtype=torch.float64)
+    xyz = xyz / xyz.norm(dim=1, keepdim=True)
+    Y = E.real_sh(6, xyz).numpy()
+    alpha, beta = (t.numpy() for t in E.xyz_to_angles(xyz))   # azimuth about / polar angle from the Y axis
+    i = 0
+    for l in range(7):
+        for m in range(-l, l + 1):
+            c = special.sph_harm_y(l, abs(m), beta, alpha) if hasattr(special, "sph_harm_y") else special.sph_harm(abs(m), l, alpha, beta)
+            r = c.real if m == 0 else math.sqrt(2) * (c.real if m > 0 else c.imag)
+            sign = np.sign((Y[:, i] * r).sum())
+            assert sign != 0 and np.abs(Y[:, i] - sign * r).max() < 1e-12, (l, m)
+            i += 1
+    # and the grid quadrature the inverse transform uses integrates them to the identity (18 x 18 grid, l <= 6)
+    to, fr = E.ToS2Grid(6, (18, 18), normalization="integral"), E.FromS2Grid((18, 18), 6, normalization="integral")
+    tg = torch.einsum("mbi,am->bai", to.shb, to.sha).reshape(18 * 18, 49)
+    fg = torch.einsum("am,mbi->bai", fr.sha, fr.shb).reshape(18 * 18, 49)
+    np.testing.assert_allclose((fg.T @ tg).numpy(), np.eye(49), atol=2e-5)
+
+
 @pytest.mark.parametrize("name,lmax", [("eqv2_l4m2.npz", 4), ("eqv2_l6m2.npz", 6)])
 def test_eqv2_groundwork_fixture(name, lmax):
     """EquiformerV2 groundwork: fixtures from the reference model on CPU under the e3nn stand-in
