@@ -12,8 +12,10 @@ allocator / stream / collective plumbing).  There is no autograd graph: `PaiNNTr
 gradients straight into ``param.grad`` of the mirror module, so ``torch.nn.parallel``-style code, checkpoints and the
 reference's parameter naming keep working.
 
-Status (round 2): correctness-first - exact f32, materialised radial projection, unfused elementwise kernels.  Pinned
-against the reference's own autograd (tests/golden/train_small.npz: loss + gradients, oracle/make_golden.py section 6).
+Status (round 4): products on the f16-rate matrix cores (f16x3 forward / data gradients, three-term bf16 split for the weight
+gradients), message forward AND backward through fused kernels that regenerate the radial projection (nothing of size
+[E, 3H] is kept from the forward), elementwise kernels unfused.  Pinned against the reference's own autograd
+(tests/golden/train_small.npz, train_full.npz: loss + gradients, oracle/make_golden.py sections 6 and 10).
 """
 from __future__ import annotations
 
@@ -160,7 +162,7 @@ class PaiNNTrainStep:
                 a["rbfh"] = ops.linear(rbf, P[mp + "rbf_proj.weight"], P[mp + "rbf_proj.bias"], E, 3 * H, R)
             a["x1"], a["vec1"] = ops.new(N, H), ops.new(N, 3, H)
             if self.fused_message_forward:
-                # the sampler's fused kernel (no read of the 6 KB-per-edge rbfh; it stays materialised for the backward)
+                # the sampler's fused kernel (no read of the 6 KB-per-edge rbfh)
                 _lib.check(lib.adf_op_message_fwd_fused(h, l, a["xh"].data_ptr(), vec.data_ptr() if vec is not None else None,
                                                         x.data_ptr(), a["x1"].data_ptr(), a["vec1"].data_ptr(),
                                                         1 if vec is None else 0, s()))
