@@ -10,10 +10,12 @@
 // (gathered from packed gradient records), w = vec[j] / sqrt3, u = unit vector, (ra, rb, rc) = the regenerated rbfh row:
 //   S = g . w;  T = -(g . u)
 //   dxh[j] += (gx ra, S rb, T rc);   dvec[j] += g (xb[j] rb / sqrt3);   drbfh[e] = (gx xa[j], S xb[j], T xc[j])
-// drbfh does not depend on rbfh; it is written in the LANE order of this kernel - per edge row [slice][q][6] =
-// (a, b, c of channel 64 slice + q, then of channel 64 slice + 32 + q) - so that a lane stores 24 contiguous bytes per row
-// (one dwordx4 + one dwordx2 instead of six dwords).  The weight-gradient product of rbf_proj runs on that column order and
-// train_step.py permutes its 3H x R result back (adf_op_message_bwd_perm gives the map).
+// drbfh does not depend on rbfh; it is written in the order this kernel holds it - per edge row [slice][6][32]: the a, b, c
+// parts of channels 64 slice + q, then of channels 64 slice + 32 + q, q = 0..31 - so that every store instruction writes whole
+// 128-byte lines (one per half-wave and value).  The weight-gradient product of rbf_proj runs on that column order and
+// train_step.py permutes its 3H x R result back (adf_op_message_bwd_perm gives the map).  (Measured: 24 contiguous bytes per
+// lane - [slice][q][6], one dwordx4 + one dwordx2 per row instead of six dwords - is 2.5 % of a training step SLOWER: partial
+// lines.  Without the stores the step is 23 ms of 167 shorter: the kernel is bound by the 15 GB it writes.)
 //
 // f16x3 split arithmetic with equally spaced Gaussian centres only (the default; otherwise the training step keeps the
 // unfused backward, train.hip tr_msg_bwd_kernel).
@@ -29,11 +31,14 @@ struct MsgBwdParams {
     const float* gv1;     // [N, 3, H] gradient of vec1 (the residual path of dvec)
     float* dxh;           // [N, 3H]
     float* dvec;          // [N, 3, H] or null
-    float* drbfh;         // [E + 1, 3H] in lane order (row E: spare, written by padded edge rows)
+    float* drbfh;         // [E + 1, 3H] in kernel order (row E: spare, written by padded edge rows)
     int E;
 };
 
 #define MSGB_WAVES_PER_SIMD 2
+#ifndef MSGB_STORE
+#define MSGB_STORE 1   // layout of a drbfh row: 0 = [slice][q][6] (24 B per lane: dwordx4 + dwordx2), 1 = [slice][6][q] (six dwords)
+#endif
 #ifndef MSGB_AHEAD
 #define MSGB_AHEAD 2   // gather rows requested ahead of the row being consumed (4: as the forward kernel)
 #endif
@@ -85,9 +90,10 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
     const float umax_scale = (float)(p.R - 1);
     const unsigned int row_bytes = (unsigned int)p.nslices * 1280u;
     const char* recA = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 16;
-    // lane order of drbfh: row e, then [slice][q][6]
+    // kernel order of drbfh: row e, then [slice][6][32] (MSGB_STORE 1) or [slice][q][6] (0)
     const size_t drow_bytes = (size_t)3 * H * sizeof(float);
     char* dlane = reinterpret_cast<char*>(pb.drbfh) + (size_t)slice * 768 + (size_t)q * 24;
+    char* dline = reinterpret_cast<char*>(pb.drbfh) + (size_t)slice * 768 + (size_t)q * 4;   // MSGB_STORE 1: [slice][6][32]
 
     auto fetch_target = [&](int& n_out) -> bool {
         while (true) {
@@ -195,10 +201,15 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
             vx0 += ga0##r.x * f0; vy0 += ga0##r.y * f0; vz0 += ga0##r.z * f0;                   \
             vx1 += ga1##r.x * f1; vy1 += ga1##r.y * f1; vz1 += ga1##r.z * f1;                   \
         }                                                                                       \
-        {                                                                                       \
+        if (MSGB_STORE == 2) {  /* timing experiment: no drbfh stores (wrong results) */        \
+        } else if (MSGB_STORE == 0) {                                                           \
             char* d = dlane + (size_t)(unsigned int)__float_as_int(m##r[4]) * drow_bytes;       \
             *reinterpret_cast<float4*>(d) = make_float4(ga0##r.w * xa0, S0 * xb0, T0 * xc0, ga1##r.w * xa1); \
             *reinterpret_cast<float2*>(d + 16) = make_float2(S1 * xb1, T1 * xc1);               \
+        } else {                                                                                \
+            float* d = reinterpret_cast<float*>(dline + (size_t)(unsigned int)__float_as_int(m##r[4]) * drow_bytes); \
+            d[0] = ga0##r.w * xa0; d[32] = S0 * xb0; d[64] = T0 * xc0;                          \
+            d[96] = ga1##r.w * xa1; d[128] = S1 * xb1; d[160] = T1 * xc1;                       \
         }                                                                                       \
     }
             GATHER(0) GATHER(1) GATHER(2) GATHER(3)
@@ -351,12 +362,12 @@ extern "C" int32_t adf_op_message_bwd_fused_supported(adf_painn_t h) {
     return h && h->weights_set && !h->msg_f32 && h->rbf_uniform && h->hp.num_rbf <= 128 && (h->hp.num_rbf % 8) == 0 ? 1 : 0;
 }
 
-// column c' of the lane-ordered drbfh row <-> column perm[c'] of the [a | b | c] layout of rbf_proj's output
+// column c' of the kernel-ordered drbfh row <-> column perm[c'] of the [a | b | c] layout of rbf_proj's output
 extern "C" int32_t adf_op_message_bwd_perm(adf_painn_t h, int32_t* perm_host, int32_t n) {
     if (!h || !perm_host || n != 3 * h->hp.hidden_channels) { adf_set_error("message_bwd_perm: bad argument"); return ADF_EINVAL; }
     const int H = h->hp.hidden_channels;
     for (int c = 0; c < n; ++c) {
-        const int slice = c / 192, r = c % 192, qq = r / 6, v = r % 6;
+        const int slice = c / 192, r = c % 192, qq = MSGB_STORE == 0 ? r / 6 : r % 32, v = MSGB_STORE == 0 ? r % 6 : r / 32;
         perm_host[c] = (v % 3) * H + slice * ADF_SLICE_CH + (v / 3) * 32 + qq;
     }
     return ADF_OK;

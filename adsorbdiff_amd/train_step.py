@@ -287,7 +287,7 @@ class PaiNNTrainStep:
             dvec_in = None if first else ops.new(N, 3, H)
             dx_in = ops.new(N, H)
             if fused_bwd:
-                # drbfh comes back with its columns in the kernel's lane order: the weight gradient is formed on that order
+                # drbfh comes back with its columns in the kernel's own order: the weight gradient is formed on that order
                 # and its rows are permuted back (3H x R, tiny)
                 _lib.check(lib.adf_op_message_bwd_fused(h, l, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
                                                         dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(), drbfh.data_ptr(), E,

@@ -344,9 +344,9 @@ int32_t adf_op_message_bwd(adf_painn_t h, const float* xh, const float* vec, con
                            void* stream);
 /* The same backward with rbfh REGENERATED inside the kernel on the matrix cores (message_bwd.hip; autograd through
  * painn_denoising.py:530-567): no [E,3H] operand is kept from the forward or recomputed by a dense product.  drbfh is written
- * ([num_edges + 1, 3H]: one spare row that the kernel's padded edge rows write) with its 3H columns in the kernel's lane
+ * ([num_edges + 1, 3H]: one spare row that the kernel's padded edge rows write) with its 3H columns in the kernel's own
  * order; adf_op_message_bwd_perm fills perm[c'] = the column of rbf_proj's output
- * that lane-order column c' holds (host array of 3H entries), so that the weight-gradient product of rbf_proj can run on it
+ * that kernel-order column c' holds (host array of 3H entries), so that the weight-gradient product of rbf_proj can run on it
  * and its rows be permuted back.  Needs the f16x3 arithmetic and equally spaced Gaussian centres
  * (adf_op_message_bwd_fused_supported returns 1) and the layer's rbf_proj images of this step (adf_op_message_fwd_fused
  * builds them).  Gradients agree with adf_op_message_bwd to ~1e-6 relative. */
