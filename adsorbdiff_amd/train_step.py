@@ -314,7 +314,7 @@ class PaiNNTrainStep:
             dlw, dlb = ops.new(H), ops.new(H)
             _lib.check(lib.adf_op_layernorm_bwd(a["x"].data_ptr(), P[mp + "x_layernorm.weight"].data_ptr(),
                                                 a["stats"].data_ptr(), dy.data_ptr(), dx_in.data_ptr(), dlw.data_ptr(),
-                                                dlb.data_ptr(), N, H, ops.scratch(64 * 2 * H + 16).data_ptr(), s()))
+                                                dlb.data_ptr(), N, H, ops.scratch(512 * 2 * H + 16).data_ptr(), s()))
             _lib.check(lib.adf_op_copy_rows(dlw.data_ptr(), H, G[mp + "x_layernorm.weight"].data_ptr(), H, 1, H, 1, s()))
             _lib.check(lib.adf_op_copy_rows(dlb.data_ptr(), H, G[mp + "x_layernorm.bias"].data_ptr(), H, 1, H, 1, s()))
             dx, dvec = dx_in, dvec_in

@@ -327,6 +327,7 @@ int32_t adf_op_ssilu_fwd(const float* h, float* y, int64_t n, void* stream);
 int32_t adf_op_ssilu_bwd(const float* h, const float* dy, float* dh, int64_t n, void* stream);
 int32_t adf_op_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int32_t N, int32_t H,
                              void* stream);
+/* dx is accumulated into; dw, db [H] are written; scratch: 512 * 2 * H floats. */
 int32_t adf_op_layernorm_bwd(const float* x, const float* w, const float* stats, const float* dy, float* dx, float* dw,
                              float* db, int32_t N, int32_t H, float* scratch, void* stream);
 int32_t adf_op_embed_fwd(adf_painn_t h, const int32_t* Z, int32_t N, float* x, void* stream);
