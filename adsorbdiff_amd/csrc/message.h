@@ -39,3 +39,7 @@ struct MsgParams {
 // message3.hip
 int32_t adf_message3_prepare();
 int32_t adf_message3_launch(const MsgParams& p, int num_cus, bool vec_is_zero, hipStream_t s);
+
+// message4.hip
+int32_t adf_message4_prepare();
+int32_t adf_message4_launch(const MsgParams& p, int num_cus, bool vec_is_zero, hipStream_t s);

@@ -554,10 +554,12 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
 #undef SET_LDS
     }
     ADF_TRY(adf_message3_prepare());
+    ADF_TRY(adf_message4_prepare());
     {   // ADF_MSG_KERNEL=v3: the interleaved single-stream kernel of round 4 (message3.hip: correct, tested, currently
         // SLOWER than this file's kernel - 9.4 vs 7.5 ms per full launch, see its header and DESIGN.md); default: this file's
         const char* e = getenv("ADF_MSG_KERNEL");
         h->msg_v3 = e && strcmp(e, "v3") == 0;
+        h->msg_v4 = e && strcmp(e, "v4") == 0;
     }
     return ADF_OK;
 }
@@ -605,6 +607,7 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
         p.dmu2 = (float)(2.0 * d); p.dmusq = (float)(d * d); p.cstep = (float)exp2(-2.0 * d * d);
     }
     if (f16 && h->rbf_uniform && h->msg_v3) return adf_message3_launch(p, h->num_cus, vec_is_zero, s);
+    if (f16 && h->rbf_uniform && h->msg_v4) return adf_message4_launch(p, h->num_cus, vec_is_zero, s);
     if (f16 && h->rbf_uniform) { if (vec_is_zero) LAUNCH_MSG(true, true, true); else LAUNCH_MSG(true, false, true); }
     else if (f16) { if (vec_is_zero) LAUNCH_MSG(true, true, false); else LAUNCH_MSG(true, false, false); }
     else { if (vec_is_zero) LAUNCH_MSG(false, true, false); else LAUNCH_MSG(false, false, false); }

@@ -1189,6 +1189,33 @@ def test_interleaved_message_kernel_agrees_with_the_default(monkeypatch):
     assert rel_err(f1.cpu(), fx["f1"]) < REL_TOL and rel_err(f2.cpu(), fx["f2"]) < REL_TOL
 
 
+def test_four_waves_per_simd_message_kernel_is_bit_identical_to_the_default(monkeypatch):
+    """csrc/message4.hip (ADF_MSG_KERNEL=v4: 16 waves per workgroup, a 32-channel half-slice per wave): the same operations in
+    the same order per channel as message.hip, so the message block's outputs (vec == 0 first layer and general layers) and the
+    model outputs are equal bit for bit."""
+    b = make_batch(3, seed=1000).to(DEV)
+
+    def run(kernel):
+        monkeypatch.setenv("ADF_MSG_KERNEL", kernel)
+        torch.manual_seed(0)
+        m = PaiNN(None, 50, 1, cutoff=10.0, max_neighbors=50, scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True).to(DEV).eval()
+        eng = m.engine()
+        eng.build_graph(b)
+        x = m.atom_emb.embeddings.weight.detach()[b.atomic_numbers.long() - 1].contiguous()
+        vec = torch.zeros(x.shape[0], 3, m.hidden_channels, device=DEV)
+        outs = []
+        for li in range(2):
+            x, vec = eng.message_layer(li, x.contiguous(), vec.contiguous())
+            outs += [x.clone(), vec.clone()]
+            x, vec = eng.update_layer(li, x.contiguous(), vec.contiguous())
+        f1, f2 = m(b)
+        return outs + [f1, f2]
+
+    ref, new = run("v1"), run("v4")
+    for a, c in zip(ref, new):
+        assert torch.equal(a, c)
+
+
 def test_interleaved_message_kernel_in_the_sampling_loop(monkeypatch):
     """ADF_MSG_KERNEL=v3 through the whole sampler (target lists of the incremental layers, compact output rows, the
     vec == 0 first layer, adsorbate-only outputs): the sampled positions agree with the default kernel's run at the size of
