@@ -273,7 +273,14 @@ __global__ __launch_bounds__(256) void tr_wgrad_bf16x6_kernel(const float* __res
     __shared__ float csum[8][128];
     __shared__ unsigned int nzblk[2][4];
     if (threadIdx.x < 8) nzblk[threadIdx.x >> 2][threadIdx.x & 3] = 0u;
-    const int tile = blockIdx.x, split = blockIdx.y;
+    int tile = blockIdx.x, split = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        // all column tiles of a row split on ONE XCD (workgroups go to the XCDs round-robin in dispatch order): its L2 then
+        // serves the split's A rows to the N / 128 tiles once - the rbf_proj call read them 12 x from HBM (29 of 31 GB)
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, j = L >> 3;
+        split = xcd + 8 * (j / (int)gridDim.x);
+        tile = j % (int)gridDim.x;
+    }
     const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = (wave >> 1) * 64, kb = wave & 1;
@@ -468,6 +475,11 @@ extern "C" int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W
     int rows = (int)((M + splits - 1) / splits);
     rows = (rows + 31) / 32 * 32;
     splits = (int)((M + rows - 1) / rows);
+    if (splits >= 8) {   // a multiple of 8 row splits (tr_wgrad_bf16x6_kernel keeps a split's column tiles on one XCD)
+        splits &= ~7;
+        rows = (int)((M + splits - 1) / splits);
+        rows = (rows + 31) / 32 * 32;   // trailing splits may be empty: they contribute zeros
+    }
     if (dA) {
         if (N % 32 == 0) {
             hipLaunchKernelGGL(tr_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(32, 8), 0, s, W, Wt, N, K);
