@@ -107,8 +107,6 @@ struct adf_painn {
     unsigned int* w16_scratch;
     bool gemm_f32;
     bool msg_f32;
-    bool msg_v4;   // ADF_MSG_KERNEL=v4: message4.hip (four waves per SIMD, a 32-channel half-slice per wave)
-    bool msg_v3;   // ADF_MSG_KERNEL=v3: message3.hip (round 4, interleaved single-stream kernel) for the f16x3 / uniform-centre mode
     // per-row power-of-two lifts of the f16x3 products' A operands (default on; ADF_LIFT=0 = the unlifted split of rounds 1-2)
     bool lift_on;
     adf_lift lift;       // [3 capN] magnitudes a launcher measures itself

@@ -1,5 +1,6 @@
-// Shared declarations of the two message kernels (message.hip: the round 1-3 kernel, two waves per SIMD, the exact-f32
-// and non-uniform-centre modes; message3.hip: the software-pipelined single-stream kernel of round 4).
+// Shared declarations of the message kernels (message.hip: forward, two waves per SIMD, f16x3 / exact-f32 / non-uniform-centre
+// modes; message_bwd.hip: the training step's fused backward).  The retired variants (message32 / message3 / message4, all
+// measured slower) live in scratch/experiments/.
 #pragma once
 #include "common.h"
 
@@ -36,10 +37,3 @@ struct MsgParams {
 };
 
 
-// message3.hip
-int32_t adf_message3_prepare();
-int32_t adf_message3_launch(const MsgParams& p, int num_cus, bool vec_is_zero, hipStream_t s);
-
-// message4.hip
-int32_t adf_message4_prepare();
-int32_t adf_message4_launch(const MsgParams& p, int num_cus, bool vec_is_zero, hipStream_t s);

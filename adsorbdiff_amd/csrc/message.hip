@@ -40,6 +40,12 @@
 
 #include "message.h"
 
+#ifndef MSG_ABL
+#define MSG_ABL 0    // timing experiments only (wrong results): 1 = no contraction loop, 2 = no gathers / sums
+#endif
+#ifndef MSG_SKIP
+#define MSG_SKIP 1
+#endif
 #ifndef MSG_EXP_NOXC
 #define MSG_EXP_NOXC 0   // timing experiments only (wrong results): 1 no xc gathers; 2 no record gathers at all
 #endif
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     _Float16* Wlo = Wh + MSG_COLS * MSG_LDK;               // [192][MSG_LDK] lo
     float* Bl = lds + wfloats;
     float* Mu = Bl + MSG_COLS;
-    float* Meta = Mu + 128;
+    float* Meta = Mu + 144;  // 16-entry tail: the operand generated one step ahead may read past the last centre
     int* Ctr = reinterpret_cast<int*>(Meta + MSG_WAVES * 32 * 8);
 
     const int tid = threadIdx.x;
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
         }
         if (!F16 && tid < MSG_COLS) Bl[tid] = p.bpack[slice * MSG_COLS + tid];
         // f16 mode: centres pre-multiplied by sqrt(-coeff*log2 e), so that a Gaussian is exp2(-(xs' - mu')^2)
-        if (tid < 128) Mu[tid] = (tid < p.R ? p.mu[tid] : 2.0f) * (F16 ? p.sarg : 1.0f);
+        if (tid < 144) Mu[tid] = (tid < p.R ? p.mu[tid] : 2.0f) * (F16 ? p.sarg : 1.0f);
         if (tid == 0) *Ctr = 0;
     }
     __syncthreads();
@@ -125,8 +131,11 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     // dwordx4 + one dword per lane (12-B-per-lane loads gather at 0.7x the rate of this split: measured 20 vs 28 TB/s).
     // Lane q owns channels c0+q (half-record 2*slice) and c0+32+q (half-record 2*slice+1).
     const unsigned int row_bytes = (unsigned int)p.nslices * 1280u;
-    const char* recA = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 16;
-    const char* recP = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + 512 + (size_t)q * 4;
+    // gathers: wave-uniform base (SGPR pair) + a 32-bit byte offset per lane -> global_load ... v_off, s[base] (one v_add_u32
+    // per piece instead of 64-bit vector address arithmetic)
+    const char* recS = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280;
+    const unsigned int qA = (unsigned int)q * 16u;
+    const unsigned int qP = 512u + (unsigned int)q * 4u;
 
     unsigned int ksteps = 0;  // wave-uniform; one global atomic per wave at the very end (profiling)
 
@@ -137,6 +146,11 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     // are requested before the current block is processed, so a block exposes no dependent
     // HBM/L2 round trip of its own.
     // n_out = target atom (CSR row, residual row); o_out = output row (= n_out unless a target list is given)
+    // CSR bounds and the target list are written by earlier launches and only read here: loading them through the constant
+    // address space makes them scalar loads (s_load), off the vector-memory queue whose in-order vmcnt the gathers share.
+    typedef const __attribute__((address_space(4))) int32_t* cint_ptr;
+    const cint_ptr nptr_c = (cint_ptr)p.nptr;
+    const cint_ptr tlist_c = (cint_ptr)p.tlist;
     auto fetch_target = [&](int& n_out, int& o_out) -> bool {
         while (true) {
             int t = 0;
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             const int g = worker + (t >> 5) * nworkers;
             if (g >= ngroups) return false;
             const int e = g * ADF_GROUP_NODES + (t & 31);
-            if (e < items) { o_out = e; n_out = p.tlist ? p.tlist[e] : e; return true; }
+            if (e < items) { o_out = e; n_out = p.tlist ? tlist_c[e] : e; return true; }
         }
     };
     auto load_block = [&](int eb, int e1, float4& geo, int& src, bool& valid) {
@@ -158,12 +172,17 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 
     int n = 0, orow = 0, eb = 0, e1 = 0;  // current block
     bool have = fetch_target(n, orow);
-    if (have) { eb = p.nptr[n]; e1 = p.nptr[n + 1]; }
+    if (have) { eb = nptr_c[n]; e1 = nptr_c[n + 1]; }
     int nN = 0, oN = 0, e0N = 0, e1N = 0;  // next target (bounds requested one target ahead)
     bool haveN = have && fetch_target(nN, oN);
-    if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
-    float4 geo; int src; bool valid;
+    if (haveN) { e0N = nptr_c[nN]; e1N = nptr_c[nN + 1]; }
+    float4 geo = make_float4(0.f, 0.f, 0.f, 0.f); int src = 0; bool valid = false;
     if (have) load_block(eb, e1, geo, src, valid);
+    // The loop-carried copies of the first block's edge rows must not be load destinations: hipcc's waitcnt pass merges the
+    // "load pending" state of this path into the loop header and then waits vmcnt(0) at the top of EVERY block, right
+    // behind the next block's streaming loads (a full HBM round trip per block and wave).  An empty asm that "rewrites" the
+    // registers forces the wait here, once.
+    asm volatile("" : "+v"(geo.x), "+v"(geo.y), "+v"(geo.z), "+v"(geo.w), "+v"(src));
     bool first = true;                   // current block is the first of its target
     // running sums over the current target's edges: sx = sum a ; s* = sum P*b ; r* = sum c*r_hat
     // (the 1/sqrt3 and 1/sqrtH factors of painn_denoising.py:550-553 are applied once at the end)
@@ -193,7 +212,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             const float xs = geo.w * p.inv_cutoff;
             // polynomial envelope (radial_basis.py:36-43)
             float xp = xs;
-            for (int i = 1; i < p.env_pi; ++i) xp *= xs;  // xs^p by repeated multiplication (p is a small int)
+            if (p.env_pi == 5) { const float x2 = xs * xs; xp = x2 * x2 * xs; }  // the shipped exponent, no loop
+            else for (int i = 1; i < p.env_pi; ++i) xp *= xs;  // xs^p by repeated multiplication (p is a small int)
             float env = 1.0f + p.env_a * xp + p.env_b * (xp * xs) + p.env_c * (xp * xs * xs);
             env = (xs < 1.0f && valid) ? env : 0.0f;
             __builtin_amdgcn_wave_barrier();  // previous block's meta reads are done
@@ -231,21 +251,24 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 
             // Gather addresses of the 16 accumulator rows of this lane (32-bit byte offsets).
 #define ROW_OF(r) ((r & 3) + 8 * (r >> 2) + 4 * hi)
-#define GATHER(r)                                                                               \
+#define DECL(r)                                                                                 \
     const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
-    const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
     float4 ga0##r, ga1##r;                                     /* P0 P1 P2 xa of channel j = 0, 1 */ \
-    float gz0##r, gz1##r;                                      /* xc */                               \
+    float gz0##r, gz1##r;                                      /* xc */
+#define GATHER(r)                                                                               \
+    {                                                                                           \
+    const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
     if (MSG_EXP_NOXC) { gz0##r = 1.0f; gz1##r = 2.0f; } else {                                 \
-    gz0##r = *reinterpret_cast<const float*>(recP + o##r);                                      \
-    gz1##r = *reinterpret_cast<const float*>(recP + o##r + 640); }                              \
+    gz0##r = *reinterpret_cast<const float*>(recS + (size_t)(o##r + qP));                       \
+    gz1##r = *reinterpret_cast<const float*>(recS + (size_t)(o##r + qP) + 640); }               \
     if (MSG_EXP_NOXC == 2) { ga0##r = make_float4(1.f, 2.f, 3.f, 4.f); ga1##r = ga0##r; }      \
     else if (!VZ) {                                                                             \
-        ga0##r = *reinterpret_cast<const float4*>(recA + o##r);                                 \
-        ga1##r = *reinterpret_cast<const float4*>(recA + o##r + 640);                           \
+        ga0##r = *reinterpret_cast<const float4*>(recS + (size_t)(o##r + qA));                  \
+        ga1##r = *reinterpret_cast<const float4*>(recS + (size_t)(o##r + qA) + 640);            \
     } else {                                                                                    \
-        ga0##r = make_float4(0.f, 0.f, 0.f, *reinterpret_cast<const float*>(recA + o##r + 12)); \
-        ga1##r = make_float4(0.f, 0.f, 0.f, *reinterpret_cast<const float*>(recA + o##r + 652)); \
+        ga0##r = make_float4(0.f, 0.f, 0.f, *reinterpret_cast<const float*>(recS + (size_t)(o##r + qA) + 12)); \
+        ga1##r = make_float4(0.f, 0.f, 0.f, *reinterpret_cast<const float*>(recS + (size_t)(o##r + qA) + 652)); \
+    }                                                                                           \
     }
 #define CONSUME(r)                                                                              \
     {                                                                                           \
@@ -259,6 +282,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
         if (!VZ) { sa1 += ga1##r.x * acc[3][r]; sb1 += ga1##r.y * acc[3][r]; sc1 += ga1##r.z * acc[3][r]; } \
         ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                         \
     }
+            DECL(0) DECL(1) DECL(2) DECL(3) DECL(4) DECL(5) DECL(6) DECL(7)
+            DECL(8) DECL(9) DECL(10) DECL(11) DECL(12) DECL(13) DECL(14) DECL(15)
             // rows 0-3: issued before the MFMA loop, they land while the matrix pipe is busy
             GATHER(0) GATHER(1) GATHER(2) GATHER(3)
 
@@ -285,10 +310,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             }
             if (F16) {
                 const float xsq = xs * p.sarg;
-                int k0 = klo;
-                do {  // at least one step: lets the accumulators live in place across the loop
-                    // A fragment: lane (row q, half hi) holds k = k0 + 8*hi + j, j = 0..7
-                    half8 ah, al;
+                // A fragment of one 16-deep step: lane (row q, half hi) holds k = k0 + 8*hi + j, j = 0..7
+                auto gen_a = [&](int k0, half8& ah, half8& al) {
                     if constexpr (UNI) {
                         // a_j = E exp2(-(t - j d)^2), t = xs' - mu'_{k0+8hi}:  a_{j+1} = a_j r_j,  r_j = exp2(2 d (t - j d) - d^2),
                         // r_{j+1} = r_j exp2(-2 d^2).  Two exp2 + 16 multiplications instead of 8 x (sub, mul, exp2, mul); the
@@ -316,20 +339,28 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                             al[j] = (_Float16)ll[0]; al[j + 1] = (_Float16)ll[1];
                         }
                     } else {
-                    const float4 mu0 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi);
-                    const float4 mu1 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi + 4);
-                    const float mus[8] = {mu0.x, mu0.y, mu0.z, mu0.w, mu1.x, mu1.y, mu1.z, mu1.w};
+                        const float4 mu0 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi);
+                        const float4 mu1 = *reinterpret_cast<const float4*>(Mu + k0 + 8 * hi + 4);
+                        const float mus[8] = {mu0.x, mu0.y, mu0.z, mu0.w, mu1.x, mu1.y, mu1.z, mu1.w};
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float dm = xsq - mus[j];
-                        // a in [0,1] is lifted by 2^8 before the split so that a_lo is a normal fp16 number
-                        // for every term that matters (the matrix core flushes fp16 subnormals)
-                        const float a = env256 * __builtin_amdgcn_exp2f(-(dm * dm));
-                        const _Float16 h = (_Float16)a;
-                        ah[j] = h;
-                        al[j] = (_Float16)(a - (float)h);
+                        for (int j = 0; j < 8; ++j) {
+                            const float dm = xsq - mus[j];
+                            // a in [0,1] is lifted by 2^8 before the split so that a_lo is a normal fp16 number
+                            // for every term that matters (the matrix core flushes fp16 subnormals)
+                            const float a = env256 * __builtin_amdgcn_exp2f(-(dm * dm));
+                            const _Float16 h = (_Float16)a;
+                            ah[j] = h;
+                            al[j] = (_Float16)(a - (float)h);
+                        }
                     }
-                    }
+                };
+                int k0 = klo;
+                if (MSG_ABL != 1)
+                do {  // at least one step: lets the accumulators live in place across the loop
+                    // (generating the NEXT step's operand beside this step's MFMAs was measured: 2-3 % slower - the other wave
+                    // of the SIMD already fills this wave's operand phase with its own MFMAs)
+                    half8 ah, al;
+                    gen_a(k0, ah, al);
                     const _Float16* wh = Wh + (size_t)q * MSG_LDK + k0 + 8 * hi;
                     const _Float16* wl = Wlo + (size_t)q * MSG_LDK + k0 + 8 * hi;
 #pragma unroll
@@ -341,6 +372,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
                         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
                     }
+                    // spread the next operand's ~45 vector instructions and this step's B-fragment reads evenly behind the
+                    // MFMAs (left alone, hipcc packs them behind the last five)
                     k0 += 16;
                 } while (k0 < khi);
             } else {
@@ -359,6 +392,26 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                 } while (k2 < khi);
             }
             // epilogue, software pipelined: next rows' gathers are in flight while rows are consumed
+#if MSG_ABL == 2
+#pragma unroll
+            for (int b = 0; b < 6; ++b) asm volatile("" :: "v"(acc[b]));
+            sx0 += m0[1];
+#elif MSG_SKIP
+            // accumulator rows 4g..4g+3 of a lane are block rows 8g..8g+7: a block with nvalid rows has nothing but padding
+            // beyond group (nvalid-1)/8 - its gathers (of the zero record) and sums are skipped (wave-uniform branches; about
+            // 22 % of all block rows are padding: 50 edges per target in 32-row blocks)
+            GATHER(4) GATHER(5) GATHER(6) GATHER(7)
+            CONSUME(0) CONSUME(1) CONSUME(2) CONSUME(3)
+            if (nvalid <= 16) {
+                CONSUME(4) CONSUME(5) CONSUME(6) CONSUME(7)
+            } else {
+                GATHER(8) GATHER(9) GATHER(10) GATHER(11)
+                CONSUME(4) CONSUME(5) CONSUME(6) CONSUME(7)
+                GATHER(12) GATHER(13) GATHER(14) GATHER(15)
+                CONSUME(8) CONSUME(9) CONSUME(10) CONSUME(11)
+                CONSUME(12) CONSUME(13) CONSUME(14) CONSUME(15)
+            }
+#else
             GATHER(4) GATHER(5) GATHER(6) GATHER(7)
             CONSUME(0) CONSUME(1) CONSUME(2) CONSUME(3)
             GATHER(8) GATHER(9) GATHER(10) GATHER(11)
@@ -366,7 +419,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             GATHER(12) GATHER(13) GATHER(14) GATHER(15)
             CONSUME(8) CONSUME(9) CONSUME(10) CONSUME(11)
             CONSUME(12) CONSUME(13) CONSUME(14) CONSUME(15)
+#endif
 #undef GATHER
+#undef DECL
 #undef CONSUME
 #undef ROW_OF
             if (last) {
@@ -403,7 +458,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
                 first = true;
                 if (have) {
                     haveN = fetch_target(nN, oN);
-                    if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
+                    if (haveN) { e0N = nptr_c[nN]; e1N = nptr_c[nN + 1]; }
                 }
             } else {
                 eb += 32;
@@ -507,7 +562,7 @@ int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec,
 
 static size_t msg_lds_bytes(int R, bool f16) {
     const size_t w = f16 ? (size_t)2 * MSG_COLS * MSG_LDK * 2 : sizeof(float) * (size_t)R * MSG_COLS;
-    return w + sizeof(float) * (MSG_COLS + 128 + MSG_WAVES * 32 * 8) + 16;
+    return w + sizeof(float) * (MSG_COLS + 144 + MSG_WAVES * 32 * 8) + 16;
 }
 
 // The message kernel's images of ONE layer's rbf_proj (f32 image, fp16 hi/lo image, bias images, scale) from the weight
@@ -552,14 +607,6 @@ int32_t adf_pack_rbf(adf_painn* h, hipStream_t s) {
         SET_LDS(false, false, false); SET_LDS(false, true, false); SET_LDS(true, false, false); SET_LDS(true, true, false);
         SET_LDS(true, false, true); SET_LDS(true, true, true);
 #undef SET_LDS
-    }
-    ADF_TRY(adf_message3_prepare());
-    ADF_TRY(adf_message4_prepare());
-    {   // ADF_MSG_KERNEL=v3: the interleaved single-stream kernel of round 4 (message3.hip: correct, tested, currently
-        // SLOWER than this file's kernel - 9.4 vs 7.5 ms per full launch, see its header and DESIGN.md); default: this file's
-        const char* e = getenv("ADF_MSG_KERNEL");
-        h->msg_v3 = e && strcmp(e, "v3") == 0;
-        h->msg_v4 = e && strcmp(e, "v4") == 0;
     }
     return ADF_OK;
 }
@@ -606,8 +653,6 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
         const double d = sqrt(0.5 / (step * step) * 1.4426950408889634) * step;
         p.dmu2 = (float)(2.0 * d); p.dmusq = (float)(d * d); p.cstep = (float)exp2(-2.0 * d * d);
     }
-    if (f16 && h->rbf_uniform && h->msg_v3) return adf_message3_launch(p, h->num_cus, vec_is_zero, s);
-    if (f16 && h->rbf_uniform && h->msg_v4) return adf_message4_launch(p, h->num_cus, vec_is_zero, s);
     if (f16 && h->rbf_uniform) { if (vec_is_zero) LAUNCH_MSG(true, true, true); else LAUNCH_MSG(true, false, true); }
     else if (f16) { if (vec_is_zero) LAUNCH_MSG(true, true, false); else LAUNCH_MSG(true, false, false); }
     else { if (vec_is_zero) LAUNCH_MSG(false, true, false); else LAUNCH_MSG(false, false, false); }

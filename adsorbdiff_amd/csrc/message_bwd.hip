@@ -89,7 +89,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
     const float out_scale = *p.inv_scale * (1.0f / 256.0f);  // accumulators hold 256*scale*rbfh
     const float umax_scale = (float)(p.R - 1);
     const unsigned int row_bytes = (unsigned int)p.nslices * 1280u;
-    const char* recA = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280 + (size_t)q * 16;
+    // gathers: wave-uniform base + 32-bit lane offset (global_load ... v_off, s[base]), as in message.hip
+    const char* recS = reinterpret_cast<const char*>(p.rec) + (size_t)slice * 1280;
+    const unsigned int qA = (unsigned int)q * 16u;
     // kernel order of drbfh: row e, then [slice][6][32] (MSGB_STORE 1) or [slice][q][6] (0)
     const size_t drow_bytes = (size_t)3 * H * sizeof(float);
     char* dlane = reinterpret_cast<char*>(pb.drbfh) + (size_t)slice * 768 + (size_t)q * 24;
@@ -114,14 +116,18 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
         if (valid) { geo = p.e_geom[e]; src = p.e_src[e]; }
     };
 
+    // CSR bounds through the constant address space (scalar loads), first block's rows laundered: see message.hip
+    typedef const __attribute__((address_space(4))) int32_t* cint_ptr;
+    const cint_ptr nptr_c = (cint_ptr)p.nptr;
     int n = 0, eb = 0, e1 = 0;
     bool have = fetch_target(n);
-    if (have) { eb = p.nptr[n]; e1 = p.nptr[n + 1]; }
+    if (have) { eb = nptr_c[n]; e1 = nptr_c[n + 1]; }
     int nN = 0, e0N = 0, e1N = 0;
     bool haveN = have && fetch_target(nN);
-    if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
-    float4 geo; int src; bool valid;
+    if (haveN) { e0N = nptr_c[nN]; e1N = nptr_c[nN + 1]; }
+    float4 geo = make_float4(0.f, 0.f, 0.f, 0.f); int src = 0; bool valid = false;
     if (have) load_block(eb, e1, geo, src, valid);
+    asm volatile("" : "+v"(geo.x), "+v"(geo.y), "+v"(geo.z), "+v"(geo.w), "+v"(src));
     bool first = true;
     // per-atom constants of this lane's two channels (c0 + q, c0 + 32 + q): xh parts and vec / sqrt3
     float xa0 = 0.f, xb0 = 0.f, xc0 = 0.f, xa1 = 0.f, xb1 = 0.f, xc1 = 0.f;
@@ -141,14 +147,14 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
                 xa0 = xr[0]; xa1 = xr[32]; xb0 = xr[H]; xb1 = xr[H + 32]; xc0 = xr[2 * H]; xc1 = xr[2 * H + 32];
                 if (!VZ) {
                     const float* vr = pb.vec + (size_t)n * 3 * H + c0 + q;
-                    wx0 = vr[0] * inv_sqrt3; wx1 = vr[32] * inv_sqrt3;
-                    wy0 = vr[H] * inv_sqrt3; wy1 = vr[H + 32] * inv_sqrt3;
-                    wz0 = vr[2 * H] * inv_sqrt3; wz1 = vr[2 * H + 32] * inv_sqrt3;
+                    // (scaled by 1/sqrt3 behind the contraction loop: a use right here would wait for the loads)
+                    wx0 = vr[0]; wx1 = vr[32]; wy0 = vr[H]; wy1 = vr[H + 32]; wz0 = vr[2 * H]; wz1 = vr[2 * H + 32];
                 }
             }
             const float xs = geo.w * p.inv_cutoff;
             float xp = xs;
-            for (int i = 1; i < p.env_pi; ++i) xp *= xs;
+            if (p.env_pi == 5) { const float x2 = xs * xs; xp = x2 * x2 * xs; }
+            else for (int i = 1; i < p.env_pi; ++i) xp *= xs;
             float env = 1.0f + p.env_a * xp + p.env_b * (xp * xs) + p.env_c * (xp * xs * xs);
             env = (xs < 1.0f && valid) ? env : 0.0f;
             __builtin_amdgcn_wave_barrier();
@@ -181,8 +187,8 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
 #define GATHER(r)                                                                               \
     const float* m##r = meta_w + ROW_OF(r) * 8;                                                 \
     const unsigned int o##r = __float_as_uint(m##r[0]);                                         \
-    const float4 ga0##r = *reinterpret_cast<const float4*>(recA + o##r);                        \
-    const float4 ga1##r = *reinterpret_cast<const float4*>(recA + o##r + 640);
+    const float4 ga0##r = *reinterpret_cast<const float4*>(recS + (size_t)(o##r + qA));         \
+    const float4 ga1##r = *reinterpret_cast<const float4*>(recS + (size_t)(o##r + qA) + 640);
 #define CONSUME(r)                                                                              \
     {                                                                                           \
         const float ux = m##r[1], uy = m##r[2], uz = m##r[3];                                   \
@@ -265,6 +271,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
                     k0 += 16;
                 } while (k0 < khi);
             }
+            if (!VZ && first) {
+                wx0 *= inv_sqrt3; wx1 *= inv_sqrt3; wy0 *= inv_sqrt3; wy1 *= inv_sqrt3; wz0 *= inv_sqrt3; wz1 *= inv_sqrt3;
+            }
 #if MSGB_AHEAD == 4
             GATHER(4) GATHER(5) GATHER(6) GATHER(7)
             CONSUME(0) CONSUME(1) CONSUME(2) CONSUME(3)
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
                 first = true;
                 if (have) {
                     haveN = fetch_target(nN);
-                    if (haveN) { e0N = p.nptr[nN]; e1N = p.nptr[nN + 1]; }
+                    if (haveN) { e0N = nptr_c[nN]; e1N = nptr_c[nN + 1]; }
                 }
             } else {
                 eb += 32;

@@ -1153,89 +1153,3 @@ def test_static_atom_cache_switch_gives_identical_samples():
         den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), static_atom_cache=flag), device=DEV)
         outs.append(den.run().pos.clone())
     assert torch.equal(outs[0], outs[1])
-
-
-def test_interleaved_message_kernel_agrees_with_the_default(monkeypatch):
-    """csrc/message3.hip (ADF_MSG_KERNEL=v3: MFMA chains interleaved with the neighbouring accumulators' vector work, ring
-    gathers, blocks cut to a 64-wide k-window) against the default kernel on benchmark-shaped systems: same arithmetic, so
-    the message block's outputs agree far inside the 1e-4 budget (measured 2e-7 on x, 1e-6 on vec), and the model outputs
-    against the reference fixture stay at 1e-4."""
-    b = make_batch(4, seed=1000).to(DEV)
-
-    def run(kernel):
-        monkeypatch.setenv("ADF_MSG_KERNEL", kernel)
-        torch.manual_seed(0)
-        m = PaiNN(None, 50, 1, cutoff=10.0, max_neighbors=50, scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True).to(DEV).eval()
-        eng = m.engine()
-        eng.build_graph(b)
-        x = m.atom_emb.embeddings.weight.detach()[b.atomic_numbers.long() - 1].contiguous()
-        vec = torch.zeros(x.shape[0], 3, m.hidden_channels, device=DEV)
-        outs = []
-        for li in range(2):   # layer 0: vec == 0 variant; layer 1: the general one
-            x, vec = eng.message_layer(li, x.contiguous(), vec.contiguous())
-            outs += [x.clone(), vec.clone()]
-            x, vec = eng.update_layer(li, x.contiguous(), vec.contiguous())
-        f1, f2 = m(b)
-        return outs + [f1, f2]
-
-    ref, new = run("v1"), run("v3")
-    for a, c in zip(ref, new):
-        assert bool(torch.isfinite(c).all())
-        assert rel_err(c.cpu(), a.cpu()) < 2e-5, rel_err(c.cpu(), a.cpu())
-    fx = load_npz("painn_small.npz")
-    monkeypatch.setenv("ADF_MSG_KERNEL", "v3")
-    m = small_model(fx)
-    f1, f2 = m(batch_from_fixture(fx, device=DEV))
-    assert rel_err(f1.cpu(), fx["f1"]) < REL_TOL and rel_err(f2.cpu(), fx["f2"]) < REL_TOL
-
-
-def test_four_waves_per_simd_message_kernel_is_bit_identical_to_the_default(monkeypatch):
-    """csrc/message4.hip (ADF_MSG_KERNEL=v4: 16 waves per workgroup, a 32-channel half-slice per wave): the same operations in
-    the same order per channel as message.hip, so the message block's outputs (vec == 0 first layer and general layers) and the
-    model outputs are equal bit for bit."""
-    b = make_batch(3, seed=1000).to(DEV)
-
-    def run(kernel):
-        monkeypatch.setenv("ADF_MSG_KERNEL", kernel)
-        torch.manual_seed(0)
-        m = PaiNN(None, 50, 1, cutoff=10.0, max_neighbors=50, scale_file=PAINN_NB6_SCALE_FACTORS, so3_denoising=True).to(DEV).eval()
-        eng = m.engine()
-        eng.build_graph(b)
-        x = m.atom_emb.embeddings.weight.detach()[b.atomic_numbers.long() - 1].contiguous()
-        vec = torch.zeros(x.shape[0], 3, m.hidden_channels, device=DEV)
-        outs = []
-        for li in range(2):
-            x, vec = eng.message_layer(li, x.contiguous(), vec.contiguous())
-            outs += [x.clone(), vec.clone()]
-            x, vec = eng.update_layer(li, x.contiguous(), vec.contiguous())
-        f1, f2 = m(b)
-        return outs + [f1, f2]
-
-    ref, new = run("v1"), run("v4")
-    for a, c in zip(ref, new):
-        assert torch.equal(a, c)
-
-
-def test_interleaved_message_kernel_in_the_sampling_loop(monkeypatch):
-    """ADF_MSG_KERNEL=v3 through the whole sampler (target lists of the incremental layers, compact output rows, the
-    vec == 0 first layer, adsorbate-only outputs): the sampled positions agree with the default kernel's run at the size of
-    the two kernels' arithmetic difference (1e-6 per forward; 8 well-conditioned steps), and a v3 run with incremental
-    layers equals a v3 run without them bit for bit."""
-    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
-    from adsorbdiff_amd.trainer import DenoisingTrainer
-
-    fx = load_npz("stepper_ode8.npz")
-    res = {}
-    for kernel, extra in (("v1", {}), ("v3", {}), ("v3", {"incremental_layers": False}), ("v3", {"scores_on_adsorbate_only": True})):
-        monkeypatch.setenv("ADF_MSG_KERNEL", kernel)
-        tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
-        b = batch_from_fixture(fx, pos_key="pos_in")
-        torch.manual_seed(int(fx["seed"]))
-        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), early_stop=False, **extra), device=DEV)
-        res[(kernel, tuple(extra))] = den.run().pos.cpu()
-        tr._unwrapped_model.engine().close()
-    ref = res[("v1", ())]
-    assert float((res[("v3", ())] - ref).abs().max()) < 2e-4
-    np.testing.assert_allclose(res[("v3", ())].numpy(), fx["pos_final"], rtol=0, atol=2e-4)
-    assert torch.equal(res[("v3", ())], res[("v3", ("incremental_layers",))])
-    assert torch.equal(res[("v3", ())], res[("v3", ("scores_on_adsorbate_only",))])
