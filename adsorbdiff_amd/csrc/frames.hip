@@ -26,7 +26,8 @@ struct adf_frames {
     bool drained_live[2];
     std::vector<hipEvent_t>* landed;      // per slot: the device-to-host copy has completed
     std::vector<int64_t>* slot_frame;     // frame index held by a slot, -1 = free
-    int64_t pushed;                        // frames pushed so far (push order = 0, 1, 2, ...)
+    int64_t pushed;                        // frames pushed so far (push order = 0, 1, 2, ...); written and read under mu
+    bool aborted;                          // set by adf_frames_abort (the writer died / the run was cancelled): wakes every waiter
     std::mutex* mu;
     std::condition_variable* cv;
 };
@@ -35,7 +36,7 @@ extern "C" int32_t adf_frames_create(int32_t device, int64_t frame_floats, int32
     if (!out || frame_floats <= 0 || slots < 2) { adf_set_error("frames_create: bad argument"); return ADF_EINVAL; }
     ADF_HIP_CHECK(hipSetDevice(device));
     adf_frames* f = new adf_frames();
-    f->device = device; f->frame_floats = frame_floats; f->slots = slots; f->pushed = 0;
+    f->device = device; f->frame_floats = frame_floats; f->slots = slots; f->pushed = 0; f->aborted = false;
     f->stage[0] = f->stage[1] = nullptr; f->ring = nullptr; f->copy_stream = nullptr;
     f->staged[0] = f->staged[1] = f->drained[0] = f->drained[1] = nullptr;
     f->landed = new std::vector<hipEvent_t>(slots, (hipEvent_t) nullptr);
@@ -86,28 +87,41 @@ extern "C" int32_t adf_frames_destroy(adf_frames_t f) {
     return ADF_OK;
 }
 
-// Enqueue frame number f->pushed (the caller's frames are numbered in push order).
+// Enqueue frame number f->pushed (the caller's frames are numbered in push order).  Returns ADF_EINVAL once the ring has been
+// aborted (adf_frames_abort: the consumer is gone) instead of waiting for a slot that will never be released.
 int32_t adf_frames_push_impl(adf_frames* f, const float* src, hipStream_t s) {
-    const int64_t index = f->pushed;
-    const int k = (int)(index & 1);
-    const int slot = (int)(index % f->slots);
+    int64_t index;
+    int slot;
     {   // the ring slot must have been released by the writer (blocks only when the writer is a whole ring behind)
         std::unique_lock<std::mutex> lk(*f->mu);
-        f->cv->wait(lk, [&] { return (*f->slot_frame)[slot] < 0; });
+        index = f->pushed;
+        slot = (int)(index % f->slots);
+        f->cv->wait(lk, [&] { return f->aborted || (*f->slot_frame)[slot] < 0; });
+        if (f->aborted) { adf_set_error("frames_push: the ring was aborted (its consumer stopped)"); return ADF_EINVAL; }
         (*f->slot_frame)[slot] = index;
     }
+    const int k = (int)(index & 1);
     const size_t bytes = sizeof(float) * (size_t)f->frame_floats;
-    if (f->drained_live[k]) ADF_HIP_CHECK(hipStreamWaitEvent(s, f->drained[k], 0));   // stage[k]'s previous frame is out
-    ADF_HIP_CHECK(hipMemcpyAsync(f->stage[k], src, bytes, hipMemcpyDeviceToDevice, s));
-    ADF_HIP_CHECK(hipEventRecord(f->staged[k], s));
-    ADF_HIP_CHECK(hipStreamWaitEvent(f->copy_stream, f->staged[k], 0));
-    ADF_HIP_CHECK(hipMemcpyAsync(f->ring + (size_t)slot * f->frame_floats, f->stage[k], bytes, hipMemcpyDeviceToHost,
-                                 f->copy_stream));
-    ADF_HIP_CHECK(hipEventRecord(f->drained[k], f->copy_stream));
-    f->drained_live[k] = true;
-    ADF_HIP_CHECK(hipEventRecord((*f->landed)[slot], f->copy_stream));
-    f->pushed = index + 1;
+    hipError_t e = hipSuccess;
+    if (f->drained_live[k]) e = hipStreamWaitEvent(s, f->drained[k], 0);   // stage[k]'s previous frame is out
+    if (e == hipSuccess) e = hipMemcpyAsync(f->stage[k], src, bytes, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipEventRecord(f->staged[k], s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(f->copy_stream, f->staged[k], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(f->ring + (size_t)slot * f->frame_floats, f->stage[k], bytes, hipMemcpyDeviceToHost,
+                                            f->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(f->drained[k], f->copy_stream);
+    if (e == hipSuccess) { f->drained_live[k] = true; e = hipEventRecord((*f->landed)[slot], f->copy_stream); }
+    {
+        std::lock_guard<std::mutex> lk(*f->mu);
+        if (e == hipSuccess) f->pushed = index + 1;
+        else (*f->slot_frame)[slot] = -1;   // the frame was not enqueued: the slot is free again, `pushed` does not advance
+    }
     f->cv->notify_all();
+    if (e != hipSuccess) {
+        adf_set_error("frames_push: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? ADF_EOOM : ADF_EHIP;
+    }
     return ADF_OK;
 }
 
@@ -125,8 +139,8 @@ extern "C" int32_t adf_frames_wait(adf_frames_t f, int64_t index, int32_t timeou
     {
         std::unique_lock<std::mutex> lk(*f->mu);
         const bool ok = f->cv->wait_for(lk, std::chrono::milliseconds(timeout_ms > 0 ? timeout_ms : 1),
-                                        [&] { return f->pushed > index; });
-        if (!ok) return ADF_OK;
+                                        [&] { return f->aborted || f->pushed > index; });
+        if (!ok || f->pushed <= index) return ADF_OK;   // time-out, or aborted before this frame was pushed
         if ((*f->slot_frame)[slot] != index) { adf_set_error("frames_wait: frame %lld is no longer in the ring", (long long)index); return ADF_EINVAL; }
     }
     ADF_HIP_CHECK(hipSetDevice(f->device));
@@ -141,6 +155,18 @@ extern "C" int32_t adf_frames_release(adf_frames_t f, int64_t index) {
     {
         std::lock_guard<std::mutex> lk(*f->mu);
         if ((*f->slot_frame)[slot] == index) (*f->slot_frame)[slot] = -1;
+    }
+    f->cv->notify_all();
+    return ADF_OK;
+}
+
+// Cancel the ring: every present and future adf_frames_push fails (ADF_EINVAL) instead of waiting for a free slot, every
+// adf_frames_wait returns at once.  Called by the host writer when it stops early (I/O error) and by a cancelled run.
+extern "C" int32_t adf_frames_abort(adf_frames_t f) {
+    if (!f) return ADF_OK;
+    {
+        std::lock_guard<std::mutex> lk(*f->mu);
+        f->aborted = true;
     }
     f->cv->notify_all();
     return ADF_OK;

@@ -24,9 +24,13 @@ Extensions (all optional, defaults reproduce the reference):
     node state of every layer across the steps and recomputes a row only if one of its inputs changed since it was
     computed (detected by comparing the new graph with the previous one bit for bit and following the edges; the
     receptive field of the moving adsorbate grows one neighbour shell per layer).  Bit-identical results.
-  * ``denoising_pos_params["scores_on_adsorbate_only"]`` (default False): the update only ever reads the
-    model output on tag-2 atoms (reference :263-268, :460-467), so the last layer and the heads can be
-    evaluated for those atoms alone (``adf_painn_forward_subset``).  Sampled positions are bit-identical.
+  * ``denoising_pos_params["scores_on_adsorbate_only"]`` (default: on inside the fused loop, off on the per-step
+    path): the update only ever reads the model output on tag-2 atoms (reference :263-268, :460-467), so the last
+    layer and the heads can be evaluated for those atoms alone (``adf_painn_forward_subset`` /
+    ``adf_eqv2_forward_subset``).  Sampled positions are bit-identical.  Inside ``adf_sample`` / ``adf_sample_traj``
+    the per-atom outputs never leave the library, so since round 5 the subset form is what runs there unless the
+    caller passes ``False``; the per-step path (step hook, host noise, graph replay) and every direct
+    ``model.forward(data)`` / ``predict_denoising`` call keep the full per-atom outputs.
   * ``denoising_pos_params["placement_noise"]`` (default None): ``[B,3]`` uniforms for the initial placement instead
     of ``torch.rand(B,3)`` from the CPU generator (:215) — a sharded run that indexes one global table by system id
     samples exactly what the single-process run samples.
@@ -197,8 +201,6 @@ class Denoiser:
                 f1 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
                 f2 = torch.zeros(N, 3, dtype=torch.float32, device=dev)
                 out_idx = None
-                if params.get("scores_on_adsorbate_only", False):
-                    out_idx = torch.nonzero(prep.tags == 2).reshape(-1).to(torch.int32).contiguous()
                 state = torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
                 frames = [] if self.traj_dir else None
                 sink = writer = None
@@ -224,6 +226,11 @@ class Denoiser:
                 # the whole loop is one library call (adf_sample), polling the early-stop flag every `check_every` steps.
                 step_hook = params.get("step_hook")  # extension: callable(t) after every applied step (diagnostics)
                 fused_loop = (not use_graph) and self.noise_fn is None and step_hook is None
+                ads_only = params.get("scores_on_adsorbate_only")
+                if ads_only is None:
+                    ads_only = fused_loop   # unobservable there: no per-atom output leaves adf_sample
+                if ads_only:
+                    out_idx = torch.nonzero(prep.tags == 2).reshape(-1).to(torch.int32).contiguous()
                 if fused_loop and frames is not None:
                     # trajectory frames leave the device from inside the fused loop (csrc/frames.hip) and a host thread
                     # writes them while the next steps compute (trajectory.py); frames = None: nothing is kept here
@@ -251,8 +258,9 @@ class Denoiser:
                                 _lib.check(eng.lib.adf_frames_push(sink.handle, pos.data_ptr(), eng._stream()))
                         eng.check_flags()
                     except BaseException:
-                        if writer is not None:   # a failed attempt (e.g. the f16x3 range was left): drop its frames
-                            writer.finish(0)
+                        if writer is not None:   # a failed attempt (e.g. the f16x3 range was left): drop its frames,
+                            writer.abort()       # publish no file (temporary files deleted), wake a blocked push
+                            sink.abort()
                             writer.join()
                             sink.close()
                         raise

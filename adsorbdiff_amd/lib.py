@@ -24,7 +24,7 @@ EXPORTS = (
     "adf_check_flags", "adf_painn_set_arithmetic", "adf_painn_set_incremental",
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_sample_traj",
-    "adf_frames_create", "adf_frames_destroy", "adf_frames_push", "adf_frames_wait", "adf_frames_release", "adf_frames_pushed",
+    "adf_frames_create", "adf_frames_destroy", "adf_frames_push", "adf_frames_wait", "adf_frames_release", "adf_frames_pushed", "adf_frames_abort",
     "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_lift_adsorbates", "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
     "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_fwd_fused", "adf_op_message_bwd", "adf_op_message_bwd_fused", "adf_op_message_bwd_fused_supported", "adf_op_message_bwd_perm", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
@@ -189,6 +189,7 @@ def load():
         "adf_frames_push": [vp, vp, vp],
         "adf_frames_wait": [vp, i64, i32, C.POINTER(C.POINTER(C.c_float))],
         "adf_frames_release": [vp, i64],
+        "adf_frames_abort": [vp],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)

@@ -54,6 +54,12 @@ class FrameSink:
     def pushed(self) -> int:
         return int(self.lib.adf_frames_pushed(self.handle))
 
+    def abort(self) -> None:
+        """Cancel the ring: a sampler blocked in (or later calling) ``adf_frames_push`` gets an error instead of waiting
+        for a slot nobody will release."""
+        if self.handle:
+            self.lib.adf_frames_abort(self.handle)
+
     def close(self) -> None:
         if self.handle:
             self.lib.adf_frames_destroy(self.handle)
@@ -76,6 +82,7 @@ class TrajectoryWriter(threading.Thread):
         self.max_frames = int(max_frames)
         self.keep_last_only = bool(keep_last_only)
         self.error: Optional[BaseException] = None
+        self._aborted = False
         self._n_final: Optional[int] = None
         self._lock = threading.Lock()
         self.frames_written = 0
@@ -86,15 +93,42 @@ class TrajectoryWriter(threading.Thread):
         with self._lock:
             self._n_final = int(n_frames)
 
+    def abort(self) -> None:
+        """The run failed: drain nothing more, delete the temporary files and publish NOTHING (the reference renames
+        ``.traj_tmp`` to ``.traj`` only after a completed run, denoising_torch.py:66-82, and ``check_traj_files`` treats
+        every existing ``<sid>`` file as a finished system)."""
+        with self._lock:
+            self._aborted = True
+            self._n_final = 0
+
     def _final(self) -> Optional[int]:
         with self._lock:
             return self._n_final
+
+    def _is_aborted(self) -> bool:
+        with self._lock:
+            return self._aborted
+
+    def _cleanup_tmp(self) -> None:
+        for pth in list(self.traj_dir.glob("*.npz_tmp")) + [self.batch_stem.with_suffix(".frames.npy_tmp"),
+                                                            self.batch_stem.with_suffix(".json_tmp")]:
+            try:
+                pth.unlink()
+            except OSError:
+                pass
 
     def run(self) -> None:
         try:
             self._run()
         except BaseException as e:  # surfaced by join_checked()
             self.error = e
+            # the sampler must not wait for ring slots this thread will never release
+            if hasattr(self.source, "abort"):
+                try:
+                    self.source.abort()
+                except Exception:
+                    pass
+            self._cleanup_tmp()
 
     def _run(self) -> None:
         self.traj_dir.mkdir(exist_ok=True, parents=True)
@@ -119,6 +153,14 @@ class TrajectoryWriter(threading.Thread):
             got += 1
             self.frames_written = got
         n = min(self._final(), got)
+        if self._is_aborted() or n <= 0:
+            # nothing to publish: an aborted run, or a run that applied no step (never a <sid>.npz with zero frames: the
+            # resume rule would count the system as done)
+            del mm
+            self._cleanup_tmp()
+            if hasattr(self.source, "abort") and self._is_aborted():
+                self.source.abort()
+            return
         # frames pushed but not counted (after an early stop): give their slots back so that the ring never blocks
         k = got
         while True:

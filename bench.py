@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--gather", choices=("torch", "rccl"), default="torch",
                     help="exchange step: torch.distributed.all_gather (nccl backend = RCCL) or the library's own "
                          "C-ABI adf_allgather_sites (RCCL communicator created by the library)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the adsorbate-only and exact-f32 extra passes")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the default-API (adsorbate-only outputs), exact-f32 and other extra passes")
     ap.add_argument("--no-incremental", action="store_true",
                     help="PaiNN: recompute every node row of every layer at every step, as the reference does "
                          "(denoising_pos_params['incremental_layers']=False) - timed like the default, warm-up included")
@@ -139,17 +139,22 @@ def cpu_baseline(model_sd, scale_factors, params, full=False):
         return {"systems": n_sys, "reverse_steps": n_steps, "seconds": round(dt, 2),
                 "system_steps_per_s": n_sys * n_steps / dt}
 
-    wide = run(64, 1) if full else run(16, 1)
-    loop = run(8, params["num_steps"]) if full else run(2, 6)
-    best = max(wide["system_steps_per_s"], loop["system_steps_per_s"])
+    # SURVEY 8d names 64 x 1 and 8 x 50 (about 10 min on the box's host cores: --cpu-full, committed once per round under
+    # profiles/); the default run is bounded to ~1 min so that the whole bench line stays within a few minutes:
+    # 32 systems x 1 step and 2 systems x 10 consecutive steps.  BOTH rates are reported; `value` is the throughput
+    # sample's (the batched workload), not the better of the two.
+    wide = run(64, 1) if full else run(32, 1)
+    loop = run(8, params["num_steps"]) if full else run(2, 10)
     return {
-        "value": best / params["num_steps"],
+        "value": wide["system_steps_per_s"] / params["num_steps"],
         "unit": "sites/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
+        "throughput_sample_sites_per_s": wide["system_steps_per_s"] / params["num_steps"],
+        "loop_sample_sites_per_s": loop["system_steps_per_s"] / params["num_steps"],
         "sample": "%d systems x 1 reverse step in %.1f s (%.3f system-steps/s) and %d systems x %d consecutive steps "
-                  "in %.1f s (%.3f system-steps/s); value = the better rate / %d steps per site, i.e. LINEARLY "
-                  "EXTRAPOLATED to the 1000-system x %d-step workload" % (
+                  "in %.1f s (%.3f system-steps/s); value = the FIRST rate / %d steps per site, i.e. LINEARLY "
+                  "EXTRAPOLATED to the 1000-system x %d-step workload (SURVEY 8d's sizes, 64 x 1 and 8 x 50: --cpu-full)" % (
                       wide["systems"], wide["seconds"], wide["system_steps_per_s"], loop["systems"],
                       loop["reverse_steps"], loop["seconds"], loop["system_steps_per_s"], params["num_steps"],
                       params["num_steps"]),
@@ -175,6 +180,11 @@ def traffic_probe(args):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
     if exe is None:
         TRAFFIC_PROBE["error"] = "rocprofv3 not found"
+        return
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", "") or \
+            os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        # this process itself runs under a profiler: its children would inherit the tool environment and nest profilers
+        TRAFFIC_PROBE["error"] = "skipped: bench.py itself runs under rocprofv3 (static figure reported)"
         return
     t_start = time.perf_counter()
     res = {}
@@ -334,8 +344,11 @@ def main():
         n_local = len(my_ids)
         batch0 = batch0.to(dev)
     total_systems = args.systems * world if args.scaling == "weak" else args.systems
+    # `value` stays on the full-output path (every atom's model outputs at every step) for round-to-round comparability;
+    # what Denoiser.run() does without options since round 5 (outputs of the adsorbate atoms only inside the fused loop:
+    # nothing else is observable there) is timed as the secondary `value_default_api`
     params = dict(num_steps=args.num_steps, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55,
-                  ode=True, early_stop=False)
+                  ode=True, early_stop=False, scores_on_adsorbate_only=False)
     if args.no_incremental:
         params["incremental_layers"] = False
     eng = model.engine(dev)
@@ -377,10 +390,17 @@ def main():
         sites = one_pass()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own time over the timed passes (its clock stops when ITS last all_gather returned) and its GPU-busy
+        # time: the first real multi-GPU run then shows the curve and where its imbalance comes from in one line
+        busy = sum(v[0] for v in eng.profile_read().values() if isinstance(v, tuple))
+        t = torch.tensor([elapsed * 1e3 / args.steps, busy / args.steps, float(n_local), float(batch0.pos.shape[0])],
+                         dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [[round(float(v), 2) for v in a.tolist()] for a in allt]
+        elapsed = max(a[0] for a in rank_ms) * args.steps / 1e3
     prof = eng.profile_read()
     eng.profile_enable(False)
     counters = eng.counters()
@@ -389,7 +409,6 @@ def main():
     # adsorbate atoms only (the stepper reads nothing else; sampled positions are bit-identical, checked here).
     ads_only = exact_f32 = all_rows = small = traj_sink = None
     if world == 1 and not args.no_secondary:
-        one_pass({"incremental_layers": False})  # untimed: switching the feature off frees its 22 GB of kept state
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         sites_full = one_pass({"incremental_layers": False})
@@ -398,18 +417,25 @@ def main():
         all_rows = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
                     "identical_sites": bool(torch.equal(sites_full, sites)),
                     "note": "denoising_pos_params['incremental_layers']=False: every node row of every layer recomputed "
-                            "at every step, as the reference does; one pass after one untimed pass, not part of `value` "
-                            "(`--no-incremental` times it like the default)"}
+                            "at every step, as the reference does; ONE pass, the first after the switch (it also frees the "
+                            "22 GB of kept layer state: ~1 % of the pass), not part of `value` (`--no-incremental` times it "
+                            "like the default, warm-up included)"}
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        sites_ads = one_pass({"scores_on_adsorbate_only": True})
+        one_pass({"scores_on_adsorbate_only": None})   # untimed: back to incremental layers (kept state re-allocated)
         torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for _ in range(2):
+            sites_ads = one_pass({"scores_on_adsorbate_only": None})
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t1) / 2
         ads_only = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
                     "identical_sites": bool(torch.equal(sites_ads, sites)),
-                    "note": "opt-in denoising_pos_params['scores_on_adsorbate_only']: last layer's message targets, its "
-                            "update and the heads evaluated for tag-2 atoms only (adf_painn_forward_subset); one pass, "
-                            "not part of `value`"}
+                    "note": "Denoiser(...).run() WITHOUT options, as a caller of the reference's API invokes it: inside the fused "
+                            "loop (adf_sample / adf_sample_traj) the per-atom model outputs never leave the library, so since "
+                            "round 5 the last layer's message targets, its update and the heads are evaluated for the tag-2 "
+                            "atoms only (adf_painn_forward_subset; bit-identical sites, checked here); 2 timed passes after 1 "
+                            "untimed; `value` itself stays on the full-output path (scores_on_adsorbate_only=False)"}
         # The reference's default call keeps every frame (ml_relaxation.py:134-149: save_full_traj=True + traj_dir): one pass
         # with the asynchronous sink (csrc/frames.hip + trajectory.py), timed until run() returns (every file written).
         import shutil
@@ -576,6 +602,12 @@ def main():
                                        % (100.0 * counters.inc_rows / max(counters.inc_rows_full, 1))) if inc_on else "off",
             },
             "sites_sha256_16": sites_digest,  # equal for every --gpus N under --scaling strong (same systems, same noise)
+            "per_rank": None if rank_ms is None else {
+                "ms_per_step": [a[0] for a in rank_ms], "gpu_busy_ms_per_step": [a[1] for a in rank_ms],
+                "systems": [int(a[2]) for a in rank_ms], "atoms": [int(a[3]) for a in rank_ms],
+                "imbalance_max_over_mean": round(max(a[0] for a in rank_ms) / (sum(a[0] for a in rank_ms) / len(rank_ms)), 4),
+                "note": "wall time of each rank over the timed passes (barrier to its own last all_gather), the GPU time of its "
+                        "kernels (HIP events), and its share of the batch; `ms_per_step` of the line is the maximum"},
             "system_steps_per_s": total_systems * args.steps * args.num_steps / elapsed,
             "gpu_ms_per_pass": gpu_ms,
             "roofline": {
@@ -590,6 +622,7 @@ def main():
                 "frac_of_measured_peak": issued / peak_meas if peak_meas > 0 else None,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "traffic_probe_seconds": TRAFFIC_PROBE.get("seconds"),
                 "avg_launch_ms": avg_s * 1e3,
                 "launches": msg_launches,
                 "flops_per_launch": issued_flops_per_launch,
@@ -614,7 +647,7 @@ def main():
             "incremental_layers_off": all_rows,
             "value_at_125_systems": small,
             "with_trajectory_sink": traj_sink,
-            "scores_on_adsorbate_only": ads_only,
+            "value_default_api": ads_only,
             "exact_f32": exact_f32,
         }
         if TRAFFIC_PROBE.get("error"):
@@ -696,6 +729,15 @@ def main_train(args, rank, world, dev, emit=True):
         step_flops = 3.0 * fwd * args.systems  # forward + data-gradient + weight-gradient products
         graphs = args.systems * world * args.steps
         grad_bytes = sum(p.numel() for p in model.parameters() if p.requires_grad) * 4
+        train_traffic = train_traffic_src = None
+        pmc = ROOT / "profiles" / "train_step_pmc.json"
+        if pmc.exists():  # separate rocprofv3 --pmc passes of this command (profiles/scripts): bytes per graph x this batch
+            try:
+                j = json.loads(pmc.read_text())
+                train_traffic = j["hbm_bytes_per_step_and_graph"] * args.systems
+                train_traffic_src = "static: profiles/train_step_pmc.json (%s); not measured in this run" % j.get("source", "")
+            except Exception:
+                train_traffic = None
         out_line = {
             "metric": "score-matching training graphs/sec (PaiNN H=512 x 6, ~200-atom OC20-shaped graphs, forward + backward + "
                       "all-reduce + AdamW + EMA)",
@@ -713,12 +755,23 @@ def main_train(args, rank, world, dev, emit=True):
             "allreduce_wait_ms_per_step": ar_ms if world > 1 else 0.0,  # what the backward did not hide
             "gradient_bytes": grad_bytes,
             "roofline": {"kernel": "whole step: dense products of forward + backward",
-                         "bound": "mfma", "achieved": step_flops * world * args.steps / elapsed / 1e12 / world,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": step_flops * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "note": "achieved = 3 x the forward's dense flops (SURVEY 8d: 34.6 GFLOP per graph) per graph and "
-                                 "step / wall time per step, per GPU, priced against the f32 matrix peak (the arithmetic the "
-                                 "reference runs); the products themselves run as f16x3 / bf16x6 splits on the f16-rate cores"},
+                         "bound": "mfma",
+                         # issued matrix-core flops per dense flop: forward and data gradients run as 3 split products
+                         # (f16x3), weight gradients as 6 (three-term bf16 split): (3 + 3 + 6) / 3 = 4 on average
+                         "achieved": 4.0 * step_flops * args.steps / elapsed / 1e12,
+                         "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 4.0 * step_flops * args.steps / elapsed / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                         "dense_equivalent_tflops": step_flops * args.steps / elapsed / 1e12,
+                         "dense_equivalent_frac_of_f32_matrix_peak": step_flops * args.steps / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": train_traffic, "traffic_source": train_traffic_src,
+                         "note": "achieved = issued split products per GPU: 3 x the forward's dense flops (SURVEY 8d: 34.6 GFLOP "
+                                 "per graph; forward + data-gradient + weight-gradient products) x 4 MFMA products per dense "
+                                 "product on average (f16x3: 3, bf16x6: 6) / wall time per step, priced against the f16 matrix "
+                                 "peak the products run on - an UPPER bound of what is issued (the message block's contraction "
+                                 "skips the Gaussian terms outside its k-window).  dense_equivalent_* is the reference's "
+                                 "arithmetic (f32) over the same time; it exceeds 1.0 of the f32 matrix peak because the split "
+                                 "products run on the 16x faster f16-rate cores.  Per kernel: profiles/r05_train_* (MfmaUtil, "
+                                 "HBM bytes)"},
         }
         if not emit:
             return out_line
@@ -793,8 +846,9 @@ def main_eqv2(args, rank, world, dev, emit=True):
         batch0 = batch0.to(dev)
     n_local = len(my_ids)
     total_systems = args.systems * world if args.scaling == "weak" else args.systems
+    # (`value`: full per-atom outputs, as in the PaiNN line; the default call is the `value_default_api` secondary)
     params = dict(num_steps=args.num_steps, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55,
-                  ode=True, early_stop=False)
+                  ode=True, early_stop=False, scores_on_adsorbate_only=False)
     eng = model.engine(dev)
     torch.manual_seed(0)
     placement = torch.rand(total_systems, 3)[torch.tensor(my_ids, dtype=torch.long)]
@@ -820,12 +874,13 @@ def main_eqv2(args, rank, world, dev, emit=True):
             Denoiser(b_, DiffTorchCalc(trainer), dict(params, num_steps=wsteps, placement_noise=placement), device=str(dev)).run()
         else:
             one_pass()
-    # secondary (one pass): the force blocks evaluated for the adsorbate atoms only (adf_eqv2_forward_subset)
+    # secondary (one pass): Denoiser.run() without options = the force blocks evaluated for the adsorbate atoms only
+    # inside the fused loop (adf_eqv2_forward_subset)
     sites_ads, ads_s = None, 0.0
     if not args.no_secondary:
         fence()
         t0 = time.perf_counter()
-        sites_ads = one_pass({"scores_on_adsorbate_only": True})
+        sites_ads = one_pass({"scores_on_adsorbate_only": None})
         fence()
         ads_s = time.perf_counter() - t0
     # secondary (one pass): every row of every block recomputed at every step, as the reference does
@@ -843,10 +898,17 @@ def main_eqv2(args, rank, world, dev, emit=True):
         sites = one_pass()
     fence()
     elapsed = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # every rank's own time over the timed passes (its clock stops when ITS last all_gather returned) and its GPU-busy
+        # time: the first real multi-GPU run then shows the curve and where its imbalance comes from in one line
+        busy = sum(v[0] for v in eng.profile_read().values() if isinstance(v, tuple))
+        t = torch.tensor([elapsed * 1e3 / args.steps, busy / args.steps, float(n_local), float(batch0.pos.shape[0])],
+                         dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [[round(float(v), 2) for v in a.tolist()] for a in allt]
+        elapsed = max(a[0] for a in rank_ms) * args.steps / 1e3
     prof = eng.profile_read()
     eng.profile_enable(False)
     c = eng.counters()
@@ -905,6 +967,10 @@ def main_eqv2(args, rank, world, dev, emit=True):
                 "parallelism": "systems sharded over %d GPU(s) by atom count, one all_gather of sites per pass" % world,
             },
             "sites_sha256_16": hashlib.sha256(torch.nan_to_num(sites).cpu().numpy().tobytes()).hexdigest()[:16],
+            "per_rank": None if rank_ms is None else {
+                "ms_per_step": [a[0] for a in rank_ms], "gpu_busy_ms_per_step": [a[1] for a in rank_ms],
+                "systems": [int(a[2]) for a in rank_ms], "atoms": [int(a[3]) for a in rank_ms],
+                "imbalance_max_over_mean": round(max(a[0] for a in rank_ms) / (sum(a[0] for a in rank_ms) / len(rank_ms)), 4)},
             "system_steps_per_s": total_systems * forwards / elapsed,
             "dense_tflops_f32_equivalent": c.dense_flops * forwards / elapsed / 1e12,
             "gpu_ms_per_pass": gpu_ms,
@@ -927,10 +993,11 @@ def main_eqv2(args, rank, world, dev, emit=True):
             "measured_peaks": measured,
         }
         if sites_ads is not None:
-            out["scores_on_adsorbate_only"] = {
+            out["value_default_api"] = {
                 "value": total_systems / ads_s, "unit": "sites/s", "identical_sites": bool(torch.equal(sites_ads, sites)),
-                "note": "opt-in denoising_pos_params['scores_on_adsorbate_only']: the two force blocks run for the tag-2 "
-                        "target atoms only (adf_eqv2_forward_subset); one pass, this rank's clock",
+                "note": "Denoiser(...).run() without options: inside the fused loop the two force blocks run for the tag-2 "
+                        "target atoms only (adf_eqv2_forward_subset; the per-atom outputs never leave the library); one "
+                        "pass, this rank's clock; `value` stays on the full-output path",
             }
         if sites_full is not None:
             out["incremental_layers_off"] = {

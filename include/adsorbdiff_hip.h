@@ -277,8 +277,10 @@ int32_t adf_measure_peaks(float* out_host3, void* stream);
  * writer thread takes them with adf_frames_wait (blocks up to timeout_ms; *host_ptr = NULL on time-out) and gives the slot
  * back with adf_frames_release; push blocks the enqueueing thread only while the slot it needs is still unreleased.
  * adf_sample_traj / adf_eqv2_sample_traj = adf_sample / adf_eqv2_sample that push a frame after every `frame_every`-th
- * applied step (and after the last one) without leaving the fused loop.  Not thread-safe per sink except
- * wait / release / pushed against push. */
+ * applied step (and after the last one) without leaving the fused loop.  adf_frames_abort cancels a sink: a push that is
+ * waiting for a slot (or any later push) returns ADF_EINVAL and every wait returns at once - the host writer calls it when
+ * it stops early (I/O error), so that the sampler reports the failure instead of blocking on a full ring.  Not thread-safe
+ * per sink except wait / release / pushed / abort against push. */
 typedef struct adf_frames* adf_frames_t;
 int32_t adf_frames_create(int32_t device, int64_t frame_floats, int32_t slots, adf_frames_t* out);
 int32_t adf_frames_destroy(adf_frames_t f);
@@ -286,6 +288,7 @@ int32_t adf_frames_push(adf_frames_t f, const float* src, void* stream);
 int32_t adf_frames_wait(adf_frames_t f, int64_t index, int32_t timeout_ms, const float** host_ptr);
 int32_t adf_frames_release(adf_frames_t f, int64_t index);
 int64_t adf_frames_pushed(adf_frames_t f);
+int32_t adf_frames_abort(adf_frames_t f);
 int32_t adf_sample_traj(adf_painn_t h, const adf_batch* b, float* pos, const int32_t* tags, const int32_t* fixed,
                         const adf_step_coef* coefs_dev, int32_t num_steps, const float* z_tr_all, const float* z_rot_all,
                         int32_t early_stop_count, int32_t poll_every, int32_t* state, const int32_t* out_idx,

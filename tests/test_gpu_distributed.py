@@ -100,6 +100,31 @@ def test_bench_launches_its_own_ranks(tmp_path, model):
     assert a["sites_sha256_16"] == b["sites_sha256_16"]
 
 
+def test_eight_ranks_share_the_benchmark_batch(tmp_path):
+    """BASELINE config 3 as far as one GPU can host it: `bench.py --gpus 8 --backend gloo` deals the REAL 1000-system batch
+    to eight ranks (125 systems each, all on cuda:0), every rank samples its shard, ONE all_gather merges the sites - and
+    the digest of the merged sites equals the one-rank run's.  The line carries each rank's wall and GPU-busy time and the
+    max/mean imbalance (what the first real 8-GPU run will need to explain its curve).  Three reverse steps, not fifty:
+    eight PROCESSES on one device take turns at kernel granularity (the full loop took 17 min this way against 5 s of GPU
+    work); the sharding, the placement noise keyed by system id and the gather are the same at any step count."""
+    def bench(n):
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--backend", "gloo", "--steps", "1", "--warmup", "0",
+               "--num-steps", "3", "--no-cpu-baseline", "--no-secondary"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return json.loads(res.stdout.strip().splitlines()[-1])
+
+    one, eight = bench(1), bench(8)
+    assert one["config"]["systems_total"] == eight["config"]["systems_total"] == 1000
+    assert eight["n_gpus"] == 8 and eight["config"]["systems_per_gpu"] == 125 and eight["scaling"] == "strong"
+    assert one["sites_sha256_16"] == eight["sites_sha256_16"]
+    pr = eight["per_rank"]
+    assert len(pr["ms_per_step"]) == 8 and pr["systems"] == [125] * 8 and sum(pr["atoms"]) == 200000
+    assert pr["imbalance_max_over_mean"] >= 1.0 and abs(max(pr["ms_per_step"]) - eight["ms_per_step"]) < 1.0
+    assert one["per_rank"] is None
+
+
 def test_bench_under_torch_distributed_run(tmp_path):
     """The driver's launch form: `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` (gloo here: two
     ranks share the one GPU of this box).  Rank 0 prints the JSON line; same sites as the self-launched run."""

@@ -457,7 +457,7 @@ def test_eqv2_config4_width_vs_reference_fixture(exact):
     normalisation unpinned): (f1, f2) at 1e-4, per atom against the largest atom, and the node embedding after the
     edge-degree embedding and after each of the 8 blocks per block and per degree (strided sample + norms over all
     atoms).  Both arithmetics; on the reference's edge list and on the device-built graph (no ties in this cell)."""
-    from tests.test_oracle_golden import cfg4_model_and_fixture, check_cfg4_blocks
+    from tests.helpers import cfg4_model_and_fixture, check_cfg4_blocks
 
     m, fx = cfg4_model_and_fixture()
     m = m.to(DEV)
@@ -485,7 +485,7 @@ def test_eqv2_config4_width_vs_oracle():
     """The same shape against oracle/eqv2_oracle.py evaluated here (≈15 s of CPU) on ANOTHER 200-atom system than the
     fixture's, on the device-built graph: outputs at 1e-4 (Frobenius and per atom against the largest atom)."""
     from oracle import eqv2_oracle as Q
-    from tests.test_oracle_golden import CFG4_ORACLE_HP, cfg4_model_and_fixture
+    from tests.helpers import CFG4_ORACLE_HP, cfg4_model_and_fixture
 
     m, _ = cfg4_model_and_fixture()
     b = safe_batch(1, 196, seed=23)

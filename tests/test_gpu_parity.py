@@ -914,21 +914,41 @@ def test_forward_subset_rows_are_bit_identical():
     assert torch.equal(sub1[idx2.long()], full1[idx2.long()]) and torch.equal(sub2[idx2.long()], full2[idx2.long()])
 
 
-def test_scores_on_adsorbate_only_gives_identical_samples():
-    """denoising_pos_params["scores_on_adsorbate_only"]: same sampled positions, bit for bit."""
+@pytest.mark.parametrize("case", ["ode", "sde", "early_stop", "trajectory_sink", "per_step"])
+def test_scores_on_adsorbate_only_gives_identical_samples(tmp_path, case):
+    """denoising_pos_params["scores_on_adsorbate_only"] (the DEFAULT inside the fused loop since round 5): the sampled
+    positions equal the full-output run's bit for bit - ODE, SDE (same device noise stream), under the reference's early
+    stop, with the per-step trajectory sink (identical files), and on the per-step host path; and a run WITHOUT the key
+    equals both (whichever form the default picks)."""
     from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
     from adsorbdiff_amd.trainer import DenoisingTrainer
 
-    fx = load_npz("stepper_ode8.npz")
+    fx = load_npz("stepper_ode_early.npz" if case == "early_stop" else "stepper_ode8.npz")
     tr = DenoisingTrainer(_stepper_model(fx), device=DEV)
-    outs = []
-    for flag in (False, True):
+    outs, steps = [], []
+    for flag in (False, True, None):
         b = batch_from_fixture(fx, pos_key="pos_in")
         torch.manual_seed(int(fx["seed"]))
-        den = Denoiser(b, DiffTorchCalc(tr), dict(_params(fx), scores_on_adsorbate_only=flag), device=DEV)
+        torch.cuda.manual_seed(4321)
+        params = dict(_params(fx))
+        if case == "sde":
+            params.update(ode=False)
+        if case != "early_stop":
+            params.update(early_stop=False)
+        if case == "per_step":
+            params.update(step_hook=lambda t: None)
+        if flag is not None:
+            params.update(scores_on_adsorbate_only=flag)
+        kw = dict(traj_dir=tmp_path / str(flag), traj_names=b.sid) if case == "trajectory_sink" else {}
+        den = Denoiser(b, DiffTorchCalc(tr), params, device=DEV, **kw)
         outs.append(den.run().pos.clone())
-        assert den.steps_applied == 8
-    assert torch.equal(outs[0], outs[1])
+        steps.append(den.steps_applied)
+    assert steps[0] == steps[1] == steps[2] and (case == "early_stop" or steps[0] == 8)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    if case == "trajectory_sink":
+        for sid in batch_from_fixture(fx, pos_key="pos_in").sid:
+            a, c = np.load(tmp_path / "False" / f"{sid}.npz"), np.load(tmp_path / "None" / f"{sid}.npz")
+            assert np.array_equal(a["positions"], c["positions"]) and a["positions"].shape[0] == 8
 
 
 @pytest.mark.parametrize("ode", [True, False])

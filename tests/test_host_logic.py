@@ -404,6 +404,86 @@ def test_trajectory_writer_thread_streams_trims_and_renames(tmp_path):
     assert np.load(tmp_path / "last" / "b_2.npz")["positions"].shape == (1, 3, 3)
 
 
+def test_trajectory_writer_abort_publishes_nothing_and_writer_death_wakes_the_producer(tmp_path):
+    """(1) a failed sampling attempt aborts the writer - no <sid>.npz, no batch file, no temporary file remains, so
+    the resume rule (check_traj_files) does not count the batch as done; (2) a writer that dies (here: its directory cannot
+    be created) aborts its frame source, so the producer's push returns instead of waiting for ring slots forever."""
+    import threading
+
+    from adsorbdiff_amd.trainer import check_traj_files
+    from adsorbdiff_amd.trajectory import TrajectoryWriter
+
+    rng = np.random.default_rng(2)
+    natoms = [4, 2]
+    N = sum(natoms)
+    frames = rng.normal(size=(6, N, 3)).astype(np.float32)
+    meta = dict(numbers=rng.integers(1, 80, N), tags=rng.integers(0, 3, N), fixed=rng.integers(0, 2, N),
+                cell=rng.normal(size=(2, 3, 3)).astype(np.float32), natoms=np.array(natoms), names=["x_1", "y_2"])
+
+    class AbortableSource(_FakeFrameSource):
+        aborted = False
+
+        def abort(self):
+            with self.cv:
+                self.aborted = True
+                self.cv.notify_all()
+
+        def push(self):
+            with self.cv:
+                self.cv.wait_for(lambda: self.aborted or self.avail < self.slots or (self.avail - self.slots) in self.released,
+                                 timeout=10)
+                if self.aborted:
+                    raise RuntimeError("ring aborted")
+                self.avail += 1
+                self.cv.notify_all()
+
+    # (1) abort after three frames were streamed
+    src = AbortableSource(frames)
+    w = TrajectoryWriter(src, tmp_path / "a", meta, max_frames=6)
+    w.start()
+    for _ in range(3):
+        src.push()
+    w.abort()
+    w.join_checked(10)
+    assert not list((tmp_path / "a").glob("*")), list((tmp_path / "a").glob("*"))
+
+    class B:
+        sid = meta["names"]
+
+    assert not check_traj_files(B, tmp_path / "a")
+    assert src.aborted
+    # a finished run with zero counted frames publishes nothing either
+    src0 = AbortableSource(frames)
+    w0 = TrajectoryWriter(src0, tmp_path / "z", meta, max_frames=6)
+    w0.start()
+    w0.finish(0)
+    w0.join_checked(10)
+    assert not list((tmp_path / "z").glob("*.npz"))
+
+    # (2) the writer dies at once (its "directory" is a file): the producer must not hang on the 3-slot ring
+    blocker = tmp_path / "file"
+    blocker.write_text("not a directory")
+    src2 = AbortableSource(frames)
+    w2 = TrajectoryWriter(src2, blocker / "sub", meta, max_frames=6)
+    w2.start()
+    err = []
+
+    def produce():
+        try:
+            for _ in range(6):
+                src2.push()
+        except RuntimeError as e:
+            err.append(e)
+
+    t = threading.Thread(target=produce)
+    t.start()
+    t.join(10)
+    assert not t.is_alive(), "producer still blocked after the writer died"
+    assert err and src2.aborted
+    with pytest.raises(OSError):
+        w2.join_checked(10)
+
+
 def test_npz_to_ase_traj_converter(tmp_path):
     """The sink's format is .npz (ase is not installable in the build image); where ase IS importable the converter must
     reproduce the reference's <sid>.traj content (relaxation/ase_utils.py:19-48)."""

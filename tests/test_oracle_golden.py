@@ -6,7 +6,8 @@ import pytest
 import torch
 
 from oracle import painn_oracle as O
-from tests.helpers import batch_from_fixture, load_npz, rel_err, state_dict_from_fixture
+from tests.helpers import (CFG4_ORACLE_HP, batch_from_fixture, cfg4_model_and_fixture, load_npz, rel_err,
+                           state_dict_from_fixture)
 
 torch.set_num_threads(4)
 
@@ -266,49 +267,6 @@ def test_eqv2_oracle_vs_reference_fixture(name, lmax):
     assert float((D @ D.transpose(1, 2) - eye).abs().max()) < 1e-5
     D01 = Q.wigner_from_rotation(lmax, R[:1] @ R[1:2])
     assert float((D01 - D[:1] @ D[1:2]).abs().max()) < 1e-5
-
-
-CFG4_KW = dict(max_neighbors=20, max_radius=12.0, max_num_elements=90, num_layers=8, sphere_channels=128,
-               attn_hidden_channels=64, num_heads=8, attn_alpha_channels=64, attn_value_channels=16,
-               ffn_hidden_channels=128, norm_type="layer_norm_sh", lmax_list=[6], mmax_list=[2], grid_resolution=18,
-               edge_channels=128, attn_activation="silu", ffn_activation="silu", use_grid_mlp=True, use_sep_s2_act=True,
-               alpha_drop=0.0, drop_path_rate=0.0, weight_init="uniform", FOR_denoising=True)
-CFG4_ORACLE_HP = dict(lmax=6, mmax=2, num_layers=8, sphere_channels=128, attn_hidden_channels=64, num_heads=8,
-                      attn_alpha_channels=64, attn_value_channels=16, ffn_hidden_channels=128, grid_resolution=18,
-                      max_radius=12.0, max_neighbors=20)
-
-
-def cfg4_model_and_fixture():
-    """The mirror class at the BASELINE config-4 width with the fixture's weights (rebuilt from parameter names, not
-    stored: tests/helpers.py::refill_parameters_by_name — oracle/make_golden.py asserts the reference model holds the
-    same values)."""
-    from adsorbdiff_amd.equiformer_v2_denoising import EquiformerV2S_OC20_DenoisingPos
-    from tests.helpers import refill_parameters_by_name
-
-    fx = load_npz("eqv2_cfg4.npz")
-    torch.manual_seed(0)
-    m = refill_parameters_by_name(EquiformerV2S_OC20_DenoisingPos(None, None, None, **CFG4_KW).eval(), float(fx["emb_scale"]))
-    assert sum(p.numel() for p in m.parameters()) == int(fx["n_params"])
-    return m, fx
-
-
-def check_cfg4_blocks(xb, fx, tol):
-    """xb [9, N, 49, 128] (after the edge-degree embedding and after each of the 8 blocks) against the fixture's strided
-    sample, per block and per degree, and against the reference's per-degree norms over ALL atoms and channels."""
-    sa, sc = int(fx["atom_stride"]), int(fx["channel_stride"])
-    xb = torch.as_tensor(xb).float().cpu()
-    ref = torch.from_numpy(fx["x_blocks_sample"])
-    got = xb[:, ::sa, :, ::sc]
-    assert got.shape == ref.shape, (got.shape, ref.shape)
-    worst = 0.0
-    for k in range(ref.shape[0]):
-        for l in range(7):
-            e = rel_err(got[k, :, l * l:(l + 1) ** 2], ref[k, :, l * l:(l + 1) ** 2])
-            worst = max(worst, e)
-            assert e < tol, (k, l, e)
-            n = float(xb[k, :, l * l:(l + 1) ** 2].double().norm())
-            assert abs(n - float(fx["x_blocks_degree_norms"][k, l])) < tol * float(fx["x_blocks_degree_norms"][k, l]), (k, l)
-    return worst
 
 
 def test_eqv2_oracle_at_config4_width_vs_reference_fixture():
