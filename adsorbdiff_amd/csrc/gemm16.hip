@@ -27,6 +27,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
+#ifndef EPI_ABL
+#define EPI_ABL 0   // timing experiments only (wrong results): bit 0 = EPI 1 without its epilogue, bit 1 = EPI 2 without,
+                    // bit 2 = EPI 1/2 without their global loads, bit 3 = without their global stores
+#endif
 #define HK 32
 // Row strides (floats) of the epilogues' transposition buffers.  Unpadded on purpose: with the lane groups of
 // ds_read_b128 ({0-3,12-15,20-27}, ...) a stride of 96 (= 32 mod 64 banks) resp. 64 puts the four rows a group
@@ -370,6 +374,12 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         // that every lane then owns 4 consecutive channels of one row: 16-B global accesses, 8 rows x
         // 128 B per wave instruction instead of 2 rows x 128 B.
         static_assert(EPI >= 3 || (NJ == 3 && MI == 2), "fused epilogues are written for the 64 x 96 wave tile");
+        if (((EPI_ABL & 1) && EPI == 1) || ((EPI_ABL & 2) && EPI == 2)) {   // keep the accumulators alive, store nothing
+            float sacc = 0.f;
+            for (int i = 0; i < MI; ++i) for (int j = 0; j < NJ; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+            if (ep.H < 0) ep.x[0] = sacc;
+            return;
+        }
         const int q = lane & 31;
         const int g = (n0 + wn) / 96;
         const int H = ep.H;
@@ -395,7 +405,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             const int c = 32 * g + 4 * c4;
             if constexpr (EPI == 1) {
                 float4 v0[4], v1[4], v2[4];
-                if (!ep.vec_is_zero) {
+                if (EPI_ABL & 4) { for (int it = 0; it < 4; ++it) { v0[it] = make_float4(1.f, 2.f, 3.f, 4.f); v1[it] = v0[it]; v2[it] = v0[it]; } }
+                else if (!ep.vec_is_zero) {
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int n = min(m0 + wm + 32 * i + it * 8 + (lane >> 3), M - 1);
@@ -412,7 +423,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                     const float4 p0 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 4 * c4);
                     const float4 p1 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 32 + 4 * c4);
                     const float4 p2 = *reinterpret_cast<const float4*>(T + lr * TLD3 + 64 + 4 * c4);
-                    if (n < M) {
+                    if ((EPI_ABL & 8) && n >= 0) { if (ep.H < 0) ep.rec[0] = p0.x + p1.x + p2.x + v0[it].x + v1[it].y + v2[it].z; }
+                    else if (n < M) {
                         // half-record of (atom n, group g): [32 x (P0, P1, P2, xa)] then [32 x xc]
                         float* rec = ep.rec + ((size_t)(ep.row_map ? ep.row_map[n] : n) * (H / 32) + g) * 160;
                         float4* ra_ = reinterpret_cast<float4*>(rec + 16 * c4);

@@ -61,13 +61,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-#define MSG_WAVES_PER_SIMD 2
+// Geometry of THIS kernel (message_bwd.hip keeps message.h's 8 waves): FWD_WAVES waves per workgroup share the slice's weight
+// image; FWD_AHEAD = gather rows requested ahead of the row being consumed (4: 80 landing registers, 2: 40).
+#ifndef FWD_WAVES
+#define FWD_WAVES 8
+#endif
+#ifndef FWD_AHEAD
+#define FWD_AHEAD 4
+#endif
+#define FWD_THREADS (64 * FWD_WAVES)
+#define MSG_WAVES_PER_SIMD (FWD_WAVES / 4)
 // VZ = true: vec is identically zero on entry (first layer, painn_denoising.py:426) — its gathers,
 // the vec*b sums and the residual read are skipped.
 // UNI: the Gaussian centres are equally spaced (GaussianSmearing's linspace, radial_basis.py:64-82; checked by the host):
 // the 8 basis values of a lane and k-step then follow from two exp2 by a multiplicative recurrence (see below).
 template <bool F16, bool VZ, bool UNI>
-__global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_kernel(MsgParams p) {
+__global__ __launch_bounds__(FWD_THREADS, MSG_WAVES_PER_SIMD) void adf_message_kernel(MsgParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // carve: weight image | [192] bias | [128] mu | [8 waves][32][8] row meta | work counter
     const int wfloats = F16 ? (2 * MSG_COLS * MSG_LDK) / 2 : p.R * MSG_COLS;
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
     float* Bl = lds + wfloats;
     float* Mu = Bl + MSG_COLS;
     float* Meta = Mu + 144;  // 16-entry tail: the operand generated one step ahead may read past the last centre
-    int* Ctr = reinterpret_cast<int*>(Meta + MSG_WAVES * 32 * 8);
+    int* Ctr = reinterpret_cast<int*>(Meta + FWD_WAVES * 32 * 8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             // k slots 128/129 of the hi image (the row padding) hold the bias as an fp16 hi/lo pair: the
             // accumulators are initialised by one MFMA against a constant A instead of 96 v_mov per block
             const _Float16* b16 = reinterpret_cast<const _Float16*>(p.bpack) + (size_t)slice * MSG_COLS * 2;
-            for (int i = tid; i < 2 * MSG_COLS * 17; i += MSG_THREADS) {
+            for (int i = tid; i < 2 * MSG_COLS * 17; i += FWD_THREADS) {
                 const int row = i / 17, piece = i - row * 17;  // row in [0, 384): hi rows then lo rows
                 half8 v = piece < R8 ? src[row * R8 + piece] : zero8;
                 if (piece == 16 && row < MSG_COLS) { v[0] = b16[2 * row]; v[1] = b16[2 * row + 1]; }
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             const float4* src = reinterpret_cast<const float4*>(p.wpack + (size_t)slice * p.R * MSG_COLS);
             float4* dst = reinterpret_cast<float4*>(Wl);
             const int n4 = p.R * MSG_COLS / 4;
-            for (int i = tid; i < n4; i += MSG_THREADS) dst[i] = src[i];
+            for (int i = tid; i < n4; i += FWD_THREADS) dst[i] = src[i];
         }
         if (!F16 && tid < MSG_COLS) Bl[tid] = p.bpack[slice * MSG_COLS + tid];
         // f16 mode: centres pre-multiplied by sqrt(-coeff*log2 e), so that a Gaussian is exp2(-(xs' - mu')^2)
@@ -285,7 +294,10 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
             DECL(0) DECL(1) DECL(2) DECL(3) DECL(4) DECL(5) DECL(6) DECL(7)
             DECL(8) DECL(9) DECL(10) DECL(11) DECL(12) DECL(13) DECL(14) DECL(15)
             // rows 0-3: issued before the MFMA loop, they land while the matrix pipe is busy
-            GATHER(0) GATHER(1) GATHER(2) GATHER(3)
+            GATHER(0) GATHER(1)
+#if FWD_AHEAD == 4
+            GATHER(2) GATHER(3)
+#endif
 
             const float env256 = env * 256.0f;
             f32x16 acc[6];
@@ -396,6 +408,26 @@ __global__ __launch_bounds__(MSG_THREADS, MSG_WAVES_PER_SIMD) void adf_message_k
 #pragma unroll
             for (int b = 0; b < 6; ++b) asm volatile("" :: "v"(acc[b]));
             sx0 += m0[1];
+#elif FWD_AHEAD == 2
+            GATHER(2) GATHER(3)
+            CONSUME(0) CONSUME(1)
+            GATHER(4) GATHER(5)
+            CONSUME(2) CONSUME(3)
+            GATHER(6) GATHER(7)
+            CONSUME(4) CONSUME(5)
+            if (nvalid <= 16) {
+                CONSUME(6) CONSUME(7)
+            } else {
+                GATHER(8) GATHER(9)
+                CONSUME(6) CONSUME(7)
+                GATHER(10) GATHER(11)
+                CONSUME(8) CONSUME(9)
+                GATHER(12) GATHER(13)
+                CONSUME(10) CONSUME(11)
+                GATHER(14) GATHER(15)
+                CONSUME(12) CONSUME(13)
+                CONSUME(14) CONSUME(15)
+            }
 #elif MSG_SKIP
             // accumulator rows 4g..4g+3 of a lane are block rows 8g..8g+7: a block with nvalid rows has nothing but padding
             // beyond group (nvalid-1)/8 - its gathers (of the zero record) and sums are skipped (wave-uniform branches; about
@@ -562,7 +594,7 @@ int32_t adf_pack_records(adf_painn* h, int N, const float* xh, const float* vec,
 
 static size_t msg_lds_bytes(int R, bool f16) {
     const size_t w = f16 ? (size_t)2 * MSG_COLS * MSG_LDK * 2 : sizeof(float) * (size_t)R * MSG_COLS;
-    return w + sizeof(float) * (MSG_COLS + 144 + MSG_WAVES * 32 * 8) + 16;
+    return w + sizeof(float) * (MSG_COLS + 144 + FWD_WAVES * 32 * 8) + 16;
 }
 
 // The message kernel's images of ONE layer's rbf_proj (f32 image, fp16 hi/lo image, bias images, scale) from the weight
@@ -648,7 +680,7 @@ int32_t adf_message_impl(adf_painn* h, int layer, int N, const float* x, const f
     if (workers > p.G) workers = p.G;
     dim3 grid((unsigned)(workers * p.nslices));
 #define LAUNCH_MSG(F16_, VZ_, UNI_)                                                                        \
-    hipLaunchKernelGGL((adf_message_kernel<F16_, VZ_, UNI_>), grid, dim3(MSG_THREADS), msg_lds_bytes(R, F16_), s, p)
+    hipLaunchKernelGGL((adf_message_kernel<F16_, VZ_, UNI_>), grid, dim3(FWD_THREADS), msg_lds_bytes(R, F16_), s, p)
     {   // scaled spacing of the (equally spaced) centres: mu_k = k / (R - 1)
         const double d = sqrt(0.5 / (step * step) * 1.4426950408889634) * step;
         p.dmu2 = (float)(2.0 * d); p.dmusq = (float)(d * d); p.cstep = (float)exp2(-2.0 * d * d);

@@ -20,4 +20,4 @@ eng.profile_enable(True)
 for _ in range(5): eng.message_layer(1, x, vec)
 torch.cuda.synchronize()
 pr = eng.profile_read()
-print(os.environ.get("ADF_LIB_PATH", "default")[-14:], os.environ.get("ADF_MSG_KERNEL", "v3"), "message ms", round(pr["message"][0] / pr["message"][1], 3))
+print(os.environ.get("ADF_LIB_PATH", "default")[-14:], "message ms", round(pr["message"][0] / pr["message"][1], 3))

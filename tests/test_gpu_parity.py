@@ -815,23 +815,35 @@ def test_hub_atom_with_many_incoming_edges():
 
 
 def test_calculator_single_structure_api():
-    """AdsorbDiffCalculator.run_diffusion on one structure == Denoiser on the same system and seed."""
+    """AdsorbDiffCalculator.run_diffusion on one structure against the CPU oracle's reverse loop on the same system with the
+    same placement noise (the calculator seeds torch's CPU generator, the Denoiser draws torch.rand(1, 3) from it -
+    reference calculator.py:180-210, denoising_torch.py:215): final positions within 2e-4 A over the 8 well-conditioned
+    steps of the fixture's schedule; tags and atom order preserved."""
     from adsorbdiff_amd.calculator import AdsorbDiffCalculator, SimpleAtoms
+    from adsorbdiff_amd.data import Batch
+    from oracle import painn_oracle as O
 
     fx = load_npz("stepper_ode8.npz")
-    params = _params(fx)
+    params = dict(_params(fx), early_stop=False)
     b = batch_from_fixture(fx, pos_key="pos_in")
     one = b.to_data_list()[0]
     atoms = SimpleAtoms(one.atomic_numbers.long().numpy(), one.pos.numpy(), one.cell[0].numpy(), one.tags.numpy(),
                         one.fixed.numpy())
-    calc = AdsorbDiffCalculator(_stepper_model(fx), params, device=DEV, seed=11)
+    model = _stepper_model(fx)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    calc = AdsorbDiffCalculator(model, params, device=DEV, seed=11)
     out = calc.run_diffusion(atoms)
-    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
-    from adsorbdiff_amd.data import Batch
-
+    ob = Batch.from_data_list([one])
     torch.manual_seed(11)
-    ref = Denoiser(Batch.from_data_list([one]), DiffTorchCalc(calc.trainer), params, device=DEV).run()
-    np.testing.assert_allclose(out.get_positions(), ref.pos.cpu().numpy(), rtol=0, atol=1e-6)
+    noise = torch.rand(1, 3)   # what the Denoiser drew after the calculator's torch.manual_seed(11)
+
+    def fn(p):
+        return O.painn_forward(sd, p, ob.atomic_numbers, ob.cell, ob.natoms, scale_factors=[1.05, 0.9], **STEP_HP)
+
+    want = O.reverse_sde_sampling_rot(ob.pos.clone(), ob.cell, ob.tags, ob.batch, ob.fixed, fn, params, noise)
+    moved = float((want - ob.pos).abs().max())
+    assert moved > 0.5, moved   # the adsorbate was placed and stepped, not left where it was
+    np.testing.assert_allclose(out.get_positions(), want.numpy(), rtol=0, atol=2e-4)
     assert (out.get_tags() == one.tags.numpy()).all()
 
 
