@@ -146,24 +146,39 @@ def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=
         meta = all_gather(torch.tensor([local.shape[0], local.shape[1]], dtype=torch.int64, device=dev)).cpu()
         bounds = (int(meta[:, 0].max()), int(meta[:, 1].max()))
     Bmax, Amax = int(bounds[0]), int(bounds[1])
+    packed = pack_sites(local, system_ids, (Bmax, Amax))
+    everything = all_gather(packed.contiguous())                       # the one exchange: [world, B_max, 1 + 3 A_max]
+    return merge_packed_sites(everything, Amax, ordered=system_ids is not None).to(local.dtype)
+
+
+def pack_sites(local: torch.Tensor, system_ids, bounds) -> torch.Tensor:
+    """One rank's message of the exchange: ``[B_max, 1 + 3 A_max]`` INT32 words - the system id as it is (-1 = padding row)
+    and the sites as their float32 bit patterns (a float -> int reinterpretation is lossless on every copy path, whereas ids
+    stored as float bits would be denormals / NaN payloads that a flush-to-zero or NaN-canonicalising copy could alter);
+    padding sites are NaN bit patterns."""
+    Bmax, Amax = int(bounds[0]), int(bounds[1])
+    dev = local.device
     if local.shape[0] > Bmax or local.shape[1] > Amax:
         raise ValueError(f"gather_sites: local sites {tuple(local.shape)} exceed the bounds {(Bmax, Amax)}")
     ids = torch.arange(local.shape[0], dtype=torch.int32) if system_ids is None else torch.as_tensor(system_ids, dtype=torch.int32)
     if ids.numel() != local.shape[0]:
         raise ValueError("every rank must pass one id per local system")
-    # The exchange buffer is INT32: ids as they are (-1 = padding), sites as their float32 bit patterns (a float -> int
-    # reinterpretation is lossless on every copy path, whereas ids stored as float bits would be denormals / NaN payloads
-    # that a flush-to-zero or NaN-canonicalising copy could alter).  Padding sites are NaN bit patterns.
     nan_bits = int(torch.tensor([float("nan")], dtype=torch.float32).view(torch.int32)[0])
     packed = torch.full((Bmax, 1 + 3 * Amax), nan_bits, dtype=torch.int32, device=dev)
     packed[:, 0] = -1
     packed[: local.shape[0], 0] = ids.to(dev)
     packed[: local.shape[0], 1 : 1 + 3 * local.shape[1]] = (
         local.reshape(local.shape[0], -1).to(torch.float32).contiguous().view(torch.int32))
-    everything = all_gather(packed.contiguous())                       # the one exchange: [world, B_max, 1 + 3 A_max]
+    return packed
+
+
+def merge_packed_sites(everything: torch.Tensor, Amax: int, ordered: bool = True) -> torch.Tensor:
+    """All ranks' messages ``[world, B_max, 1 + 3 A_max]`` -> sites ``[B, A_max, 3]`` (float32), in global system order when
+    the ranks sent global ids (``ordered``), rank-major otherwise."""
+    world, Bmax = everything.shape[0], everything.shape[1]
     gid = everything[:, :, 0]
     keep = gid >= 0
-    sites = everything[:, :, 1:].contiguous().view(torch.float32).reshape(world, Bmax, Amax, 3)[keep].to(local.dtype)
-    if system_ids is None:
+    sites = everything[:, :, 1:].contiguous().view(torch.float32).reshape(world, Bmax, Amax, 3)[keep]
+    if not ordered:
         return sites                                                   # rank-major
     return sites[torch.argsort(gid[keep].to(torch.int64))]
