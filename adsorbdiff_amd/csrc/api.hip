@@ -18,7 +18,7 @@ void adf_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* adf_last_error(void) { return g_err; }
-extern "C" const char* adf_version(void) { return "adsorbdiff_hip 0.4.0 (gfx950)"; }
+extern "C" const char* adf_version(void) { return "adsorbdiff_hip 0.5.0 (gfx950)"; }
 
 // ---- HIP-event profiling: pairs of events on the launch stream around kernel groups
 void adf_prof_begin(adf_painn* h, int cat, hipStream_t s) {
