@@ -423,14 +423,18 @@ def main():
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         one_pass({"scores_on_adsorbate_only": None})   # untimed: back to incremental layers (kept state re-allocated)
+        eng.profile_enable(True)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for _ in range(2):
             sites_ads = one_pass({"scores_on_adsorbate_only": None})
         torch.cuda.synchronize(dev)
         dt = (time.perf_counter() - t1) / 2
+        prof_ads = eng.profile_read()
+        eng.profile_enable(False)
         ads_only = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
                     "identical_sites": bool(torch.equal(sites_ads, sites)),
+                    "gpu_ms_per_pass": {k: round(v[0] / 2, 2) for k, v in prof_ads.items() if isinstance(v, tuple)},
                     "note": "Denoiser(...).run() WITHOUT options, as a caller of the reference's API invokes it: inside the fused "
                             "loop (adf_sample / adf_sample_traj) the per-atom model outputs never leave the library, so since "
                             "round 5 the last layer's message targets, its update and the heads are evaluated for the tag-2 "
@@ -638,9 +642,11 @@ def main():
                         "the k-window skips Gaussian terms below 1.5e-8 of the leading one. Timed on the "
                         "launch stream; measured_peak = the same MFMA instruction in a register-resident loop on this "
                         "box (non-zero operands). rbfh is never materialised, so neither SURVEY 8d roofline binds alone: "
-                        "per 32-edge block the kernel issues ~600 VALU instructions (8 FMA per gathered channel-row) "
-                        "beside ~64 MFMAs and 10 KB/edge of L2-served record gathers (l2_gather_tbps; the same access "
-                        "pattern alone sustains ~28 TB/s) - see DESIGN.md 4.",
+                        "per 32-edge block the kernel issues ~560 vector instructions (8 FMA per gathered channel-row) "
+                        "beside ~54 MFMAs and 10 KB/edge of L2-served record gathers (l2_gather_tbps); on gfx950 the "
+                        "matrix-pipe time and the vector-issue time of the two waves of a SIMD ADD "
+                        "(profiles/r05_mfma_valu_overlap.txt), which puts this formulation's floor at ~0.42 of nominal - "
+                        "see DESIGN.md 4.",
             },
             "measured_peaks": measured,
             "recomputed_row_fraction_per_step": row_frac or None,  # warm-up pass: layer x atom rows recomputed / all rows
