@@ -1,8 +1,8 @@
-// RETIRED EXPERIMENT (round 5; not part of the build).  Measured 8.0 ms per full launch against message.hip's 6.9 (1.81 vs
-// 1.55 at 200 systems): placing the gathers and sums between the MFMAs couples the matrix pipe to the gathers' latency - an
+// RETIRED EXPERIMENT (round 5; not part of the build).  Measured 7.76 ms per full launch against message.hip's 6.92 (1.72 vs
+// 1.52 at 200 systems; 8.0 ms before the B fragments were requested one slot ahead and the unit vectors carried in registers): placing the gathers and sums between the MFMAs couples the matrix pipe to the gathers' latency - an
 // in-order wave that waits for a record cannot issue its next MFMA - which costs more than the in-wave overlap returns (the
-// overlap microbenchmark hides register-resident FMAs only).  A first bit-identity test against message.hip also failed and
-// was not debugged.  To rebuild: copy into adsorbdiff_amd/csrc/, add to build.SOURCES, declare adf_message_il_prepare /
+// overlap microbenchmark hides register-resident FMAs only).  Its outputs agree with message.hip's to 1e-6, not bit for bit (not
+// debugged).  To rebuild: copy into adsorbdiff_amd/csrc/, add to build.SOURCES, declare adf_message_il_prepare /
 // adf_message_il_launch in message.h and call them from message.hip (git history of round 5).
 //
 // PaiNN message block, the kernel of message.hip with the sums of one channel half placed BETWEEN the MFMAs of the other
@@ -143,31 +143,32 @@ __global__ __launch_bounds__(IL_THREADS, 2) void adf_message_il_kernel(MsgParams
 
 #define ROW_OF(r) ((r & 3) + 8 * (r >> 2) + 4 * hi)
     // one half-row of gathered record: (P0, P1, P2, xa) + xc of channel c0 + 32 j + q
-#define DECLH(h, r) float4 g##h##a##r; float g##h##z##r;
+#define DECLH(h, r) float4 g##h##a##r; float g##h##z##r; float u##h##x##r, u##h##y##r, u##h##z##r;
+    // gather of one half-row: ONE 16-byte LDS read brings the record offset and the unit vector of the row (kept in
+    // registers until the row is summed: an LDS round trip in front of the sums would sit in an MFMA's shadow and hold the
+    // next MFMA back)
 #define GATHERH(h, J, MP, r)                                                                              \
     {                                                                                                     \
-        const unsigned int o_ = __float_as_uint((MP)[ROW_OF(r) * 8]);                                     \
+        const float4 mm_ = *reinterpret_cast<const float4*>((MP) + ROW_OF(r) * 8);                        \
+        const unsigned int o_ = __float_as_uint(mm_.x);                                                   \
+        u##h##x##r = mm_.y; u##h##y##r = mm_.z; u##h##z##r = mm_.w;                                       \
         g##h##z##r = *reinterpret_cast<const float*>(recS + (size_t)(o_ + qP) + 640 * (J));              \
         if (!VZ) g##h##a##r = *reinterpret_cast<const float4*>(recS + (size_t)(o_ + qA) + 640 * (J));    \
         else g##h##a##r = make_float4(0.f, 0.f, 0.f, *reinterpret_cast<const float*>(recS + (size_t)(o_ + qA) + 640 * (J) + 12)); \
     }
 #define CONSUMEX(MP, r)                                                                                   \
     {                                                                                                     \
-        const float* m_ = (MP) + ROW_OF(r) * 8;                                                           \
-        const float ux = m_[1]; const float uy = m_[2]; const float uz = m_[3];                           \
         const float t3 = gxz##r * acc[4][r];                                                              \
         sx0 += gxa##r.w * acc[0][r];                                                                      \
         if (!VZ) { sa0 += gxa##r.x * acc[2][r]; sb0 += gxa##r.y * acc[2][r]; sc0 += gxa##r.z * acc[2][r]; } \
-        ra0 += t3 * ux; rb0 += t3 * uy; rc0 += t3 * uz;                                                   \
+        ra0 += t3 * uxx##r; rb0 += t3 * uxy##r; rc0 += t3 * uxz##r;                                       \
     }
 #define CONSUMEY(MP, r)                                                                                   \
     {                                                                                                     \
-        const float* m_ = (MP) + ROW_OF(r) * 8;                                                           \
-        const float ux = m_[1]; const float uy = m_[2]; const float uz = m_[3];                           \
         const float u3 = gyz##r * acc[5][r];                                                              \
         sx1 += gya##r.w * acc[1][r];                                                                      \
         if (!VZ) { sa1 += gya##r.x * acc[3][r]; sb1 += gya##r.y * acc[3][r]; sc1 += gya##r.z * acc[3][r]; } \
-        ra1 += u3 * ux; rb1 += u3 * uy; rc1 += u3 * uz;                                                   \
+        ra1 += u3 * uyx##r; rb1 += u3 * uyy##r; rc1 += u3 * uyz##r;                                       \
     }
     DECLH(x, 0) DECLH(x, 1) DECLH(x, 2) DECLH(x, 3) DECLH(x, 4) DECLH(x, 5) DECLH(x, 6) DECLH(x, 7)
     DECLH(x, 8) DECLH(x, 9) DECLH(x, 10) DECLH(x, 11) DECLH(x, 12) DECLH(x, 13) DECLH(x, 14) DECLH(x, 15)
@@ -263,21 +264,24 @@ __global__ __launch_bounds__(IL_THREADS, 2) void adf_message_il_kernel(MsgParams
         // A slot = the three products of column block B_ at halves offset KO_ of the window, with gathers (G_) and the sums
         // of up to three rows (C0_, C1_, C2_) of the other half between them.  No branch inside a phase: hipcc's waitcnt
         // pass counts the outstanding gathers exactly only in straight-line code.
-#define SLOT(B_, AH_, AL_, KO_, G_, C0_, C1_, C2_)                                                        \
+#define LOADB(BH_, BL_, B_, KO_)                                                                          \
+        BH_ = *reinterpret_cast<const half8*>(whq + (B_) * 32 * MSG_LDK + (KO_));                         \
+        BL_ = *reinterpret_cast<const half8*>(wlq + (B_) * 32 * MSG_LDK + (KO_));
+        // BH_/BL_: this slot's fragments (requested by the previous slot); NB_: statement that requests the next slot's
+#define SLOT(B_, AH_, AL_, BH_, BL_, NB_, G_, C0_, C1_, C2_)                                              \
         {                                                                                                  \
-            const half8 bh_ = *reinterpret_cast<const half8*>(whq + (B_) * 32 * MSG_LDK + (KO_));         \
-            const half8 bl_ = *reinterpret_cast<const half8*>(wlq + (B_) * 32 * MSG_LDK + (KO_));         \
-            acc[B_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL_, bh_, acc[B_], 0, 0, 0);                  \
+            NB_                                                                                            \
+            acc[B_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL_, BH_, acc[B_], 0, 0, 0);                  \
             G_ __builtin_amdgcn_sched_barrier(0);                                                          \
-            acc[B_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH_, bl_, acc[B_], 0, 0, 0);                  \
+            acc[B_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH_, BL_, acc[B_], 0, 0, 0);                  \
             C0_ __builtin_amdgcn_sched_barrier(0);                                                         \
-            acc[B_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH_, bh_, acc[B_], 0, 0, 0);                  \
+            acc[B_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH_, BH_, acc[B_], 0, 0, 0);                  \
             C1_ C2_ __builtin_amdgcn_sched_barrier(0);                                                     \
         }
         // the same slot without MFMAs (vec == 0: the xb columns multiply P = 0)
 #define NOSLOT(G_, C0_, C1_, C2_) { G_ C0_ C1_ C2_ }
-#define SLOTB(B_, AH_, AL_, KO_, G_, C0_, C1_, C2_)                                                       \
-        if (!VZ) SLOT(B_, AH_, AL_, KO_, G_, C0_, C1_, C2_) else NOSLOT(G_, C0_, C1_, C2_)
+#define SLOTB(B_, AH_, AL_, BH_, BL_, NB_, G_, C0_, C1_, C2_)                                             \
+        if (!VZ) SLOT(B_, AH_, AL_, BH_, BL_, NB_, G_, C0_, C1_, C2_) else { NB_ NOSLOT(G_, C0_, C1_, C2_) }
         half8 aone = zero8h;
         if (hi == 0) { aone[0] = (_Float16)256.0f; aone[1] = (_Float16)256.0f; }
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -290,19 +294,21 @@ __global__ __launch_bounds__(IL_THREADS, 2) void adf_message_il_kernel(MsgParams
 
         // ================= phase X: MFMAs of (a, b, c)(channel c0 + q) || sums of the previous block's Y half
         GX(0) GX(1)     // head start of this block's X rows (summed in phase Y)
+        half8 bhA, blA, bhB, blB;        // B fragments of the current / next slot (requested one slot ahead)
+        LOADB(bhA, blA, 0, 0)
         BIAS_INIT(0) if (!VZ) { BIAS_INIT(2) } BIAS_INIT(4)
         __builtin_amdgcn_sched_barrier(0);
-        SLOT(0, ah0, al0, 0, GY(2) GY(3), CY(0), CY(1), NOP_)
-        SLOTB(2, ah0, al0, 0, GY(4) GY(5), CY(2), CY(3), NOP_)
-        SLOT(4, ah0, al0, 0, GY(6) GY(7), CY(4), CY(5), NOP_)
-        SLOT(0, ah1, al1, soff1, GY(8) GY(9), CY(6), CY(7), NOP_)
-        SLOTB(2, ah1, al1, soff1, GY(10) GY(11), CY(8), CY(9), NOP_)
-        SLOT(4, ah1, al1, soff1, GY(12) GY(13), CY(10), CY(11), NOP_)
+        SLOT(0, ah0, al0, bhA, blA, LOADB(bhB, blB, 2, 0), GY(2) GY(3), CY(0), CY(1), NOP_)
+        SLOTB(2, ah0, al0, bhB, blB, LOADB(bhA, blA, 4, 0), GY(4) GY(5), CY(2), CY(3), NOP_)
+        SLOT(4, ah0, al0, bhA, blA, LOADB(bhB, blB, 0, soff1), GY(6) GY(7), CY(4), CY(5), NOP_)
+        SLOT(0, ah1, al1, bhB, blB, LOADB(bhA, blA, 2, soff1), GY(8) GY(9), CY(6), CY(7), NOP_)
+        SLOTB(2, ah1, al1, bhA, blA, LOADB(bhB, blB, 4, soff1), GY(10) GY(11), CY(8), CY(9), NOP_)
+        SLOT(4, ah1, al1, bhB, blB, LOADB(bhA, blA, 0, 32), GY(12) GY(13), CY(10), CY(11), NOP_)
         if (three) {   // (the empty asm keeps hipcc from hoisting the arms' common gathers / sums in front of the branch)
             asm volatile("" ::: "memory");
-            SLOT(0, ah2, al2, 32, GY(14) GY(15), CY(12), CY(13), NOP_)
-            SLOTB(2, ah2, al2, 32, NOP_, CY(14), CY(15), NOP_)
-            SLOT(4, ah2, al2, 32, NOP_, NOP_, NOP_, NOP_)
+            SLOT(0, ah2, al2, bhA, blA, LOADB(bhB, blB, 2, 32), GY(14) GY(15), CY(12), CY(13), NOP_)
+            SLOTB(2, ah2, al2, bhB, blB, LOADB(bhA, blA, 4, 32), NOP_, CY(14), CY(15), NOP_)
+            SLOT(4, ah2, al2, bhA, blA, NOP_, NOP_, NOP_, NOP_, NOP_)
             for (int s = 3; s < nsteps; ++s) {   // unusually wide window: further steps regenerate their operand
                 half8 ahs, als;
                 gen_a(klo + 16 * s, ahs, als);
@@ -342,19 +348,20 @@ __global__ __launch_bounds__(IL_THREADS, 2) void adf_message_il_kernel(MsgParams
 
         // ================= phase Y: MFMAs of (a, b, c)(channel c0 + 32 + q) || sums of this block's X half
         GATHERH(y, 1, meta_c, 0) GATHERH(y, 1, meta_c, 1)   // head start of this block's Y rows (summed in the next block)
+        LOADB(bhA, blA, 1, 0)
         BIAS_INIT(1) if (!VZ) { BIAS_INIT(3) } BIAS_INIT(5)
         __builtin_amdgcn_sched_barrier(0);
-        SLOT(1, ah0, al0, 0, GX(2) GX(3), CX(0), CX(1), NOP_)
-        SLOTB(3, ah0, al0, 0, GX(4) GX(5), CX(2), CX(3), NOP_)
-        SLOT(5, ah0, al0, 0, GX(6) GX(7), CX(4), CX(5), NOP_)
-        SLOT(1, ah1, al1, soff1, GX(8) GX(9), CX(6), CX(7), NOP_)
-        SLOTB(3, ah1, al1, soff1, GX(10) GX(11), CX(8), CX(9), NOP_)
-        SLOT(5, ah1, al1, soff1, GX(12) GX(13), CX(10), CX(11), NOP_)
+        SLOT(1, ah0, al0, bhA, blA, LOADB(bhB, blB, 3, 0), GX(2) GX(3), CX(0), CX(1), NOP_)
+        SLOTB(3, ah0, al0, bhB, blB, LOADB(bhA, blA, 5, 0), GX(4) GX(5), CX(2), CX(3), NOP_)
+        SLOT(5, ah0, al0, bhA, blA, LOADB(bhB, blB, 1, soff1), GX(6) GX(7), CX(4), CX(5), NOP_)
+        SLOT(1, ah1, al1, bhB, blB, LOADB(bhA, blA, 3, soff1), GX(8) GX(9), CX(6), CX(7), NOP_)
+        SLOTB(3, ah1, al1, bhA, blA, LOADB(bhB, blB, 5, soff1), GX(10) GX(11), CX(8), CX(9), NOP_)
+        SLOT(5, ah1, al1, bhB, blB, LOADB(bhA, blA, 1, 32), GX(12) GX(13), CX(10), CX(11), NOP_)
         if (three) {   // (the empty asm keeps hipcc from hoisting the arms' common gathers / sums in front of the branch)
             asm volatile("" ::: "memory");
-            SLOT(1, ah2, al2, 32, GX(14) GX(15), CX(12), CX(13), NOP_)
-            SLOTB(3, ah2, al2, 32, NOP_, CX(14), CX(15), NOP_)
-            SLOT(5, ah2, al2, 32, NOP_, NOP_, NOP_, NOP_)
+            SLOT(1, ah2, al2, bhA, blA, LOADB(bhB, blB, 3, 32), GX(14) GX(15), CX(12), CX(13), NOP_)
+            SLOTB(3, ah2, al2, bhB, blB, LOADB(bhA, blA, 5, 32), NOP_, CX(14), CX(15), NOP_)
+            SLOT(5, ah2, al2, bhA, blA, NOP_, NOP_, NOP_, NOP_, NOP_)
             for (int s = 3; s < nsteps; ++s) {   // unusually wide window: further steps regenerate their operand
                 half8 ahs, als;
                 gen_a(klo + 16 * s, ahs, als);
@@ -443,6 +450,7 @@ __global__ __launch_bounds__(IL_THREADS, 2) void adf_message_il_kernel(MsgParams
 #undef CONSUMEX
 #undef CONSUMEY
 #undef SLOT
+#undef LOADB
 #undef NOSLOT
 #undef SLOTB
 #undef GX
