@@ -1,7 +1,8 @@
 // RETIRED EXPERIMENT (round 5; not part of the build).  Measured 7.76 ms per full launch against message.hip's 6.92 (1.72 vs
-// 1.52 at 200 systems; 8.0 ms before the B fragments were requested one slot ahead and the unit vectors carried in registers): placing the gathers and sums between the MFMAs couples the matrix pipe to the gathers' latency - an
-// in-order wave that waits for a record cannot issue its next MFMA - which costs more than the in-wave overlap returns (the
-// overlap microbenchmark hides register-resident FMAs only).  Its outputs agree with message.hip's to 1e-6, not bit for bit (not
+// 1.52 ms at 200 systems; 8.0 ms before the B fragments were requested one slot ahead and the unit vectors carried in
+// registers).  Placing the gathers and sums between the MFMAs couples the matrix pipe to the gathers' latency - an in-order
+// wave that waits for a record cannot issue its next MFMA - which costs more than the in-wave overlap returns (the overlap
+// microbenchmark hides register-resident FMAs only).  Its outputs agree with message.hip's to 1e-6, not bit for bit (not
 // debugged).  To rebuild: copy into adsorbdiff_amd/csrc/, add to build.SOURCES, declare adf_message_il_prepare /
 // adf_message_il_launch in message.h and call them from message.hip (git history of round 5).
 //
