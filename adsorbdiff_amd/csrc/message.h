@@ -1,6 +1,6 @@
 // Shared declarations of the message kernels (message.hip: forward, two waves per SIMD, f16x3 / exact-f32 / non-uniform-centre
-// modes; message_bwd.hip: the training step's fused backward).  The retired variants (message32 / message3 / message4, all
-// measured slower) live in scratch/experiments/.
+// modes; message_bwd.hip: the training step's fused backward).  The retired variants (message32 / message3 / message4 /
+// message_il, all measured slower) live in scratch/experiments/.
 #pragma once
 #include "common.h"
 
