@@ -168,7 +168,7 @@ def pack_sites(local: torch.Tensor, system_ids, bounds) -> torch.Tensor:
     packed[:, 0] = -1
     packed[: local.shape[0], 0] = ids.to(dev)
     packed[: local.shape[0], 1 : 1 + 3 * local.shape[1]] = (
-        local.reshape(local.shape[0], -1).to(torch.float32).contiguous().view(torch.int32))
+        local.reshape(local.shape[0], 3 * local.shape[1]).to(torch.float32).contiguous().view(torch.int32))   # (a rank may be empty)
     return packed
 
 

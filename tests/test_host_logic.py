@@ -484,6 +484,39 @@ def test_trajectory_writer_abort_publishes_nothing_and_writer_death_wakes_the_pr
         w2.join_checked(10)
 
 
+def test_site_messages_pack_and_merge_for_eight_ragged_ranks():
+    """sampler.pack_sites / merge_packed_sites (what gather_sites sends and what it makes of the all-gather's result), without
+    any process group: eight ranks with different system counts and adsorbate sizes, ids dealt out of order, NaN and
+    denormal-looking bit patterns in the sites - the merged array is the global-order array, bit for bit; padding rows and
+    padding atoms never leak; a shard larger than the bounds is refused."""
+    from adsorbdiff_amd.sampler import merge_packed_sites, pack_sites
+
+    g = torch.Generator().manual_seed(5)
+    B, Amax = 37, 5
+    natoms = torch.randint(1, Amax + 1, (B,), generator=g)
+    full = torch.full((B, Amax, 3), float("nan"))
+    for i in range(B):
+        full[i, : natoms[i]] = torch.randn(int(natoms[i]), 3, generator=g) * 10.0 ** float(torch.randint(-30, 20, (1,), generator=g))
+    full[3, 0, 0] = torch.tensor([1e-42])[0]          # a denormal survives the int32 transport
+    perm = torch.randperm(B, generator=g).tolist()
+    cuts = [0, 4, 4, 11, 15, 23, 24, 31, 37]           # rank 1 is empty, the others ragged
+    Bmax = max(b - a for a, b in zip(cuts[:-1], cuts[1:]))
+    msgs = []
+    for r in range(8):
+        ids = perm[cuts[r]:cuts[r + 1]]
+        local = full[ids][:, : max([int(natoms[i]) for i in ids] + [1])] if ids else torch.empty(0, 1, 3)
+        msgs.append(pack_sites(local, ids, (Bmax, Amax)))
+        assert msgs[-1].dtype == torch.int32 and msgs[-1].shape == (Bmax, 1 + 3 * Amax)
+    merged = merge_packed_sites(torch.stack(msgs), Amax, ordered=True)
+    assert merged.shape == full.shape
+    assert torch.equal(merged.view(torch.int32)[~torch.isnan(full)], full.view(torch.int32)[~torch.isnan(full)])
+    assert torch.equal(torch.isnan(merged), torch.isnan(full))
+    rank_major = merge_packed_sites(torch.stack(msgs), Amax, ordered=False)
+    assert torch.equal(torch.nan_to_num(rank_major), torch.nan_to_num(full[perm]))
+    with pytest.raises(ValueError):
+        pack_sites(full[:Bmax + 1], list(range(Bmax + 1)), (Bmax, Amax))
+
+
 def test_npz_to_ase_traj_converter(tmp_path):
     """The sink's format is .npz (ase is not installable in the build image); where ase IS importable the converter must
     reproduce the reference's <sid>.traj content (relaxation/ase_utils.py:19-48)."""
