@@ -27,18 +27,24 @@ def balanced_partition(sizes: Sequence[int], num_parts: int) -> List[List[int]]:
 
 
 def shard_batch(batch, rank: int, world: int):
-    """This rank's share of ``batch`` (systems dealt by atom count); returns (sub_batch, system ids)."""
+    """This rank's share of ``batch`` (systems dealt by atom count); returns (sub_batch, system ids) - (None, []) for a rank
+    that is dealt nothing (more ranks than systems): it skips the sampling and only joins ``gather_sites``."""
     from .data import Batch
 
     parts = balanced_partition(batch.natoms.tolist(), world)
     mine = parts[rank]
+    if not mine:
+        return None, []
     data = batch.to_data_list()
     return Batch.from_data_list([data[i] for i in mine]), mine
 
 
 def adsorbate_sites(batch) -> torch.Tensor:
     """[B, A, 3] positions of each system's adsorbate (tag==2) atoms, NaN-padded to the largest
-    adsorbate in the batch."""
+    adsorbate in the batch.  A rank that was dealt no system (more ranks than systems) passes None or an empty batch and
+    gets a [0, 1, 3] tensor: it still takes part in the exchange with an all-padding message."""
+    if batch is None or not hasattr(batch, "pos"):
+        return torch.empty(0, 1, 3, dtype=torch.float32)
     tags, bidx = batch.tags, batch.batch
     B = int(batch.natoms.shape[0])
     m = tags == 2
@@ -115,7 +121,7 @@ def shard_bounds(batch, world: int):
     return max(len(p) for p in parts), max(int(counts.max().item()), 1)
 
 
-def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=None) -> torch.Tensor:
+def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=None, local=None) -> torch.Tensor:
     """All ranks' adsorbate sites: [sum_r B_r, A_max, 3] (NaN padded), rank-major — or, when every rank passes the
     global ids of its systems (``system_ids``, what ``shard_batch`` returns), in global system order.
 
@@ -125,7 +131,8 @@ def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=
 
     via="torch": ``torch.distributed.all_gather`` (backend nccl = RCCL over xGMI; gloo in the CPU tests);
     via="rccl":  the library's C-ABI entry ``adf_allgather_sites`` (one GPU per rank)."""
-    local = adsorbate_sites(batch)
+    if local is None:   # (``local``: the sites already extracted - what a rank without systems passes, on its device)
+        local = adsorbate_sites(batch)
     if world <= 1:
         return local
     import torch.distributed as dist

@@ -342,7 +342,7 @@ def main():
         else:
             batch0, my_ids = full, list(range(args.systems))
         n_local = len(my_ids)
-        batch0 = batch0.to(dev)
+        batch0 = batch0.to(dev) if n_local else None   # (more ranks than systems: this rank only joins the exchange)
     total_systems = args.systems * world if args.scaling == "weak" else args.systems
     # `value` stays on the full-output path (every atom's model outputs at every step) for round-to-round comparability;
     # what Denoiser.run() does without options since round 5 (outputs of the adsorbate atoms only inside the fused loop:
@@ -358,6 +358,9 @@ def main():
     placement = torch.rand(total_systems, 3)[torch.tensor(my_ids, dtype=torch.long)]
 
     def one_pass(extra=None):
+        if batch0 is None:
+            empty = torch.empty(0, 1, 3, device=dev)
+            return gather_sites(None, world, via=args.gather, system_ids=my_ids, bounds=bounds, local=empty)
         b = batch0.clone()
         torch.manual_seed(0)
         den = Denoiser(b, DiffTorchCalc(trainer), dict(params, placement_noise=placement, **(extra or {})),
@@ -395,7 +398,7 @@ def main():
         # every rank's own time over the timed passes (its clock stops when ITS last all_gather returned) and its GPU-busy
         # time: the first real multi-GPU run then shows the curve and where its imbalance comes from in one line
         busy = sum(v[0] for v in eng.profile_read().values() if isinstance(v, tuple))
-        t = torch.tensor([elapsed * 1e3 / args.steps, busy / args.steps, float(n_local), float(batch0.pos.shape[0])],
+        t = torch.tensor([elapsed * 1e3 / args.steps, busy / args.steps, float(n_local), float(batch0.pos.shape[0] if batch0 is not None else 0)],
                          dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -403,7 +406,7 @@ def main():
         elapsed = max(a[0] for a in rank_ms) * args.steps / 1e3
     prof = eng.profile_read()
     eng.profile_enable(False)
-    counters = eng.counters()
+    counters = eng.counters() if batch0 is not None else None   # (rank 0 always holds systems)
 
     # Secondary measurement, N = 1 only, never `value`: the same pass with the model outputs evaluated on the
     # adsorbate atoms only (the stepper reads nothing else; sampled positions are bit-identical, checked here).
@@ -849,7 +852,7 @@ def main_eqv2(args, rank, world, dev, emit=True):
         full = eqv2_batch(args.systems, seed=1000)
         batch0, my_ids = shard_batch(full, rank, world) if world > 1 else (full, list(range(args.systems)))
         bounds = shard_bounds(full, world) if world > 1 else None
-        batch0 = batch0.to(dev)
+        batch0 = batch0.to(dev) if len(my_ids) else None   # (more ranks than systems: this rank only joins the exchange)
     n_local = len(my_ids)
     total_systems = args.systems * world if args.scaling == "weak" else args.systems
     # (`value`: full per-atom outputs, as in the PaiNN line; the default call is the `value_default_api` secondary)
@@ -860,6 +863,9 @@ def main_eqv2(args, rank, world, dev, emit=True):
     placement = torch.rand(total_systems, 3)[torch.tensor(my_ids, dtype=torch.long)]
 
     def one_pass(extra=None):
+        if batch0 is None:
+            return gather_sites(None, world, via=args.gather, system_ids=my_ids, bounds=bounds,
+                                local=torch.empty(0, 1, 3, device=dev))
         b = batch0.clone()
         torch.manual_seed(0)
         den = Denoiser(b, DiffTorchCalc(trainer), dict(params, placement_noise=placement, **(extra or {})), device=str(dev))
@@ -874,7 +880,7 @@ def main_eqv2(args, rank, world, dev, emit=True):
 
     wsteps = getattr(args, "warmup_num_steps", None)  # embedded in the PaiNN line: a short warm-up pass
     for _ in range(args.warmup):
-        if wsteps:
+        if wsteps and batch0 is not None:
             b_ = batch0.clone()
             torch.manual_seed(0)
             Denoiser(b_, DiffTorchCalc(trainer), dict(params, num_steps=wsteps, placement_noise=placement), device=str(dev)).run()
@@ -909,7 +915,7 @@ def main_eqv2(args, rank, world, dev, emit=True):
         # every rank's own time over the timed passes (its clock stops when ITS last all_gather returned) and its GPU-busy
         # time: the first real multi-GPU run then shows the curve and where its imbalance comes from in one line
         busy = sum(v[0] for v in eng.profile_read().values() if isinstance(v, tuple))
-        t = torch.tensor([elapsed * 1e3 / args.steps, busy / args.steps, float(n_local), float(batch0.pos.shape[0])],
+        t = torch.tensor([elapsed * 1e3 / args.steps, busy / args.steps, float(n_local), float(batch0.pos.shape[0] if batch0 is not None else 0)],
                          dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
@@ -917,7 +923,7 @@ def main_eqv2(args, rank, world, dev, emit=True):
         elapsed = max(a[0] for a in rank_ms) * args.steps / 1e3
     prof = eng.profile_read()
     eng.profile_enable(False)
-    c = eng.counters()
+    c = eng.counters() if batch0 is not None else None
     if rank == 0:
         assert sites.shape[0] == total_systems and bool(torch.isfinite(sites).all())
         forwards = args.steps * args.num_steps

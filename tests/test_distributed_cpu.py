@@ -78,6 +78,35 @@ def test_two_rank_shard_and_gather(tmp_path):
     assert torch.equal(torch.nan_to_num(r0["sites"]), torch.nan_to_num(want))
 
 
+def _empty_rank_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = make_batch(2, n_slab=16, n_ads=3, seed=9)      # two systems, three ranks: one rank is dealt nothing
+    mine, ids = shard_batch(full, rank, world)
+    bounds = shard_bounds(full, world)
+    if ids:
+        mine.pos = mine.pos + float(rank + 1)
+        got = gather_sites(mine, world, system_ids=ids, bounds=bounds)
+    else:
+        got = gather_sites(None, world, system_ids=ids, bounds=bounds)
+    torch.save({"sites": got, "ids": ids}, os.path.join(out_dir, f"e{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_without_systems_joins_the_exchange(tmp_path):
+    """More ranks than systems (a user sampling 2 structures on a 3-GPU launch): the surplus rank sends an all-padding message
+    and every rank still receives both systems' sites in global order."""
+    world = 3
+    mp.spawn(_empty_rank_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"e{r}.pt") for r in range(world)]
+    assert sorted(len(r["ids"]) for r in res) == [0, 1, 1]
+    for r in res:
+        assert r["sites"].shape == (2, 3, 3) and bool(torch.isfinite(r["sites"]).all())
+        assert torch.equal(r["sites"], res[0]["sites"])
+
+
 def _grad_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
