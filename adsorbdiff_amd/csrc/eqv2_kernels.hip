@@ -442,8 +442,12 @@ int32_t eq_launch_edge_degree(const adf_eqv2* h, const float* m0, const int32_t*
 // thread = one of the 2C input channels.
 struct eq_ptrs { float* p[EQ_MAX_M + 1]; };
 
-template <int LT, bool PRESPLIT>
-__global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __restrict__ rad, const float* __restrict__ wig,
+// MT > 0: the order cut-off M as a compile-time constant (= d.M): which rows of D_l are kept is then known statically and
+// every load of the edge - the 49 coefficients of the thread's channel and the 29 radial weights - is requested BEFORE the
+// first product (round 5; the runtime-M form loads degree by degree and weight by weight: 7 + dependent round trips per edge
+// in a kernel that lives for one edge).  MT = 0: M read from d.
+template <int LT, bool PRESPLIT, int MT>
+__global__ __launch_bounds__(256) void eq_rotate_in_kernel(const float* __restrict__ y, const float* __restrict__ rad, const float* __restrict__ wig,
                                     const int32_t* __restrict__ eptr, const int32_t* __restrict__ e_src,
                                     const int32_t* __restrict__ e_dst, int n0, int n1, eq_dims d, eq_ptrs mb, eq_ptrs rs,
                                     const int32_t* __restrict__ Z, int pair_ne) {
@@ -479,12 +483,28 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
             rrow = (long long)zs * pair_ne + zt;
         }
         const float* rr = rad + (size_t)rrow * d.RW * C2;
+        constexpr int SS = (LT + 1) * (LT + 1);
+        float vin[MT > 0 ? SS : 1], rw[MT > 0 ? SS : 1];
+        if constexpr (MT > 0) {
+#pragma unroll
+            for (int t = 0; t < SS; ++t) vin[t] = yr[(size_t)t * d.C];
+#pragma unroll
+            for (int l = 0; l <= LT; ++l) {
+#pragma unroll
+                for (int mp = -l; mp <= l; ++mp) {
+                    const int am = mp < 0 ? -mp : mp;
+                    if (am > (l < MT ? l : MT)) continue;
+                    rw[l * l + l + mp] = rr[(size_t)(d.rad_off[am] + (l - am)) * C2 + c];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // every load of the edge is requested before the first product
+        }
 #pragma unroll
         for (int l = 0; l <= LT; ++l) {
             float v[2 * LT + 1];
 #pragma unroll
-            for (int m = 0; m < 2 * l + 1; ++m) v[m] = yr[(size_t)(l * l + m) * d.C];
-            const int ml = l < d.M ? l : d.M;
+            for (int m = 0; m < 2 * l + 1; ++m) v[m] = MT > 0 ? vin[l * l + m] : yr[(size_t)(l * l + m) * d.C];
+            const int ml = MT > 0 ? (l < MT ? l : MT) : (l < d.M ? l : d.M);
             const float* Dl = D + d.d_off[l];
 #pragma unroll
             for (int mp = -l; mp <= l; ++mp) {  // compile-time order: the row-maximum slot is a constant
@@ -495,7 +515,7 @@ __global__ void eq_rotate_in_kernel(const float* __restrict__ y, const float* __
 #pragma unroll
                 for (int m = 0; m < 2 * l + 1; ++m) a += Dl[ri * (2 * l + 1) + m] * v[m];
                 const int nm = LT - am + 1;
-                a *= rr[(size_t)(d.rad_off[am] + (l - am)) * C2 + c];
+                a *= MT > 0 ? rw[l * l + l + mp] : rr[(size_t)(d.rad_off[am] + (l - am)) * C2 + c];
                 if (PRESPLIT) {
                     vals[l * l + l + mp] = a;
                 } else {
@@ -557,15 +577,19 @@ int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad,
     eq_ptrs mb, rs;
     for (int m = 0; m <= EQ_MAX_M; ++m) { mb.p[m] = m <= h->d.M ? mbuf[m] : nullptr; rs.p[m] = (rsp && m <= h->d.M) ? rsp[m] : nullptr; }
     const int bd = (2 * h->d.C + 63) / 64 * 64;
-#define EQ_RI(LT_)                                                                                                     \
+    if (bd > 256) { adf_set_error("rotate_in: more than 128 sphere channels"); return ADF_EINVAL; }
+    const bool m2 = h->d.M == 2 && !getenv("ADF_EQV2_ROTIN_GENERIC");   // compile-time-M fast path (M = 2: the shipped models)
+#define EQ_RI_(LT_, MT_)                                                                                               \
     if (presplit)                                                                                                      \
-        hipLaunchKernelGGL((eq_rotate_in_kernel<LT_, true>), dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
+        hipLaunchKernelGGL((eq_rotate_in_kernel<LT_, true, MT_>), dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
                            h->e_src, h->e_dst, n0, n1, dd, mb, rs, Z, pair_ne);                                       \
     else                                                                                                               \
-        hipLaunchKernelGGL((eq_rotate_in_kernel<LT_, false>), dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
+        hipLaunchKernelGGL((eq_rotate_in_kernel<LT_, false, MT_>), dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
                            h->e_src, h->e_dst, n0, n1, dd, mb, rs, Z, pair_ne)
+#define EQ_RI(LT_) if (m2) { EQ_RI_(LT_, 2); } else { EQ_RI_(LT_, 0); }
     EQ_FOR_L(h->d.L, EQ_RI)
 #undef EQ_RI
+#undef EQ_RI_
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
@@ -941,8 +965,12 @@ int32_t eq_launch_alpha(const adf_eqv2* h, const eq_attn* at, const float* y0, i
 // slower, 61 -> 80 ms per forward at 256 k edges: the edge's Wigner rows stop being wave-uniform scalar loads.  Dealing the
 // DEGREES of a target to four thread groups instead - whole waves, scalar Wigner loads kept, bit-identical sums, four times
 // the waves per target - was slower too: 64.4 vs 60.9 ms.  Unrolling the edge loop 2x / 4x: no change.)
-template <int LT, bool ONLY1>
-__global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, const float* __restrict__ alpha,
+// MT > 0: the order cut-off M as a compile-time constant (= d.M; the shipped models use M = 2): the loop over the kept rows of
+// D_l unrolls, the choice between the m = 0 row and the +-m pair resolves at compile time, and the 29 values an edge
+// contributes are requested together instead of one dependent load per row (round 5: the runtime-M loop waited for every
+// load before issuing the next - 580 memory round trips per target).  MT = 0: M read from d (any other cut-off).
+template <int LT, bool ONLY1, int MT>
+__global__ __launch_bounds__(256) void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, const float* __restrict__ alpha,
                                      const float* __restrict__ wig, const int32_t* __restrict__ eptr, int n0, int n1,
                                      eq_dims d, int compact, float* __restrict__ agg) {
     // compact (ONLY1): the convolution wrote only the l = 1 columns - z0 [E, HV], z1 [2E, 2 HV] (real | imaginary part)
@@ -955,13 +983,62 @@ __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, c
     for (int s = 0; s < NS; ++s) acc[s] = 0.f;
     const int hd = c / d.V;
     const int ld0 = compact ? d.HV : (d.L + 1) * d.HV;
+    const int Mrt = MT > 0 ? MT : d.M;
     for (long long e = eptr[n]; e < eptr[n + 1]; ++e) {
         const long long el = e - ebase;
         const float a = alpha[(size_t)el * d.NH + hd];
         const float* D = wig + (size_t)e * d.DR;
+        if constexpr (MT > 0) {
+            // gather the edge's values first (static indices), then the products
+            constexpr int LA = ONLY1 ? 1 : 0, LB = ONLY1 ? 1 : LT;
+            float va[LB - LA + 1][2 * MT + 1], vb[LB - LA + 1][2 * MT + 1];   // the two loads of a +-m row (vb unused for m = 0)
+#pragma unroll
+            for (int l = LA; l <= LB; ++l) {
+                const int ml = l < MT ? l : MT;
+#pragma unroll
+                for (int ri = 0; ri < 2 * MT + 1; ++ri) {
+                    if (ri >= 2 * ml + 1) continue;
+                    const int mp = ri - ml, am = mp < 0 ? -mp : mp;
+                    if (am == 0) {
+                        va[l - LA][ri] = z0[(size_t)el * ld0 + (compact ? 0 : l * d.HV) + c];
+                        vb[l - LA][ri] = 0.f;
+                    } else {
+                        const int nm = compact ? 1 : d.L - am + 1, half = nm * d.HV, W = 2 * half, q = (compact ? 0 : (l - am) * d.HV) + c;
+                        const float* zr = zm.p[am] + (size_t)(2 * el) * W;
+                        va[l - LA][ri] = mp > 0 ? zr[q] : zr[W + q];
+                        vb[l - LA][ri] = mp > 0 ? zr[W + half + q] : zr[half + q];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // every load of the edge is requested before the first one is used
+            float vals[LB - LA + 1][2 * MT + 1];
+#pragma unroll
+            for (int l = LA; l <= LB; ++l) {
+                const int ml = l < MT ? l : MT;
+#pragma unroll
+                for (int ri = 0; ri < 2 * MT + 1; ++ri) {
+                    if (ri >= 2 * ml + 1) continue;
+                    const int mp = ri - ml;
+                    vals[l - LA][ri] = mp > 0 ? va[l - LA][ri] - vb[l - LA][ri] : va[l - LA][ri] + vb[l - LA][ri];
+                }
+            }
+#pragma unroll
+            for (int l = LA; l <= LB; ++l) {
+                const int ml = l < MT ? l : MT;
+                const float* Dl = D + d.d_off[l];
+                const float sc = a * d.resc[l];
+#pragma unroll
+                for (int ri = 0; ri < 2 * MT + 1; ++ri) {
+                    if (ri >= 2 * ml + 1) continue;
+                    const float v = vals[l - LA][ri] * sc;
+#pragma unroll
+                    for (int m = 0; m < 2 * l + 1; ++m) acc[(ONLY1 ? 0 : l * l) + m] += Dl[ri * (2 * l + 1) + m] * v;
+                }
+            }
+        } else {
 #pragma unroll
         for (int l = (ONLY1 ? 1 : 0); l <= (ONLY1 ? 1 : LT); ++l) {
-            const int ml = l < d.M ? l : d.M;
+            const int ml = l < Mrt ? l : Mrt;
             const float* Dl = D + d.d_off[l];
             const float sc = a * d.resc[l];
             for (int ri = 0; ri < 2 * ml + 1; ++ri) {
@@ -979,6 +1056,7 @@ __global__ void eq_rotate_out_kernel(const float* __restrict__ z0, eq_ptrs zm, c
                 for (int m = 0; m < 2 * l + 1; ++m) acc[(ONLY1 ? 0 : l * l) + m] += Dl[ri * (2 * l + 1) + m] * v;
             }
         }
+        }
     }
     float* out = agg + (size_t)n * NS * d.HV + c;
 #pragma unroll
@@ -992,15 +1070,19 @@ int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* al
     eq_ptrs zm;
     for (int m = 0; m <= h->d.M; ++m) zm.p[m] = z[m];
     const int bd = (h->d.HV + 63) / 64 * 64;
-#define EQ_RO(LT_)                                                                                                     \
+    if (bd > 256) { adf_set_error("rotate_out: more than 256 value channels"); return ADF_EINVAL; }
+    const bool m2 = h->d.M == 2 && !getenv("ADF_EQV2_ROTOUT_GENERIC");   // the compile-time-M fast path (M = 2: the shipped models)
+#define EQ_RO_(LT_, MT_)                                                                                               \
     if (only_l1)                                                                                                       \
-        hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, true>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
+        hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, true, MT_>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
                            h->eptr, n0, n1, h->d, compact ? 1 : 0, agg);                                               \
     else                                                                                                               \
-        hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, false>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
+        hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, false, MT_>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \
                            h->eptr, n0, n1, h->d, 0, agg)
+#define EQ_RO(LT_) if (m2) { EQ_RO_(LT_, 2); } else { EQ_RO_(LT_, 0); }
     EQ_FOR_L(h->d.L, EQ_RO)
 #undef EQ_RO
+#undef EQ_RO_
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
