@@ -31,7 +31,8 @@ struct MsgBwdParams {
     const float* gv1;     // [N, 3, H] gradient of vec1 (the residual path of dvec)
     float* dxh;           // [N, 3H]
     float* dvec;          // [N, 3, H] or null
-    float* drbfh;         // [E + 1, 3H] in kernel order (row E: spare, written by padded edge rows)
+    float* drbfh;         // [E + 1, 3H] in kernel order (row E: spare, written by padded edge rows); unused when !ST
+    float* dbias_rows;    // !ST: [N, 3H] per-atom column sums of drbfh over the atom's edge rows ([a | b | c] order)
     int E;
 };
 
@@ -43,7 +44,10 @@ struct MsgBwdParams {
 #define MSGB_AHEAD 2   // gather rows requested ahead of the row being consumed (4: as the forward kernel)
 #endif
 
-template <bool VZ>
+// ST: drbfh is stored (the materialised path: tr_wgrad_bf16x6_kernel reads it back).  !ST: nothing per edge leaves the
+// kernel - rbf_wgrad.hip forms drbfh again while it stages its product - and the bias gradient's column sums are handed
+// over per atom (deterministic: an atom's rows are summed by one wave in row order, whichever wave pulls the atom).
+template <bool VZ, bool ST>
 __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_bwd_kernel(MsgBwdParams pb) {
     const MsgParams& p = pb.m;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -135,6 +139,7 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
     // running sums over the atom's edges
     float da0 = 0.f, da1 = 0.f, db0 = 0.f, db1 = 0.f, dc0 = 0.f, dc1 = 0.f;
     float vx0 = 0.f, vy0 = 0.f, vz0 = 0.f, vx1 = 0.f, vy1 = 0.f, vz1 = 0.f;
+    float ba0 = 0.f, ba1 = 0.f, bb0 = 0.f, bb1 = 0.f, bc0 = 0.f, bc1 = 0.f;   // !ST: column sums of the atom's drbfh rows
 
     while (have) {
         {
@@ -207,7 +212,9 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
             vx0 += ga0##r.x * f0; vy0 += ga0##r.y * f0; vz0 += ga0##r.z * f0;                   \
             vx1 += ga1##r.x * f1; vy1 += ga1##r.y * f1; vz1 += ga1##r.z * f1;                   \
         }                                                                                       \
-        if (MSGB_STORE == 2) {  /* timing experiment: no drbfh stores (wrong results) */        \
+        if (!ST) {                                                                              \
+            ba0 += ga0##r.w * xa0; ba1 += ga1##r.w * xa1; bc0 += T0 * xc0; bc1 += T1 * xc1;     \
+            if (!VZ) { bb0 += S0 * xb0; bb1 += S1 * xb1; }                                      \
         } else if (MSGB_STORE == 0) {                                                           \
             char* d = dlane + (size_t)(unsigned int)__float_as_int(m##r[4]) * drow_bytes;       \
             *reinterpret_cast<float4*>(d) = make_float4(ga0##r.w * xa0, S0 * xb0, T0 * xc0, ga1##r.w * xa1); \
@@ -324,6 +331,14 @@ __global__ __launch_bounds__(MSG_THREADS, MSGB_WAVES_PER_SIMD) void adf_message_
                     pb.dvec[ro + H] = pb.gv1[ro + H] + vy0; pb.dvec[ro + H + 32] = pb.gv1[ro + H + 32] + vy1;
                     pb.dvec[ro + 2 * H] = pb.gv1[ro + 2 * H] + vz0; pb.dvec[ro + 2 * H + 32] = pb.gv1[ro + 2 * H + 32] + vz1;
                 }
+                if (!ST) {
+                    ba0 += __shfl_xor(ba0, 32); ba1 += __shfl_xor(ba1, 32);
+                    bb0 += __shfl_xor(bb0, 32); bb1 += __shfl_xor(bb1, 32);
+                    bc0 += __shfl_xor(bc0, 32); bc1 += __shfl_xor(bc1, 32);
+                    float* br = pb.dbias_rows + ro + 32 * hi;
+                    br[0] = hi ? ba1 : ba0; br[H] = hi ? bb1 : bb0; br[2 * H] = hi ? bc1 : bc0;
+                    ba0 = ba1 = bb0 = bb1 = bc0 = bc1 = 0.f;
+                }
                 da0 = da1 = db0 = db1 = dc0 = dc1 = 0.f;
                 vx0 = vx1 = vy0 = vy1 = vz0 = vz1 = 0.f;
                 have = haveN;
@@ -384,9 +399,9 @@ extern "C" int32_t adf_op_message_bwd_perm(adf_painn_t h, int32_t* perm_host, in
 
 extern "C" int32_t adf_op_message_bwd_fused(adf_painn_t h, int32_t layer, const float* xh, const float* vec, const float* gx1,
                                             const float* gv1, float* dxh, float* drbfh_lane_order, int64_t num_edges,
-                                            float* dvec, float* dx, int32_t vec_is_zero, void* stream) {
-    if (!h || h->lastN <= 0 || layer < 0 || layer >= h->hp.num_layers || !xh || !gx1 || !gv1 || !dxh || !drbfh_lane_order ||
-        !dx || (!vec_is_zero && (!vec || !dvec))) {
+                                            float* dvec, float* dx, int32_t vec_is_zero, float* dbias_rows, void* stream) {
+    if (!h || h->lastN <= 0 || layer < 0 || layer >= h->hp.num_layers || !xh || !gx1 || !gv1 || !dxh ||
+        (!drbfh_lane_order && !dbias_rows) || !dx || (!vec_is_zero && (!vec || !dvec))) {
         adf_set_error("message_bwd_fused: bad argument or no graph");
         return ADF_EINVAL;
     }
@@ -404,10 +419,12 @@ extern "C" int32_t adf_op_message_bwd_fused(adf_painn_t h, int32_t layer, const 
     }
     static bool attr_set = false;  // per process and device: training runs on one device per process
     if (!attr_set) {
-        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_bwd_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)msgb_lds_bytes()));
-        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(adf_message_bwd_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)msgb_lds_bytes()));
+        const void* kernels[4] = {reinterpret_cast<const void*>(adf_message_bwd_kernel<false, false>),
+                                  reinterpret_cast<const void*>(adf_message_bwd_kernel<false, true>),
+                                  reinterpret_cast<const void*>(adf_message_bwd_kernel<true, false>),
+                                  reinterpret_cast<const void*>(adf_message_bwd_kernel<true, true>)};
+        for (const void* k : kernels)
+            ADF_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)msgb_lds_bytes()));
         attr_set = true;
     }
     const size_t row = (size_t)(H / 32) * 160;
@@ -446,10 +463,14 @@ extern "C" int32_t adf_op_message_bwd_fused(adf_painn_t h, int32_t layer, const 
     if (workers < 1) workers = 1;
     if (workers > p.G) workers = p.G;
     dim3 grid((unsigned)(workers * p.nslices));
-    if (vec_is_zero)
-        hipLaunchKernelGGL(adf_message_bwd_kernel<true>, grid, dim3(MSG_THREADS), msgb_lds_bytes(), s, pb);
-    else
-        hipLaunchKernelGGL(adf_message_bwd_kernel<false>, grid, dim3(MSG_THREADS), msgb_lds_bytes(), s, pb);
+    pb.dbias_rows = dbias_rows;
+    if (drbfh_lane_order) {
+        if (vec_is_zero) hipLaunchKernelGGL((adf_message_bwd_kernel<true, true>), grid, dim3(MSG_THREADS), msgb_lds_bytes(), s, pb);
+        else hipLaunchKernelGGL((adf_message_bwd_kernel<false, true>), grid, dim3(MSG_THREADS), msgb_lds_bytes(), s, pb);
+    } else {
+        if (vec_is_zero) hipLaunchKernelGGL((adf_message_bwd_kernel<true, false>), grid, dim3(MSG_THREADS), msgb_lds_bytes(), s, pb);
+        else hipLaunchKernelGGL((adf_message_bwd_kernel<false, false>), grid, dim3(MSG_THREADS), msgb_lds_bytes(), s, pb);
+    }
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }

@@ -188,8 +188,11 @@ __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restric
     float bs = 0.f;
     const int lr = tid >> 5, lc = (tid & 31) * 4;  // staging: 8 rows x 32 float4 per pass, 4 passes
     int par = 0;
-    for (int m0 = mbeg; m0 < mend; m0 += 32, par ^= 1) {
-        float4 c4[4], a4[4];
+    // The rows of chunk i + 1 are requested right after chunk i's rows have been converted into the LDS image, so they are in
+    // flight while chunk i's MFMAs run (round 5; requested at the top of their own iteration they cost every 32-row chunk
+    // a full memory round trip in front of its barrier).
+    float4 c4[4], a4[4];
+    auto load_chunk = [&](int m0) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int m = m0 + lr + 8 * ps;
@@ -197,6 +200,9 @@ __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restric
             c4[ps] = m < mend ? *reinterpret_cast<const float4*>(dC + (size_t)m * ldc + n0 + lc) : z;
             a4[ps] = m < mend ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k0 + lc) : z;
         }
+    };
+    load_chunk(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += 32, par ^= 1) {
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -300,8 +306,11 @@ __global__ __launch_bounds__(256) void tr_wgrad_bf16x6_kernel(const float* __res
     const int kg = g >> 1;            // k half of the MFMA operand (lanes 32..63)
     const int cgrp = g & 1;           // 16-column half of the 32-column block
     int par = 0;
-    for (int m0 = mbeg; m0 < mend; m0 += 32, par ^= 1) {
-        float4 c4[4], a4[4];
+    // The rows of chunk i + 1 are requested right after chunk i's rows have been converted into the LDS image, so they are in
+    // flight while chunk i's MFMAs run (round 5; requested at the top of their own iteration they cost every 32-row chunk
+    // a full memory round trip in front of its barrier).
+    float4 c4[4], a4[4];
+    auto load_chunk = [&](int m0) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int m = m0 + lr + 8 * ps;
@@ -309,6 +318,9 @@ __global__ __launch_bounds__(256) void tr_wgrad_bf16x6_kernel(const float* __res
             c4[ps] = m < mend ? *reinterpret_cast<const float4*>(dC + (size_t)m * ldc + n0 + lc) : z;
             a4[ps] = m < mend ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k0 + lc) : z;
         }
+    };
+    load_chunk(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += 32, par ^= 1) {
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -340,6 +352,7 @@ __global__ __launch_bounds__(256) void tr_wgrad_bf16x6_kernel(const float* __res
             for (int ps = 1; ps < 4; ++ps) { sum.x += c4[ps].x; sum.y += c4[ps].y; sum.z += c4[ps].z; sum.w += c4[ps].w; }
             *reinterpret_cast<float4*>(&csum[lr][lc]) = sum;
         }
+        if (m0 + 32 < mend) load_chunk(m0 + 32);   // the next chunk's rows: in flight behind this chunk's MFMAs
         __syncthreads();
         if (colsum && tid < 128) {
 #pragma unroll

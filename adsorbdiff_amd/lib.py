@@ -27,7 +27,7 @@ EXPORTS = (
     "adf_frames_create", "adf_frames_destroy", "adf_frames_push", "adf_frames_wait", "adf_frames_release", "adf_frames_pushed", "adf_frames_abort",
     "adf_get_counters", "adf_profile_enable", "adf_profile_read", "adf_measure_peaks",
     "adf_lift_adsorbates", "adf_comm_unique_id", "adf_comm_create", "adf_comm_destroy", "adf_allgather_sites",
-    "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_fwd_fused", "adf_op_message_bwd", "adf_op_message_bwd_fused", "adf_op_message_bwd_fused_supported", "adf_op_message_bwd_perm", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
+    "adf_op_linear_fwd", "adf_op_linear_bwd_scratch", "adf_op_linear_bwd", "adf_op_ssilu_fwd", "adf_op_ssilu_bwd", "adf_op_layernorm_fwd", "adf_op_layernorm_bwd", "adf_op_embed_fwd", "adf_op_embed_bwd", "adf_op_rbf", "adf_op_message_fwd", "adf_op_message_fwd_fused", "adf_op_message_bwd", "adf_op_message_bwd_fused", "adf_op_message_bwd_fused_supported", "adf_op_message_bwd_perm", "adf_op_edge_owner", "adf_op_rbf_image_bytes", "adf_op_rbf_image", "adf_op_rbf_wgrad_fused_scratch", "adf_op_rbf_wgrad_fused", "adf_op_vdot_fwd", "adf_op_vdot_bwd", "adf_op_update_out_fwd", "adf_op_update_out_bwd", "adf_op_vnorm_fwd", "adf_op_vnorm_bwd", "adf_op_gate_fwd", "adf_op_gate_bwd", "adf_op_copy_rows", "adf_op_score_loss", "adf_op_sqnorm_accumulate", "adf_op_adamw_step",
     "adf_eqv2_create", "adf_eqv2_destroy", "adf_eqv2_set_constants", "adf_eqv2_set_weights", "adf_eqv2_set_arithmetic",
     "adf_eqv2_set_edges", "adf_eqv2_set_moving", "adf_eqv2_set_incremental", "adf_eqv2_forward", "adf_eqv2_forward_subset", "adf_eqv2_check_flags", "adf_eqv2_init_placement",
     "adf_eqv2_sde_step", "adf_eqv2_sample", "adf_eqv2_sample_traj", "adf_eqv2_linear_forward", "adf_eqv2_get_counters", "adf_eqv2_profile_enable", "adf_eqv2_profile_read",
@@ -148,7 +148,10 @@ def load():
         "adf_op_message_fwd": [vp, vp, vp, vp, vp, vp, vp, i32, vp],
         "adf_op_message_fwd_fused": [vp, i32, vp, vp, vp, vp, vp, i32, vp],
         "adf_op_message_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
-        "adf_op_message_bwd_fused": [vp, i32, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, i32, vp],
+        "adf_op_message_bwd_fused": [vp, i32, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, i32, vp, vp],
+        "adf_op_edge_owner": [vp, vp, C.c_int64, vp],
+        "adf_op_rbf_image": [vp, vp, C.c_int64, vp, vp],
+        "adf_op_rbf_wgrad_fused": [vp, vp, vp, vp, vp, C.c_int64, vp, vp, i32, vp],
         "adf_op_message_bwd_fused_supported": [vp],
         "adf_op_message_bwd_perm": [vp, vp, i32],
         "adf_op_vdot_fwd": [vp, vp, vp, i32, i64, i32, C.c_float, vp],
@@ -197,6 +200,10 @@ def load():
         fn.restype = i32
     lib.adf_op_linear_bwd_scratch.argtypes = [i64, i32, i32]
     lib.adf_op_linear_bwd_scratch.restype = i64
+    lib.adf_op_rbf_image_bytes.argtypes = [i64]
+    lib.adf_op_rbf_image_bytes.restype = i64
+    lib.adf_op_rbf_wgrad_fused_scratch.argtypes = [vp]
+    lib.adf_op_rbf_wgrad_fused_scratch.restype = i64
     lib.adf_frames_pushed.argtypes = [vp]
     lib.adf_frames_pushed.restype = i64
     _LIB = lib

@@ -90,6 +90,10 @@ class PaiNNTrainStep:
         # ADF_TRAIN_MSG_BWD=plain: the rbfh-reading kernel
         self.fused_message_backward = self.fused_message_forward and os.environ.get("ADF_TRAIN_MSG_BWD", "fused") != "plain"
         self._bwd_perm = None
+        # rbf_proj's weight gradient without d(rbfh) [E, 3H] in memory (csrc/rbf_wgrad.hip: the fused backward stores
+        # nothing per edge and the weight-gradient kernel forms d(rbfh) again while it stages its product);
+        # ADF_TRAIN_RBF_WGRAD=materialised: the round-4 path (d(rbfh) written by the backward, read by adf_op_linear_bwd)
+        self.rbf_wgrad_fused = os.environ.get("ADF_TRAIN_RBF_WGRAD", "fused") != "materialised"
 
     # ------------------------------------------------------------------ helpers
     def _params(self) -> Dict[str, torch.nn.Parameter]:
@@ -260,6 +264,7 @@ class PaiNNTrainStep:
         if grads_ready is not None:
             grads_ready(["out_forces.", "out_forces2."])
         # ---------------- backward: layers, last to first
+        edge_owner = rbf_image = None
         for l in range(L - 1, -1, -1):
             a = saved[l]
             mp, up = f"message_layers.{l}.", f"update_layers.{l}."
@@ -283,22 +288,42 @@ class PaiNNTrainStep:
                            dA=dvec1, acc_dA=True)
             # message block
             first = a["vec"] is None
-            dxh, drbfh = ops.new(N, 3 * H), ops.new(E + 1, 3 * H)  # (+1: the fused kernel's spare row)
+            dxh = ops.new(N, 3 * H)
             dvec_in = None if first else ops.new(N, 3, H)
             dx_in = ops.new(N, H)
-            if fused_bwd:
+            if fused_bwd and self.rbf_wgrad_fused:
+                # nothing per edge leaves the backward; the bias gradient arrives as per-atom column sums
+                db_rows = ops.new(N, 3 * H)
+                _lib.check(lib.adf_op_message_bwd_fused(h, l, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
+                                                        dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(), None, E,
+                                                        dvec_in.data_ptr() if not first else None, dx_in.data_ptr(),
+                                                        1 if first else 0, db_rows.data_ptr(), s()))
+                if edge_owner is None:   # once per step: the graph and the radial basis are the same for every layer
+                    edge_owner = torch.empty(E, dtype=torch.int32, device=self.dev)
+                    _lib.check(lib.adf_op_edge_owner(h, edge_owner.data_ptr(), E, s()))
+                    rbf_image = torch.empty(int(lib.adf_op_rbf_image_bytes(E)), dtype=torch.uint8, device=self.dev)
+                    _lib.check(lib.adf_op_rbf_image(h, rbf.data_ptr(), E, rbf_image.data_ptr(), s()))
+                sc = ops.scratch(int(lib.adf_op_rbf_wgrad_fused_scratch(h)))
+                _lib.check(lib.adf_op_rbf_wgrad_fused(h, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
+                                                      rbf_image.data_ptr(), edge_owner.data_ptr(), E,
+                                                      G[mp + "rbf_proj.weight"].data_ptr(), sc.data_ptr(), 1 if first else 0, s()))
+                ops.linear_bwd(None, P[mp + "rbf_proj.weight"], db_rows, N, 3 * H, R, None, G[mp + "rbf_proj.bias"],
+                               want_dA=False)
+            elif fused_bwd:
+                drbfh = ops.new(E + 1, 3 * H)  # (+1: the fused kernel's spare row)
                 # drbfh comes back with its columns in the kernel's own order: the weight gradient is formed on that order
                 # and its rows are permuted back (3H x R, tiny)
                 _lib.check(lib.adf_op_message_bwd_fused(h, l, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
                                                         dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(), drbfh.data_ptr(), E,
                                                         dvec_in.data_ptr() if not first else None, dx_in.data_ptr(),
-                                                        1 if first else 0, s()))
+                                                        1 if first else 0, None, s()))
                 dwp = torch.zeros(3 * H, R, dtype=torch.float32, device=self.dev)
                 dbp = torch.zeros(3 * H, dtype=torch.float32, device=self.dev)
                 ops.linear_bwd(rbf, P[mp + "rbf_proj.weight"], drbfh, E, 3 * H, R, dwp, dbp, want_dA=False)
                 G[mp + "rbf_proj.weight"].index_add_(0, self._bwd_perm, dwp)
                 G[mp + "rbf_proj.bias"].index_add_(0, self._bwd_perm, dbp)
             else:
+                drbfh = ops.new(E, 3 * H)
                 _lib.check(lib.adf_op_message_bwd(h, a["xh"].data_ptr(), a["vec"].data_ptr() if not first else None,
                                                   a["rbfh"].data_ptr(), dx1.data_ptr(), dvec1.data_ptr(), dxh.data_ptr(),
                                                   drbfh.data_ptr(), dvec_in.data_ptr() if not first else None,

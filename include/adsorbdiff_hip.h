@@ -358,7 +358,23 @@ int32_t adf_op_message_bwd_fused_supported(adf_painn_t h);
 int32_t adf_op_message_bwd_perm(adf_painn_t h, int32_t* perm_host, int32_t n);
 int32_t adf_op_message_bwd_fused(adf_painn_t h, int32_t layer, const float* xh, const float* vec, const float* gx1,
                                  const float* gv1, float* dxh, float* drbfh_lane_order, int64_t num_edges, float* dvec,
-                                 float* dx, int32_t vec_is_zero, void* stream);
+                                 float* dx, int32_t vec_is_zero, float* dbias_rows, void* stream);
+/* The default since round 5: d(rbfh) never reaches memory.  adf_op_message_bwd_fused is called with drbfh_lane_order = NULL and
+ * dbias_rows = [N, 3H] (it then writes, per atom, the column sums of the atom's d(rbfh) rows - the bias gradient of rbf_proj is
+ * their sum over the atoms - and leaves the packed gradient records of the layer in the handle); adf_op_rbf_wgrad_fused then
+ * ACCUMULATES dW [3H, R] of the layer's rbf_proj (reference row order), forming d(rbfh) again from those records, xh / vec
+ * of the owning atom and the edge geometry while it stages the product (three-term bf16 split, six products, as
+ * adf_op_linear_bwd's weight-gradient kernel).  edge_owner [num_edges] = the atom whose CSR segment holds an edge row
+ * (adf_op_edge_owner, once per graph); rbf_image: adf_op_rbf_image; scratch: adf_op_rbf_wgrad_fused_scratch(h) floats.
+ * Replaces autograd's dW = d(rbfh)^T edge_rbf for models/painn/painn_denoising.py:530-567 (PaiNNMessage.rbf_proj). */
+int32_t adf_op_edge_owner(adf_painn_t h, int32_t* edge_owner, int64_t num_edges, void* stream);
+/* the radial basis [num_edges, num_rbf] (adf_op_rbf) as the three bf16 terms of the product in the kernel's own layout, once per
+ * step (it does not depend on the layer); `image`: adf_op_rbf_image_bytes(num_edges) bytes */
+int64_t adf_op_rbf_image_bytes(int64_t num_edges);
+int32_t adf_op_rbf_image(adf_painn_t h, const float* rbf, int64_t num_edges, void* image, void* stream);
+int64_t adf_op_rbf_wgrad_fused_scratch(adf_painn_t h);
+int32_t adf_op_rbf_wgrad_fused(adf_painn_t h, const float* xh, const float* vec, const void* rbf_image, const int32_t* edge_owner,
+                               int64_t num_edges, float* dW, float* scratch, int32_t vec_is_zero, void* stream);
 int32_t adf_op_vdot_fwd(const float* vv, float* dot, float* nrm, int32_t ldn, int64_t N, int32_t C, float eps, void* stream);
 int32_t adf_op_vdot_bwd(const float* vv, const float* nrm, int32_t ldn, const float* ddot, const float* dnrm, int32_t lddn,
                         const float* dv1, float* dvv, int64_t N, int32_t C, void* stream);

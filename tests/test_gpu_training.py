@@ -168,6 +168,36 @@ def test_fused_message_backward_agrees_with_the_rbfh_reading_backward(monkeypatc
         assert rel_err(grads["fused"][k], g) < 2e-5, (k, rel_err(grads["fused"][k], g))
 
 
+def test_rbf_proj_gradient_without_drbfh_in_memory_equals_the_materialised_path(monkeypatch):
+    """csrc/rbf_wgrad.hip forms d(rbfh) again while it stages the weight-gradient product (the backward then stores nothing per
+    edge); ADF_TRAIN_RBF_WGRAD=materialised is the round-4 path (d(rbfh) [E, 3H] written and read back).  The staged values
+    are computed by the same expressions, the product is the same three-term bf16 split: rbf_proj's weight gradient agrees to
+    fp32 summation order (the edge ranges of the partial sums differ), its bias gradient likewise; the other gradients come from
+    the same arithmetic (bit-identical except where the step sums with atomics, e.g. the embedding rows)."""
+    fx, m, b, targets, tables = _setup()
+    grads = {}
+    for mode in ("materialised", "fused"):
+        monkeypatch.setenv("ADF_TRAIN_RBF_WGRAD", mode)
+        step = PaiNNTrainStep(m, DEV, igso3=tables)
+        assert step.fused_message_backward and step.rbf_wgrad_fused == (mode == "fused")
+        step.zero_grad()
+        step.loss_and_grad(b, targets)
+        grads[mode] = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+    assert set(grads["materialised"]) == set(grads["fused"])
+    worst, same = 0.0, 0
+    for k, g in grads["materialised"].items():
+        if "rbf_proj" in k:
+            assert float(g.norm()) > 0.0, k
+            e = rel_err(grads["fused"][k], g)
+            worst = max(worst, e)
+            assert e < 2e-6, (k, e)
+        else:
+            same += int(torch.equal(grads["fused"][k], g))
+            assert rel_err(grads["fused"][k], g) < 1e-6, (k, rel_err(grads["fused"][k], g))
+    print(f"rbf_proj gradients, fused vs materialised: worst relative difference {worst:.2e}; "
+          f"{same} of {len(grads['fused']) - 4} other gradients bit-identical")
+
+
 def test_fused_adamw_matches_torch_adamw_clip_ema():
     """AdamW + clip_grad_norm_ + EMA in one kernel per tensor == torch.optim.AdamW, torch clip and the EMA mirror."""
     from adsorbdiff_amd.exponential_moving_average import ExponentialMovingAverage
