@@ -68,7 +68,7 @@ struct RbfWgradParams {
 #define RW_ACC(k, a, b)
 #endif
 #ifndef RW_ABL
-#define RW_ABL 0   // timing experiments (wrong results): 1 no gathers, 2 no products, 4 no d(rbfh) conversion / stores, 8 no basis staging
+#define RW_ABL 0   // timing experiments: 1 no gathers, 2 no products, 4 no d(rbfh) conversion / stores, 8 no basis copy (wrong results); 64 no zero-block skipping (right results)
 #endif
 
 // v[0..7] -> three bf16 terms t[0] + t[1] + t[2] = v exactly (24 significant bits), round-to-nearest terms.  The packed conversion
@@ -150,36 +150,42 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
         // thread = (edge row sr, channels c0 + 4 sg .. + 3 and c0 + 32 + 4 sg .. + 3): the 8 lanes of a row read 512 contiguous
         // bytes of each 32-channel record group and one 128-byte line of each xh / vec row per instruction
         const int sr = pt >> 3, sg = pt & 7;
-        const size_t rec_row = (size_t)(H / 32) * 160;
-        const size_t rec_off = (size_t)(2 * slice) * 160 + (size_t)sg * 16;
-        const int cch = c0 + 4 * sg;
+        // uniform bases + 32-bit byte offsets (global_load ... v_off, s[base]): the node tables are < 4 GB (checked by the launcher)
+        const unsigned int rec_row_b = (unsigned int)(H / 32) * 640u, row_b = 12u * (unsigned int)H;
+        const char* rec_b = reinterpret_cast<const char*>(p.rec) + (size_t)(2 * slice) * 640;
+        const unsigned int rec_lane = (unsigned int)sg * 64u;
+        const char* xh_b = reinterpret_cast<const char*>(p.xh) + (size_t)c0 * 4;
+        const char* vec_b = VZ ? nullptr : reinterpret_cast<const char*>(p.vec) + (size_t)c0 * 4;
+        const unsigned int ch_lane = (unsigned int)sg * 16u;
+        const unsigned int Hb = 4u * (unsigned int)H;
         const float inv_sqrt3 = 0.57735026918962576f;
         int srcN = p.N, ownN = 0;
         float4 geoN = make_float4(0.f, 0.f, 0.f, 0.f);
         auto load_meta = [&](int t) {   // rows past the end gather the zero record (row N) and a valid owner
-            const int e = row0(t) + sr, ec = min(e, p.E - 1);
-            const int sv = p.e_src[ec];
+            const int e = row0(t) + sr;
+            const unsigned int ec = (unsigned int)min(e, p.E - 1);
+            const int sv = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.e_src) + 4u * ec);
             srcN = e < p.E ? sv : p.N;
-            ownN = p.owner[ec];
-            geoN = p.e_geom[ec];
+            ownN = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.owner) + 4u * ec);
+            geoN = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.e_geom) + 16u * ec);
         };
         auto request = [&](rw_gather_set& S) {   // gathers of the chunk whose (neighbour, owner, unit vector) are in srcN / ownN / geoN
             S.ux = geoN.x; S.uy = geoN.y; S.uz = geoN.z;
             if (RW_ABL & 1) return;
-            const float4* rp = reinterpret_cast<const float4*>(p.rec + (size_t)srcN * rec_row + rec_off);
+            const unsigned int ro = (unsigned int)srcN * rec_row_b + rec_lane;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) S.g[c] = rp[(c >> 2) * 40 + (c & 3)];   // group c / 4 (160 floats apart), channel 4 sg + c % 4
-            const float* xr = p.xh + (size_t)ownN * 3 * H + cch;
+            for (int c = 0; c < 8; ++c)   // group c / 4 (640 bytes apart), channel 4 sg + c % 4
+                S.g[c] = *reinterpret_cast<const float4*>(rec_b + (ro + (unsigned int)((c >> 2) * 640 + (c & 3) * 16)));
+            const unsigned int oo = (unsigned int)ownN * row_b + ch_lane;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                S.xa[hh] = *reinterpret_cast<const float4*>(xr + 32 * hh);
-                S.xc[hh] = *reinterpret_cast<const float4*>(xr + 2 * H + 32 * hh);
+                S.xa[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 128u * hh));
+                S.xc[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 2u * Hb + 128u * hh));
                 if (!VZ) {
-                    const float* vr = p.vec + (size_t)ownN * 3 * H + cch;
-                    S.xb[hh] = *reinterpret_cast<const float4*>(xr + H + 32 * hh);
-                    S.wx[hh] = *reinterpret_cast<const float4*>(vr + 32 * hh);
-                    S.wy[hh] = *reinterpret_cast<const float4*>(vr + H + 32 * hh);
-                    S.wz[hh] = *reinterpret_cast<const float4*>(vr + 2 * H + 32 * hh);
+                    S.xb[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + Hb + 128u * hh));
+                    S.wx[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + 128u * hh));
+                    S.wy[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + Hb + 128u * hh));
+                    S.wz[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + 2u * Hb + 128u * hh));
                 }
             }
         };
@@ -198,11 +204,11 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
                     const float T = -(gg.x * S.ux + gg.y * S.uy + gg.z * S.uz);
                     vc[k] = T * xcc;
                     vb[k] = 0.f;
-                    if (!VZ) {
-                        const float xbc = k == 0 ? S.xb[hh].x : k == 1 ? S.xb[hh].y : k == 2 ? S.xb[hh].z : S.xb[hh].w;
-                        const float wxc = (k == 0 ? S.wx[hh].x : k == 1 ? S.wx[hh].y : k == 2 ? S.wx[hh].z : S.wx[hh].w) * inv_sqrt3;
-                        const float wyc = (k == 0 ? S.wy[hh].x : k == 1 ? S.wy[hh].y : k == 2 ? S.wy[hh].z : S.wy[hh].w) * inv_sqrt3;
-                        const float wzc = (k == 0 ? S.wz[hh].x : k == 1 ? S.wz[hh].y : k == 2 ? S.wz[hh].z : S.wz[hh].w) * inv_sqrt3;
+                    if (!VZ) {   // (g . vec / sqrt3) xb as (g . vec)(xb / sqrt3): one scaling per channel instead of three
+                        const float xbc = (k == 0 ? S.xb[hh].x : k == 1 ? S.xb[hh].y : k == 2 ? S.xb[hh].z : S.xb[hh].w) * inv_sqrt3;
+                        const float wxc = k == 0 ? S.wx[hh].x : k == 1 ? S.wx[hh].y : k == 2 ? S.wx[hh].z : S.wx[hh].w;
+                        const float wyc = k == 0 ? S.wy[hh].x : k == 1 ? S.wy[hh].y : k == 2 ? S.wy[hh].z : S.wy[hh].w;
+                        const float wzc = k == 0 ? S.wz[hh].x : k == 1 ? S.wz[hh].y : k == 2 ? S.wz[hh].z : S.wz[hh].w;
                         const float Sd = gg.x * wxc + gg.y * wyc + gg.z * wzc;
                         vb[k] = Sd * xbc;
                     }
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // the six products of one (32-column block of d(rbfh)) x (32 basis functions) pair over one 16-row step
-    auto six = [&](f32x16& c, const rw_bf16x8* a, const rw_bf16x8* bq) {
+    auto six = [&](f32x16& c, const rw_bf16x8* a, const rw_bf16x8* bq) __attribute__((always_inline)) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[2], c, 0, 0, 0);
@@ -309,9 +315,9 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
     };
     // D0 / D1: this wave's basis blocks kb / kb + 2 hold a non-zero in this chunk (straight-line code per case, so that the
     // fragment reads of the next pair are issued behind the products of the current one)
-    auto products_case = [&](const unsigned char* imgC, const unsigned char* imgA, auto D0, auto D1) {
-#pragma unroll 1
-        for (int ks = 0; ks < 2; ++ks) {   // (not unrolled: both steps' fragments in flight at once spill beside the accumulators)
+    auto products_case = [&](const unsigned char* imgC, const unsigned char* imgA, auto D0, auto D1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {   // (unrolled: as a loop the compiler copied all 96 accumulator registers around every step)
             const unsigned int koff = 32u * ks + 16u * fkg;
             rw_bf16x8 b0[3], b1[3];
 #pragma unroll
@@ -342,13 +348,14 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
             }
         }
     };
-    auto products = [&](int b) {
+    auto products = [&](int b) __attribute__((always_inline)) {
         const unsigned char* imgC = rw_lds + (size_t)b * RW_BUF;
         const unsigned char* imgA = imgC + 3 * RW_CIMG;
         const unsigned int* nzf = reinterpret_cast<const unsigned int*>(imgC + RW_IMG);
         const unsigned int nzmask = nzf[0];                                   // bit k: basis block k of this chunk holds a non-zero
         const bool do0 = ((nzmask >> kb) & 1u) != 0u, do1 = ((nzmask >> (kb + 2)) & 1u) != 0u;   // wave-uniform
         if (RW_ABL & 2) return;
+        if (RW_ABL & 64) { products_case(imgC, imgA, rw_yes(), rw_yes()); return; }   // no skipping
         if (do0 && do1) products_case(imgC, imgA, rw_yes(), rw_yes());
         else if (do0) products_case(imgC, imgA, rw_yes(), rw_no());
         else if (do1) products_case(imgC, imgA, rw_no(), rw_yes());
@@ -504,6 +511,11 @@ extern "C" int32_t adf_op_rbf_wgrad_fused(adf_painn_t h, const float* xh, const 
         return ADF_EINVAL;
     }
 
+    if ((unsigned long long)(N + 1) * 5ull * H * sizeof(float) >= (1ull << 32) || (unsigned long long)num_edges * 16ull >= (1ull << 32)) {
+        adf_set_error("rbf_wgrad_fused: 32-bit byte offsets into the node / edge tables: N=%d, E=%lld is too large, split the batch", N,
+                      (long long)num_edges);
+        return ADF_EOOM;
+    }
     hipStream_t s = (hipStream_t)stream;
     RbfWgradParams p;
     memset(&p, 0, sizeof(p));
