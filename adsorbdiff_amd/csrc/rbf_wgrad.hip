@@ -11,11 +11,13 @@
 // with (g, gx) the packed gradient records of i (adf_pack_grad_records_kernel) and (xa, xb, xc) = xh[j].  This kernel
 // forms those values while it stages a 32-edge chunk - the same 16-B record gathers as the forward message kernel, served
 // by the XCD's L2 (slice = workgroup index mod 8: one XCD only touches its own 64 channels of the record table) - and runs
-// the product exactly as tr_wgrad_bf16x6_kernel does: both operands split into three bf16 terms, six products, rows staged
-// row-major in LDS and read with the transposing ds_read_b64_tr_b16, all-zero 32-column blocks of the radial basis skipped.
-// A workgroup owns the 192 gradient rows of its slice (a, b, c parts of 64 channels) x all R <= 128 basis functions for one
-// range of edges; the per-range partial results are summed in a fixed order (run-to-run reproducible), directly into the
-// reference's row order.  The values staged are computed by the same expressions as message_bwd.hip's stores were.
+// the product with tr_wgrad_bf16x6_kernel's arithmetic: both operands as three bf16 terms, six products, all-zero 32-column
+// blocks of the radial basis skipped.  A workgroup owns the 192 gradient rows of its slice (a, b, c parts of 64 channels) x
+// all R <= 128 basis functions for its share of the edge rows; the per-workgroup partial results are summed in a fixed
+// order (run-to-run reproducible), directly into the reference's row order.  The values staged are computed by the same
+// expressions as message_bwd.hip's stores were (the 1/sqrt3 of the b part multiplies xb instead of the three vec components).
+// Entry points: adf_op_edge_owner, adf_op_rbf_image (once per step), adf_op_rbf_wgrad_fused (per layer, after
+// adf_op_message_bwd_fused with drbfh = NULL).  Experiment log: profiles/NOTES.md (round 5, training).
 #include <stdlib.h>
 #include <string.h>
 

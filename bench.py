@@ -412,6 +412,7 @@ def main():
     # adsorbate atoms only (the stepper reads nothing else; sampled positions are bit-identical, checked here).
     ads_only = exact_f32 = all_rows = small = traj_sink = None
     if world == 1 and not args.no_secondary:
+        one_pass({"incremental_layers": False})   # untimed: the switch frees the 22 GB of kept layer state
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         sites_full = one_pass({"incremental_layers": False})
@@ -420,9 +421,9 @@ def main():
         all_rows = {"value": total_systems / dt, "unit": "sites/s", "ms_per_step": dt * 1e3,
                     "identical_sites": bool(torch.equal(sites_full, sites)),
                     "note": "denoising_pos_params['incremental_layers']=False: every node row of every layer recomputed "
-                            "at every step, as the reference does; ONE pass, the first after the switch (it also frees the "
-                            "22 GB of kept layer state: ~1 % of the pass), not part of `value` (`--no-incremental` times it "
-                            "like the default, warm-up included)"}
+                            "at every step, as the reference does; one timed pass after one untimed (the first pass after "
+                            "the switch also frees the 22 GB of kept layer state; timed alone it read 192-216 sites/s over "
+                            "the boxes of round 5), not part of `value` (`--no-incremental` times it like the default)"}
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         one_pass({"scores_on_adsorbate_only": None})   # untimed: back to incremental layers (kept state re-allocated)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # round-5 profile set (run on the GPU box): the driver's bench line, rocprofv3 kernel stats of the same command,
 # MfmaUtil / VALUBusy pass, training and EquiformerV2 kernel stats, SQ counters of the message kernel, HBM counters of the
-# training step (-> profiles/train_step_pmc.json), the MFMA/VALU overlap microbenchmark
+# training step (-> profiles/train_step_pmc.json), the training kernels per launch shape, SQ / TCP / TCC counters of the fused
+# rbf_proj weight-gradient kernel, the MFMA/VALU overlap microbenchmark
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run on the GPU box through gpurun)}"; export TMPDIR=/tmp
 o=gpurun_out/r05; rm -rf "$o"; mkdir -p "$o"
@@ -15,6 +16,9 @@ rm -rf gpurun_out/msgpmc
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c -d $o/train_hbm/$c -o p --output-format csv -- python3 bench.py --mode train --steps 1 --warmup 1 > $o/train_hbm_$c.log 2>&1
 done
+rocprofv3 --kernel-trace -d $o/train_trace -o t --output-format csv -- python3 bench.py --mode train --steps 2 --warmup 1 > /dev/null 2>&1
+python3 profiles/scripts/trace_by_grid.py $o/train_trace 40 > $o/train_kernels_by_launch_shape.txt; rm -rf $o/train_trace
+bash profiles/scripts/rw_pmc.sh > $o/rbf_wgrad_counters.txt 2>&1; rm -rf gpurun_out/rwpmc
 (cd profiles/scripts && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize mfma_valu_overlap.hip -o /tmp/overlap 2>/dev/null && /tmp/overlap) > $o/mfma_valu_overlap.txt 2>&1
 find $o -name "*agent_info.csv" -delete
 python3 - <<'PY'
