@@ -1,3 +1,13 @@
+// RETIRED EXPERIMENT (round 5), kept for the record; not built.  The "octet" layout of csrc/rbf_wgrad.hip: a producer wave owns
+// the edge rows 8 w .. 8 w + 7 of every chunk and lane = channel, so that a row's (neighbour, owner, unit vector) are
+// wave-uniform (scalar loads), every gather instruction reads two full 512-byte record groups, the owner's xh / vec rows are
+// read once per OWNER (an octet has one or two; rows of a third one are zeroed, their chunk flagged and replayed behind the
+// main loop), d(rbfh) is staged column-major (8 rows of a column = one ds_write_b128; fragments by plain ds_read_b128).
+// Measured 8.1-9.2 ms per launch at 256 graphs against 6.5 ms of the thread = (edge row, 8 channels) layout it was meant to
+// beat (5.3 ms in its final form): SQ_INSTS_VALU 865 per SIMD and chunk against 570 - 350 scalar instructions of bookkeeping
+// per chunk, the lane <-> scalar moves of spilled SGPRs (v_readlane / v_writelane are vector-issue slots) and the per-row
+// owner selection cost more vector-issue time than the coalescing saved, and the kernel is bound by vector issue + MFMA, not
+// by memory.  See profiles/NOTES.md (round 5, training).
 // Weight (and bias) gradient of a message block's rbf_proj for the training step (BASELINE config 5) WITHOUT
 // the per-edge gradient d(rbfh) [E, 3H] in memory.
 //
