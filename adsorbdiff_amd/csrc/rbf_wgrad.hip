@@ -40,6 +40,8 @@ struct RbfWgradParams {
     const int32_t* owner;    // atom j whose CSR segment holds row e
     const float4* e_geom;    // (unit vector, distance) of row e
     float* part;             // [splits][3H x R] partial gradients, reference row order
+    const float* lift;          // RW_F16: [3][H] power-of-two lift of a d(rbfh) column (part b: x 1/sqrt3); null otherwise
+    const float* unlift;        // RW_F16: [3][H] 1 / (lift x 2^14): what an accumulator row is multiplied by
     unsigned long long* prof;   // RW_PROF builds only: [workgroup][8] cycle sums
     int E, N, H, R, workers, nslices;   // workers: workgroups per slice (= edge-range partial results)
 };
@@ -52,11 +54,16 @@ struct RbfWgradParams {
 // is one ds_read_b128; it arrives in that layout from rw_basis_image_kernel.
 #define RW_CROW 512
 #define RW_COLB 80
+#ifndef RW_F16
+#define RW_F16 1   // 1: both operands as TWO fp16 terms (hi + lo), three products, d(rbfh) lifted per column by a power of two, the
+                   //    basis by 2^14 (the arithmetic of every other product of the step); 0: three bf16 terms, six products, no lifts
+#endif
+#define RW_NT (RW_F16 ? 2 : 3)                  // terms per operand
 #define RW_CIMG (32 * RW_CROW)                  // one term of d(rbfh)
 #define RW_AIMG (128 * RW_COLB)                 // one term of the radial basis
-#define RW_IMG (3 * (RW_CIMG + RW_AIMG))
+#define RW_IMG (RW_NT * (RW_CIMG + RW_AIMG))
 #define RW_BUF (RW_IMG + 64)                    // + the chunk's mask of non-zero 32-column basis blocks
-#define RW_IMG_CHUNK (3 * 4 * 128 * 16)         // global image of the basis: [chunk][term][row octet][column][8 rows] bf16
+#define RW_IMG_CHUNK (RW_NT * 4 * 128 * 16)     // global image of the basis: [chunk][term][row octet][column][8 rows] 16-bit
 #define RW_THREADS 512
 #define RW_MINI 8      // chunks per mini-range of the sweep
 #ifndef RW_PROF
@@ -70,32 +77,42 @@ struct RbfWgradParams {
 #define RW_ACC(k, a, b)
 #endif
 #ifndef RW_ABL
-#define RW_ABL 0   // timing experiments: 1 no gathers, 2 no products, 4 no d(rbfh) conversion / stores, 8 no basis copy (wrong results); 64 no zero-block skipping (right results)
+#define RW_ABL 0   // timing experiments: 1 no gathers, 2 no products, 4 no d(rbfh) conversion / stores, 8 no basis copy, 128 owner rows of atom 0, 256 records of atom 0 (wrong results); 64 no zero-block skipping (right results)
 #endif
 
-// v[0..7] -> three bf16 terms t[0] + t[1] + t[2] = v exactly (24 significant bits), round-to-nearest terms.  The packed conversion
-// of a pair is reused for the residuals (low half << 16, high half masked): 5.5 vector instructions per value.
+// v[0..N-1] -> RW_NT 16-bit terms, packed pairs o[term][pair].
+//  RW_F16: hi = round-to-zero fp16 (one packed conversion per pair), lo = fp16(v - hi) (mixed-precision subtraction): 2 vector
+//          instructions per value, 22 significant bits while v stays inside fp16's normal range (the lifts see to that);
+//  else:   three bf16 terms t0 + t1 + t2 = v exactly (24 bits), round-to-nearest; the packed conversion of a pair is reused for
+//          the residuals (low half << 16, high half masked): 5.5 vector instructions per value.
 typedef float rw_f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 rw_bf16x2 __attribute__((ext_vector_type(2)));
-template <int N> struct rw_bfvec;
-template <> struct rw_bfvec<8> { typedef rw_bf16x8 type; };
-template <> struct rw_bfvec<4> { typedef rw_bf16x4 type; };
+typedef __fp16 rw_h2 __attribute__((ext_vector_type(2)));
 template <int N>
-__device__ __forceinline__ void rw_split3(float* v, typename rw_bfvec<N>::type* t) {
-    union { typename rw_bfvec<N>::type b; unsigned int u[N / 2]; } o[3];
+__device__ __forceinline__ void rw_split(float* v, unsigned int (*o)[N / 2]) {
+#if RW_F16
+#pragma unroll
+    for (int e = 0; e < N; e += 2) {
+        union { rw_h2 h; unsigned int u; } hi, lo;
+        hi.h = __builtin_amdgcn_cvt_pkrtz(v[e], v[e + 1]);
+        lo.h = __builtin_amdgcn_cvt_pkrtz(v[e] - (float)hi.h[0], v[e + 1] - (float)hi.h[1]);
+        o[0][e >> 1] = hi.u;
+        o[1][e >> 1] = lo.u;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int e = 0; e < N; e += 2) {
             union { rw_bf16x2 b; unsigned int u; } pk;
             pk.b = __builtin_convertvector((rw_f32x2){v[e], v[e + 1]}, rw_bf16x2);
-            o[k].u[e >> 1] = pk.u;
+            o[k][e >> 1] = pk.u;
             if (k < 2) {
                 v[e] -= __uint_as_float(pk.u << 16);
                 v[e + 1] -= __uint_as_float(pk.u & 0xffff0000u);
             }
         }
-    t[0] = o[0].b; t[1] = o[1].b; t[2] = o[2].b;
+#endif
 }
 
 struct rw_yes { static const bool value = true; };
@@ -112,7 +129,7 @@ struct rw_gather_set {
     float ux, uy, uz;
 };
 typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
-struct rw_basis_set { rw_u32x4 q[2][3]; int mask; };
+struct rw_basis_set { rw_u32x4 q[2][RW_NT]; int mask; };
 
 // Waves 4-7 PRODUCE: producer thread (edge row sr, 8 channels) gathers the neighbour's packed gradients and the owner's xh / vec
 // rows, forms the three parts of d(rbfh), splits them into three bf16 terms and writes them into LDS buffer h & 1; it also
@@ -161,6 +178,14 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
         const unsigned int ch_lane = (unsigned int)sg * 16u;
         const unsigned int Hb = 4u * (unsigned int)H;
         const float inv_sqrt3 = 0.57735026918962576f;
+        float la[8], lb[8], lc[8];   // column lifts of this thread's 8 channels (part b: x 1/sqrt3)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ch = c0 + 32 * (c >> 2) + 4 * sg + (c & 3);
+            la[c] = RW_F16 ? p.lift[ch] : 1.0f;
+            lb[c] = RW_F16 ? p.lift[H + ch] : inv_sqrt3;
+            lc[c] = RW_F16 ? p.lift[2 * H + ch] : 1.0f;
+        }
         int srcN = p.N, ownN = 0;
         float4 geoN = make_float4(0.f, 0.f, 0.f, 0.f);
         auto load_meta = [&](int t) {   // rows past the end gather the zero record (row N) and a valid owner
@@ -171,43 +196,44 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
             ownN = *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(p.owner) + 4u * ec);
             geoN = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.e_geom) + 16u * ec);
         };
-        auto request = [&](rw_gather_set& S) {   // gathers of the chunk whose (neighbour, owner, unit vector) are in srcN / ownN / geoN
-            S.ux = geoN.x; S.uy = geoN.y; S.uz = geoN.z;
+        // gathers of the chunk whose (neighbour, owner, unit vector) are in srcN / ownN / geoN, one half of the thread's channels at
+        // a time: each half is requested right behind the staging of the same registers' previous contents, so the 26 loads of
+        // a chunk are spread over the staging instead of arriving at the texture addresser in one burst
+        auto request_half = [&](rw_gather_set& S, int hh) {
+            if (hh == 0) { S.ux = geoN.x; S.uy = geoN.y; S.uz = geoN.z; }
             if (RW_ABL & 1) return;
-            const unsigned int ro = (unsigned int)srcN * rec_row_b + rec_lane;
+            const unsigned int ro = (unsigned int)((RW_ABL & 256) ? 0 : srcN) * rec_row_b + rec_lane;   // (256: every row gathers atom 0's record)
 #pragma unroll
-            for (int c = 0; c < 8; ++c)   // group c / 4 (640 bytes apart), channel 4 sg + c % 4
-                S.g[c] = *reinterpret_cast<const float4*>(rec_b + (ro + (unsigned int)((c >> 2) * 640 + (c & 3) * 16)));
-            const unsigned int oo = (unsigned int)ownN * row_b + ch_lane;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                S.xa[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 128u * hh));
-                S.xc[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 2u * Hb + 128u * hh));
-                if (!VZ) {
-                    S.xb[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + Hb + 128u * hh));
-                    S.wx[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + 128u * hh));
-                    S.wy[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + Hb + 128u * hh));
-                    S.wz[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + 2u * Hb + 128u * hh));
-                }
+            for (int k = 0; k < 4; ++k)   // group hh (640 bytes apart), channel 4 sg + k
+                S.g[4 * hh + k] = *reinterpret_cast<const float4*>(rec_b + (ro + (unsigned int)(hh * 640 + k * 16)));
+            const unsigned int oo = (unsigned int)((RW_ABL & 128) ? 0 : ownN) * row_b + ch_lane;   // (128: every row reads atom 0's rows)
+            S.xa[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 128u * hh));
+            S.xc[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 2u * Hb + 128u * hh));
+            if (!VZ) {
+                S.xb[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + Hb + 128u * hh));
+                S.wx[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + 128u * hh));
+                S.wy[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + Hb + 128u * hh));
+                S.wz[hh] = *reinterpret_cast<const float4*>(vec_b + (oo + 2u * Hb + 128u * hh));
             }
         };
-        auto stage = [&](rw_gather_set& S, int b) {   // d(rbfh) of this thread's row and 8 channels -> three bf16 terms in buffer b
+        // d(rbfh) of this thread's row and 4 of its 8 channels -> the terms' images in buffer b (u: the row's unit vector, read
+        // before the first half's request overwrites it)
+        auto stage_half = [&](rw_gather_set& S, int b, int hh, float ux, float uy, float uz) {
             if (RW_ABL & 4) { if (S.g[0].x == 123.f && S.xa[0].x == 1.f) rw_lds[tid] = 1; return; }
             unsigned char* imgC = rw_lds + (size_t)b * RW_BUF;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            {
                 float va[4], vb[4], vc[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float4 gg = S.g[4 * hh + k];
                     const float xac = k == 0 ? S.xa[hh].x : k == 1 ? S.xa[hh].y : k == 2 ? S.xa[hh].z : S.xa[hh].w;
                     const float xcc = k == 0 ? S.xc[hh].x : k == 1 ? S.xc[hh].y : k == 2 ? S.xc[hh].z : S.xc[hh].w;
-                    va[k] = gg.w * xac;
-                    const float T = -(gg.x * S.ux + gg.y * S.uy + gg.z * S.uz);
-                    vc[k] = T * xcc;
+                    va[k] = gg.w * (RW_F16 ? xac * la[4 * hh + k] : xac);
+                    const float T = -(gg.x * ux + gg.y * uy + gg.z * uz);
+                    vc[k] = T * (RW_F16 ? xcc * lc[4 * hh + k] : xcc);
                     vb[k] = 0.f;
                     if (!VZ) {   // (g . vec / sqrt3) xb as (g . vec)(xb / sqrt3): one scaling per channel instead of three
-                        const float xbc = (k == 0 ? S.xb[hh].x : k == 1 ? S.xb[hh].y : k == 2 ? S.xb[hh].z : S.xb[hh].w) * inv_sqrt3;
+                        const float xbc = (k == 0 ? S.xb[hh].x : k == 1 ? S.xb[hh].y : k == 2 ? S.xb[hh].z : S.xb[hh].w) * lb[4 * hh + k];
                         const float wxc = k == 0 ? S.wx[hh].x : k == 1 ? S.wx[hh].y : k == 2 ? S.wx[hh].z : S.wx[hh].w;
                         const float wyc = k == 0 ? S.wy[hh].x : k == 1 ? S.wy[hh].y : k == 2 ? S.wy[hh].z : S.wy[hh].w;
                         const float wzc = k == 0 ? S.wz[hh].x : k == 1 ? S.wz[hh].y : k == 2 ? S.wz[hh].z : S.wz[hh].w;
@@ -221,10 +247,10 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
                     float* v = part == 0 ? va : part == 1 ? vb : vc;
                     // image column 64 part + 32 hh + 4 sg: 16-byte piece 8 part + 4 hh + sg / 2, half sg % 2
                     const unsigned int off = RW_CROW * sr + 16u * ((unsigned int)(8 * part + 4 * hh + (sg >> 1)) ^ rw_swz(sr)) + 8u * (sg & 1);
-                    rw_bf16x4 tt[3];
-                    rw_split3<4>(v, tt);
+                    unsigned int tt[RW_NT][2];
+                    rw_split<4>(v, tt);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) *reinterpret_cast<rw_bf16x4*>(imgC + (size_t)t * RW_CIMG + off) = tt[t];
+                    for (int t = 0; t < RW_NT; ++t) *reinterpret_cast<uint2*>(imgC + (size_t)t * RW_CIMG + off) = make_uint2(tt[t][0], tt[t][1]);
                 }
             }
         };
@@ -238,18 +264,18 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int tm = 0; tm < 3; ++tm)
+                for (int tm = 0; tm < RW_NT; ++tm)
                     B.q[k][tm] = *reinterpret_cast<const rw_u32x4*>(src + (size_t)tm * 8192 + (size_t)(boct + 2 * k) * 2048);
             B.mask = mask_c[gc];
         };
         auto stage_basis = [&](rw_basis_set& B, int b) {
             if (RW_ABL & 8) { if (B.q[0][0][0] == 123u) rw_lds[tid] = 1; return; }
-            unsigned char* imgA = rw_lds + (size_t)b * RW_BUF + 3 * RW_CIMG;
+            unsigned char* imgA = rw_lds + (size_t)b * RW_BUF + RW_NT * RW_CIMG;
             unsigned int* nzf = reinterpret_cast<unsigned int*>(rw_lds + (size_t)b * RW_BUF + RW_IMG);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int tm = 0; tm < 3; ++tm)
+                for (int tm = 0; tm < RW_NT; ++tm)
                     *reinterpret_cast<rw_u32x4*>(imgA + (size_t)tm * RW_AIMG + (size_t)bcol * RW_COLB + 16 * (boct + 2 * k)) = B.q[k][tm];
             if (tid == 256) nzf[0] = (unsigned int)B.mask;
         };
@@ -266,9 +292,15 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
         for (int h = 0;; h += 2) {
             if (h - 2 >= nchunks) break;
             RW_T(t0);
-            if (h >= 2) { stage(S0, 0); stage_basis(B0, 0); }
+            {
+                const float ux = S0.ux, uy = S0.uy, uz = S0.uz;
+                if (h >= 2) stage_half(S0, 0, 0, ux, uy, uz);
+                request_half(S0, 0);
+                if (h >= 2) stage_half(S0, 0, 1, ux, uy, uz);
+                request_half(S0, 1);
+                if (h >= 2) stage_basis(B0, 0);
+            }
             RW_T(t1);
-            request(S0);
             request_basis(B0, h);
             load_meta(h + 1);
             RW_T(t2);
@@ -276,9 +308,15 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
             RW_T(t3);
             RW_ACC(0, t0, t1); RW_ACC(1, t1, t2); RW_ACC(2, t2, t3);
             if (h - 1 >= nchunks) break;
-            if (h >= 2) { stage(S1, 1); stage_basis(B1, 1); }
+            {
+                const float ux = S1.ux, uy = S1.uy, uz = S1.uz;
+                if (h >= 2) stage_half(S1, 1, 0, ux, uy, uz);
+                request_half(S1, 0);
+                if (h >= 2) stage_half(S1, 1, 1, ux, uy, uz);
+                request_half(S1, 1);
+                if (h >= 2) stage_basis(B1, 1);
+            }
             RW_T(t4);
-            request(S1);
             request_basis(B1, h + 1);
             load_meta(h + 2);
             RW_T(t5);
@@ -306,14 +344,27 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // the six products of one (32-column block of d(rbfh)) x (32 basis functions) pair over one 16-row step
-    auto six = [&](f32x16& c, const rw_bf16x8* a, const rw_bf16x8* bq) __attribute__((always_inline)) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bq[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bq[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[0], c, 0, 0, 0);
+    // the products of one (32-column block of d(rbfh)) x (32 basis functions) pair over one 16-row step: lo x hi, hi x lo,
+    // hi x hi (fp16 terms) or the six products of order <= 2^-16 of the three-term bf16 split
+    auto multiply = [&](f32x16& c, const rw_u32x4* a, const rw_u32x4* bq) __attribute__((always_inline)) {
+#if RW_F16
+        typedef _Float16 rw_half8 __attribute__((ext_vector_type(8)));
+        const rw_half8 ah = __builtin_bit_cast(rw_half8, a[0]), al = __builtin_bit_cast(rw_half8, a[1]);
+        const rw_half8 bh = __builtin_bit_cast(rw_half8, bq[0]), bl = __builtin_bit_cast(rw_half8, bq[1]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+#else
+        rw_bf16x8 x[3], y[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { x[t] = __builtin_bit_cast(rw_bf16x8, a[t]); y[t] = __builtin_bit_cast(rw_bf16x8, bq[t]); }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[2], y[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1], y[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0], y[0], c, 0, 0, 0);
+#endif
     };
     // D0 / D1: this wave's basis blocks kb / kb + 2 hold a non-zero in this chunk (straight-line code per case, so that the
     // fragment reads of the next pair are issued behind the products of the current one)
@@ -321,21 +372,21 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {   // (unrolled: as a loop the compiler copied all 96 accumulator registers around every step)
             const unsigned int koff = 32u * ks + 16u * fkg;
-            rw_bf16x8 b0[3], b1[3];
+            rw_u32x4 b0[RW_NT], b1[RW_NT];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                if (D0.value) b0[t] = *reinterpret_cast<const rw_bf16x8*>(imgA + (size_t)t * RW_AIMG + (size_t)(32 * kb + fm) * RW_COLB + koff);
-                if (D1.value) b1[t] = *reinterpret_cast<const rw_bf16x8*>(imgA + (size_t)t * RW_AIMG + (size_t)(32 * (kb + 2) + fm) * RW_COLB + koff);
+            for (int t = 0; t < RW_NT; ++t) {
+                if (D0.value) b0[t] = *reinterpret_cast<const rw_u32x4*>(imgA + (size_t)t * RW_AIMG + (size_t)(32 * kb + fm) * RW_COLB + koff);
+                if (D1.value) b1[t] = *reinterpret_cast<const rw_u32x4*>(imgA + (size_t)t * RW_AIMG + (size_t)(32 * (kb + 2) + fm) * RW_COLB + koff);
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int bi = 3 * cgp + i;           // 32-column block of the slice's 192: part = bi / 2
                 if (VZ && (bi >> 1) == 1) continue;
-                rw_bf16x8 a[3];
+                rw_u32x4 a[RW_NT];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {   // rows 16 ks + 8 kg + (0..7) of the 16 columns that hold this lane's column
+                for (int t = 0; t < RW_NT; ++t) {   // rows 16 ks + 8 kg + (0..7) of the 16 columns that hold this lane's column
                     const int col = 32 * bi + 16 * cgrp + 4 * tp;
-                    union { rw_fp16x4 h[2]; rw_bf16x8 b; } u;
+                    union { rw_fp16x4 h[2]; rw_u32x4 b; } u;
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
                         const int row = 16 * ks + 8 * kg + 4 * hh + tq;
@@ -345,14 +396,14 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
                     }
                     a[t] = u.b;
                 }
-                if (D0.value) six(acc[i][0], a, b0);
-                if (D1.value) six(acc[i][1], a, b1);
+                if (D0.value) multiply(acc[i][0], a, b0);
+                if (D1.value) multiply(acc[i][1], a, b1);
             }
         }
     };
     auto products = [&](int b) __attribute__((always_inline)) {
         const unsigned char* imgC = rw_lds + (size_t)b * RW_BUF;
-        const unsigned char* imgA = imgC + 3 * RW_CIMG;
+        const unsigned char* imgA = imgC + RW_NT * RW_CIMG;
         const unsigned int* nzf = reinterpret_cast<const unsigned int*>(imgC + RW_IMG);
         const unsigned int nzmask = nzf[0];                                   // bit k: basis block k of this chunk holds a non-zero
         const bool do0 = ((nzmask >> kb) & 1u) != 0u, do1 = ((nzmask >> (kb + 2)) & 1u) != 0u;   // wave-uniform
@@ -398,7 +449,7 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
             for (int r = 0; r < 16; ++r) {
                 const int cc = 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int row = (cc >> 6) * H + c0 + (cc & 63);
-                if (col < R) out[(size_t)row * R + col] = acc[i][j][r];
+                if (col < R) out[(size_t)row * R + col] = RW_F16 ? acc[i][j][r] * p.unlift[row] : acc[i][j][r];
             }
         }
     }
@@ -436,11 +487,16 @@ __global__ __launch_bounds__(256) void rw_basis_image_kernel(const float* __rest
             nz = nz || v[r] != 0.f;
         }
         if (nz) blk[col >> 5] = 1u;
-        rw_bf16x8 tt[3];
-        rw_split3<8>(v, tt);
+        if (RW_F16) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-            *reinterpret_cast<rw_bf16x8*>(img + (size_t)c * RW_IMG_CHUNK + (size_t)t * 8192 + (size_t)oct * 2048 + (size_t)col * 16) = tt[t];
+            for (int r = 0; r < 8; ++r) v[r] *= 16384.0f;   // exact; basis values down to 2^-28 keep an fp16-normal hi term
+        }
+        unsigned int tt[RW_NT][4];
+        rw_split<8>(v, tt);
+#pragma unroll
+        for (int t = 0; t < RW_NT; ++t)
+            *reinterpret_cast<uint4*>(img + (size_t)c * RW_IMG_CHUNK + (size_t)t * 8192 + (size_t)oct * 2048 + (size_t)col * 16) =
+                make_uint4(tt[t][0], tt[t][1], tt[t][2], tt[t][3]);
     }
     __syncthreads();
     if (tid == 0)
@@ -459,6 +515,54 @@ extern "C" int32_t adf_op_rbf_image(adf_painn_t h, const float* rbf, int64_t num
                        h->hp.num_rbf, reinterpret_cast<unsigned char*>(image), chunks);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
+}
+
+// Column lifts of d(rbfh) (RW_F16).  The contraction runs along the EDGES, so a power of two per COLUMN factors out of the sum.
+// The columns' maxima are bounded from the node tables instead of from the 16 GB the kernel never writes:
+//   |d_a[e,c]| <= max_i |gx[i,c]| max_j |xa[j,c]|,   |d_b| <= sum_d max|g_d| max|vec_d| / sqrt3 max|xb|,   |d_c| <= sum_d max|g_d| max|xc|
+// (|u_d| <= 1).  rw_colmax_kernel: maxima of the 10 node-table columns per channel (|.| as unsigned bits, atomicMax);
+// rw_lifts_kernel: lift = 2^(13 - floor(log2 bound)) so that every lifted value is below 2^14, unlift = 1 / (lift x 2^14)
+// (2^14: the basis' own scale).  A value 2^-24 of its column's bound still has an fp16-normal hi term.
+__global__ __launch_bounds__(256) void rw_colmax_kernel(const float* __restrict__ rec, const float* __restrict__ xh,
+                                                        const float* __restrict__ vec, int N, int H, int rows_per_block,
+                                                        unsigned int* __restrict__ mx) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    const int n0 = blockIdx.y * rows_per_block, n1 = min(N, n0 + rows_per_block);
+    const size_t rec_row = (size_t)(H / 32) * 160, rec_off = (size_t)(c >> 5) * 160 + (size_t)(c & 31) * 4;
+    float m[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int n = n0; n < n1; ++n) {
+        const float4 g = *reinterpret_cast<const float4*>(rec + (size_t)n * rec_row + rec_off);
+        const float* xr = xh + (size_t)n * 3 * H + c;
+        m[0] = fmaxf(m[0], fabsf(g.x)); m[1] = fmaxf(m[1], fabsf(g.y)); m[2] = fmaxf(m[2], fabsf(g.z)); m[3] = fmaxf(m[3], fabsf(g.w));
+        m[4] = fmaxf(m[4], fabsf(xr[0])); m[5] = fmaxf(m[5], fabsf(xr[H])); m[6] = fmaxf(m[6], fabsf(xr[2 * H]));
+        if (vec) {
+            const float* vr = vec + (size_t)n * 3 * H + c;
+            m[7] = fmaxf(m[7], fabsf(vr[0])); m[8] = fmaxf(m[8], fabsf(vr[H])); m[9] = fmaxf(m[9], fabsf(vr[2 * H]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) atomicMax(&mx[(size_t)k * H + c], __float_as_uint(m[k]));
+}
+
+__global__ void rw_lifts_kernel(const unsigned int* __restrict__ mx, int H, float* __restrict__ lift, float* __restrict__ unlift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    float m[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m[k] = __uint_as_float(mx[(size_t)k * H + c]);
+    const float inv_sqrt3 = 0.57735026918962576f;
+    const float bound[3] = {m[3] * m[4], (m[0] * m[7] + m[1] * m[8] + m[2] * m[9]) * inv_sqrt3 * m[5], (m[0] + m[1] + m[2]) * m[6]};
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        const float b = bound[part];
+        int e = (b > 0.f && b < 3.0e38f) ? 13 - ilogbf(b) : 0;      // b x 2^e in [2^13, 2^14)
+        e = max(-100, min(100, e));
+        const float l = ldexpf(1.0f, e);
+        lift[part * H + c] = part == 1 ? l * inv_sqrt3 : l;            // part b: the 1/sqrt3 of the value rides on the lift
+        unlift[part * H + c] = ldexpf(1.0f, -e - 14);
+    }
 }
 
 // owner[e] = the atom whose CSR segment holds edge row e (binary search over nptr)
@@ -494,7 +598,7 @@ static int rw_splits(const adf_painn* h, int nslices) {   // workgroups per slic
 extern "C" int64_t adf_op_rbf_wgrad_fused_scratch(adf_painn_t h) {
     if (!h) return 0;
     const int H = h->hp.hidden_channels, R = h->hp.num_rbf;
-    return (int64_t)rw_splits(h, H / ADF_SLICE_CH) * ((int64_t)3 * H * R);
+    return (int64_t)rw_splits(h, H / ADF_SLICE_CH) * ((int64_t)3 * H * R) + 16 * (int64_t)H + 64;   // partial gradients + maxima, lifts
 }
 
 // dW [3H, R] of the layer's rbf_proj is ACCUMULATED (the bias gradient: message_bwd.hip's per-atom column sums).  Uses the gradient records the preceding
@@ -526,6 +630,19 @@ extern "C" int32_t adf_op_rbf_wgrad_fused(adf_painn_t h, const float* xh, const 
     int splits = rw_splits(h, p.nslices);
     p.workers = splits;
     p.part = scratch;
+#if RW_F16
+    {   // column lifts of this layer's d(rbfh): maxima of the node tables -> powers of two
+        float* lifts = scratch + (size_t)splits * 3 * H * R;
+        unsigned int* mx = reinterpret_cast<unsigned int*>(lifts + 6 * (size_t)H);
+        ADF_HIP_CHECK(hipMemsetAsync(mx, 0, sizeof(unsigned int) * 10 * (size_t)H, s));
+        const int row_blocks = 2 * h->num_cus, rows_per_block = (N + row_blocks - 1) / row_blocks;
+        hipLaunchKernelGGL(rw_colmax_kernel, dim3((unsigned)((H + 255) / 256), (unsigned)row_blocks), dim3(256), 0, s, h->rec, xh,
+                           vec_is_zero ? (const float*)nullptr : vec, N, H, rows_per_block, mx);
+        hipLaunchKernelGGL(rw_lifts_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, s, mx, H, lifts, lifts + 3 * (size_t)H);
+        p.lift = lifts;
+        p.unlift = lifts + 3 * (size_t)H;
+    }
+#endif
     const dim3 grid((unsigned)(splits * p.nslices));
     static bool attr_set = false;  // per process and device: training runs on one device per process
     if (!attr_set) {
