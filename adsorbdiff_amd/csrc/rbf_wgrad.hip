@@ -11,8 +11,12 @@
 // with (g, gx) the packed gradient records of i (adf_pack_grad_records_kernel) and (xa, xb, xc) = xh[j].  This kernel
 // forms those values while it stages a 32-edge chunk - the same 16-B record gathers as the forward message kernel, served
 // by the XCD's L2 (slice = workgroup index mod 8: one XCD only touches its own 64 channels of the record table) - and runs
-// the product with tr_wgrad_bf16x6_kernel's arithmetic: both operands as three bf16 terms, six products, all-zero 32-column
-// blocks of the radial basis skipped.  A workgroup owns the 192 gradient rows of its slice (a, b, c parts of 64 channels) x
+// the product on the f16-rate matrix cores with all-zero 32-column blocks of the radial basis skipped.  Arithmetic (RW_F16, the
+// default): both operands as TWO fp16 terms (hi + lo, 22 bits), three products - the arithmetic of the step's other
+// products; the contraction runs along the edges, so a power-of-two lift per COLUMN of d(rbfh) factors out of the sum, and
+// the columns' maxima are bounded from the node tables (rw_colmax_kernel) instead of from the tensor that is never written;
+// the basis is scaled by 2^14.  RW_F16=0: tr_wgrad_bf16x6_kernel's three bf16 terms, six products, no lifts (5.3 ms per
+// launch at 256 graphs against 3.6).  A workgroup owns the 192 gradient rows of its slice (a, b, c parts of 64 channels) x
 // all R <= 128 basis functions for its share of the edge rows; the per-workgroup partial results are summed in a fixed
 // order (run-to-run reproducible), directly into the reference's row order.  The values staged are computed by the same
 // expressions as message_bwd.hip's stores were (the 1/sqrt3 of the b part multiplies xb instead of the three vec components).
@@ -35,7 +39,7 @@ struct RbfWgradParams {
     const float* rec;        // gradient records [(N+1)][H/32][160]: [32 x (g0, g1, g2, gx)] + [32 unused]; row N zero
     const float* xh;         // [N, 3H]
     const float* vec;        // [N, 3, H] or null (first layer)
-    const unsigned char* img;   // radial basis as three bf16 terms in the kernel's LDS layout (rw_basis_image_kernel), + masks
+    const unsigned char* img;   // radial basis as the product's RW_NT terms in the kernel's LDS layout (rw_basis_image_kernel), + masks
     const int32_t* e_src;    // neighbour i of edge row e
     const int32_t* owner;    // atom j whose CSR segment holds row e
     const float4* e_geom;    // (unit vector, distance) of row e
@@ -132,15 +136,17 @@ typedef unsigned int rw_u32x4 __attribute__((ext_vector_type(4)));
 struct rw_basis_set { rw_u32x4 q[2][RW_NT]; int mask; };
 
 // Waves 4-7 PRODUCE: producer thread (edge row sr, 8 channels) gathers the neighbour's packed gradients and the owner's xh / vec
-// rows, forms the three parts of d(rbfh), splits them into three bf16 terms and writes them into LDS buffer h & 1; it also
+// rows, forms the three parts of d(rbfh), lifts and splits them (RW_NT terms) and writes them into LDS buffer h & 1; it also
 // copies the chunk's radial-basis image (already split, rw_basis_image_kernel) into that buffer.  Waves 0-3 CONSUME the other
 // buffer: 96 accumulator registers each, nothing else to do.  One barrier per chunk.  Every request is TWO chunks ahead of
 // its use in two alternating register sets (the producers hold no accumulators), the edge rows' (neighbour, owner, unit
 // vector) one chunk before that.
 //
 // What bounds it (profiles/r05_rbf_wgrad_*): on a SIMD the producer's vector instructions (4 cycles each) and the consumer's
-// MFMAs (32 cycles each) ADD - per 32-edge chunk ~55 MFMAs (of 72: all-zero basis blocks are skipped) + the split's ~5.5
-// instructions per value.  Not memory: the records and owner rows are L2 hits, the launch reads ~3 GB from HBM.
+// MFMAs (32 cycles each) ADD - per 32-edge chunk 307 vector instructions + 28 MFMAs (of 36: all-zero basis blocks are
+// skipped) = 2 100 cycles - and the CU's vector-memory path moves ~100 KB per chunk (32 KB of records, 48 KB of owner rows,
+// 16 KB of basis image: ~1 600 cycles at 64 B per clock), which is why the requests are spread over the staging.  3 200
+// cycles per chunk measured.
 //
 // Measured on the way here (256 graphs, per launch; the kernel that read d(rbfh) from memory took 5.2 ms and its producer,
 // message_bwd, 3.0 ms longer): one role per wave and requests at the top of the chunk 6.7 ms (two dependent round trips);
@@ -148,7 +154,10 @@ struct rw_basis_set { rw_u32x4 q[2][RW_NT]; int mask; };
 // and with it the prefetch; producer / consumer waves, requests one chunk ahead 8.5 ms (a request issued at the end of a
 // chunk has only the barrier wait to land); two chunks ahead 6.5 ms; wave = row octet and lane = channel with wave-uniform
 // rows (coalesced gathers, column-major d(rbfh), owner rows once per owner: scratch/experiments/rbf_wgrad_octet.hip)
-// 8.1-9.2 ms - the scalar bookkeeping and lane<->scalar moves cost more vector-issue slots than the coalescing saved.
+// 8.1-9.2 ms - the scalar bookkeeping and lane<->scalar moves cost more vector-issue slots than the coalescing saved; back to
+// thread = edge row x 8 channels with the basis image copied, not converted, and a 5.5-instruction bf16 split 5.3 ms; two
+// fp16 terms with column lifts 4.3 ms; each half's requests right behind the staging of the same registers 3.6 ms (the
+// basis copy in front of the staging instead of behind it: 4.1 ms; records and owner rows requested apart: 3.9 ms).
 template <bool VZ>
 __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rw_lds[];
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
                 }
             }
         };
-        // radial basis: already three bf16 terms in the LDS layout (rw_basis_image_kernel, once per step): a producer thread moves
+        // radial basis: already split into its terms, in the LDS layout (rw_basis_image_kernel, once per step): a producer thread moves
         // two (column, row octet) units of 16 bytes per term (the consumers' registers are the accumulators)
         const int bcol = 64 * (pw & 1) + lane, boct = pw >> 1;   // unit k: column bcol, octet boct + 2 k
         const rw_cint_ptr mask_c = (rw_cint_ptr) reinterpret_cast<const int32_t*>(p.img + (size_t)total_chunks * RW_IMG_CHUNK);
@@ -465,8 +474,8 @@ __global__ void rw_reduce_kernel(const float* __restrict__ part, long long strid
     }
 }
 
-// The radial basis [E, R] as the three bf16 terms of the product, in the layout the consumers copy into LDS: per 32-row chunk
-// [term][row octet][column 0..127][8 rows] (24 KB), followed for all chunks by one mask word each (bit k: 32-column block k of the
+// The radial basis [E, R] as the RW_NT 16-bit terms of the product (RW_F16: x 2^14, hi / lo fp16), in the layout the producers
+// copy into LDS: per 32-row chunk [term][row octet][column 0..127][8 rows] (16 KB; 24 KB with three bf16 terms), followed for all chunks by one mask word each (bit k: 32-column block k of the
 // chunk holds a non-zero).  Written once per training step - the basis does not depend on the layer - instead of being split
 // by every slice's workgroup of every layer's launch (8 x 6 times, ~120 vector instructions per thread and chunk).
 __global__ __launch_bounds__(256) void rw_basis_image_kernel(const float* __restrict__ rbf, int E, int R, unsigned char* __restrict__ img,
