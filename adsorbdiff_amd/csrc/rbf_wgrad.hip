@@ -81,7 +81,7 @@ struct RbfWgradParams {
 #define RW_ACC(k, a, b)
 #endif
 #ifndef RW_ABL
-#define RW_ABL 0   // timing experiments: 1 no gathers, 2 no products, 4 no d(rbfh) conversion / stores, 8 no basis copy, 128 owner rows of atom 0, 256 records of atom 0 (wrong results); 64 no zero-block skipping (right results)
+#define RW_ABL 0   // timing experiments: 1 no gathers, 2 no products, 4 no d(rbfh) conversion / stores, 8 no basis copy, 128 owner rows of atom 0, 256 records of atom 0, 512 the 8 lanes of a row read the same 16 bytes of the owner rows (wrong results); 64 no zero-block skipping (right results)
 #endif
 
 // v[0..N-1] -> RW_NT 16-bit terms, packed pairs o[term][pair].
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(RW_THREADS, 1) void rw_rbf_wgrad_kernel(RbfWgradPar
 #pragma unroll
             for (int k = 0; k < 4; ++k)   // group hh (640 bytes apart), channel 4 sg + k
                 S.g[4 * hh + k] = *reinterpret_cast<const float4*>(rec_b + (ro + (unsigned int)(hh * 640 + k * 16)));
-            const unsigned int oo = (unsigned int)((RW_ABL & 128) ? 0 : ownN) * row_b + ch_lane;   // (128: every row reads atom 0's rows)
+            const unsigned int oo = (unsigned int)((RW_ABL & 128) ? 0 : ownN) * row_b + ((RW_ABL & 512) ? 0u : ch_lane);   // (128: every row reads atom 0's rows; 512: the 8 lanes of a row read the same 16 bytes)
             S.xa[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 128u * hh));
             S.xc[hh] = *reinterpret_cast<const float4*>(xh_b + (oo + 2u * Hb + 128u * hh));
             if (!VZ) {
