@@ -67,6 +67,7 @@ struct adf_epi {
     // any EPI: the row count lives on the device (an incremental layer's recompute list, incremental.hip): rows =
     // min(M, *m_dev); the launch is sized for M.  null = M.
     const int32_t* m_dev;
+    int accumulate;          // EPI 0: C += A W^T (+ bias) instead of C = (the training step's accumulated data gradients)
 };
 // scratch for the row magnitudes a launcher measures itself (adf_launch_rowmag) when the caller has none to hand over
 struct adf_lift {
@@ -207,7 +208,7 @@ int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const 
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s, const float* A2 = nullptr, int K1 = 0,
                           const adf_lift* lf = nullptr, const float* premag = nullptr, float* out_mag = nullptr,
-                          const int32_t* m_dev = nullptr);  // m_dev: see adf_epi::m_dev
+                          const int32_t* m_dev = nullptr, int accumulate = 0);  // m_dev: see adf_epi::m_dev
 // m_dev / m_mul: rows = min(M, *m_dev * m_mul) when the count lives on the device (m_mul = 3: [N,3,K] vector rows)
 int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s,
                           const int32_t* m_dev = nullptr, int m_mul = 1);

@@ -250,8 +250,14 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                         const int item = lane + 64 * it;
                         const int lr = item >> 4, c4 = item & 15;
                         const int row = m0 + wm + 32 * i + lr, col = cb + 4 * c4;
-                        const float4 v = *reinterpret_cast<const float4*>(T + lr * TLD2 + 4 * c4);
-                        if (row < M && col < N) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+                        float4 v = *reinterpret_cast<const float4*>(T + lr * TLD2 + 4 * c4);
+                        if (row < M && col < N) {
+                            if (ep.accumulate) {   // (training: data gradients summed into their destination, no temporary + add pass)
+                                const float4 o = *reinterpret_cast<const float4*>(C + (size_t)row * ldc + col);
+                                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                            }
+                            *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+                        }
                         if (ep.out_mag) {  // the 16 lanes of a DPP row hold one output row: its maximum by four rotations
                             float mg = col < N ? fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) : 0.f;
                             mg = adf_row16_max(mg);
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                     if (row < M) {
                         float v = acc[i][j][r] * (isc * rinv[row - m0]) + bv;
                         if (ACT) v = ssilu16(v);
+                        if (ep.accumulate) v += C[(size_t)row * ldc + col];
                         C[(size_t)row * ldc + col] = v;
                         if (ep.out_mag) atomicMax(ep.out_mag + row, __float_as_uint(fabsf(v)));
                     }
@@ -597,7 +604,7 @@ static int32_t check_a_span(long long rows, int lda) {
 
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s, const float* A2, int K1, const adf_lift* lf,
-                          const float* premag, float* out_mag, const int32_t* m_dev) {
+                          const float* premag, float* out_mag, const int32_t* m_dev, int accumulate) {
     if (M <= 0) return ADF_OK;
     if (K % HK != 0 || (lda & 3) || (A2 && (K1 <= 0 || K1 % HK != 0 || K1 >= K))) {
         adf_set_error("gemm16: K=%d (K1=%d) must be multiples of %d and lda a multiple of 4", K, K1, HK);
@@ -612,7 +619,7 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     const int tiles_m8 = (tiles_m + 7) / 8 * 8;
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
     adf_epi ep = {};
-    ep.A2 = A2; ep.K1 = A2 ? K1 : 0; ep.m_dev = m_dev;
+    ep.A2 = A2; ep.K1 = A2 ? K1 : 0; ep.m_dev = m_dev; ep.accumulate = accumulate;
     ADF_TRY(lift_mags(A, lda, A2 ? K1 : K, A2, A2 ? K - K1 : 0, M, lf, premag, &ep.rmag, s, m_dev, 1));
     if (out_mag) {
         ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));

@@ -47,17 +47,29 @@ __device__ __forceinline__ float tr_dssilu(float x) {
 // ~1e-6 gradient rows of the data-gradient products, keep both fp16 terms) and the weight split per call - in training
 // the weights change every step; the hi/lo image and the row magnitudes live in per-device scratch that consecutive
 // calls on one stream reuse in order.  ADF_TRAIN_GEMM=f32 selects the exact-f32 MFMA GEMM (gemm.hip) everywhere.
-static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, long long M, int N,
-                       int K, hipStream_t s) {
+static int tr_gemm_mode() {
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("ADF_TRAIN_GEMM"); mode = (e && strcmp(e, "f32") == 0) ? 0 : 1; }
+    return mode;
+}
+// the f16x3 path takes this product (A [M, K] with row stride lda)
+static bool tr_gemm16_ok(int lda, long long M, int K) {
+    return tr_gemm_mode() == 1 && K % 32 == 0 && (lda & 3) == 0 && M * (long long)lda * 4 < (1ll << 32);
+}
+static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, long long M, int N,
+                       int K, hipStream_t s, int accumulate = 0) {
+    const int mode = tr_gemm_mode();
     const bool ok16 = mode == 1 && K % 32 == 0 && (lda & 3) == 0 && M * (long long)lda * 4 < (1ll << 32);
+    if (accumulate && !ok16) { adf_set_error("internal: accumulating product needs the f16x3 path"); return ADF_EINVAL; }
     if (!ok16) return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
     static unsigned char* buf[16] = {};
     static size_t cap[16] = {};
     int dev = 0;
     ADF_HIP_CHECK(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
+    if (dev < 0 || dev >= 16) {
+        if (accumulate) { adf_set_error("internal: accumulating product needs the f16x3 path"); return ADF_EINVAL; }
+        return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
+    }
     const size_t n = (size_t)N * K, need = n * 4 + 256;
     if (need > cap[dev]) {
         ADF_HIP_CHECK(hipDeviceSynchronize());
@@ -66,6 +78,7 @@ static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bia
         const size_t want = need + need / 4;
         if (hipMalloc(reinterpret_cast<void**>(&buf[dev]), want) != hipSuccess) {
             (void)hipGetLastError();
+            if (accumulate) { adf_set_error("out of memory (weight image of a product)"); return ADF_EOOM; }
             return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
         }
         cap[dev] = want;
@@ -79,6 +92,7 @@ static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bia
         const long long want = M + M / 4 + 1024;
         if (hipMalloc(reinterpret_cast<void**>(&mag[dev]), sizeof(float) * (size_t)want) != hipSuccess) {
             (void)hipGetLastError();
+            if (accumulate) { adf_set_error("out of memory (weight image of a product)"); return ADF_EOOM; }
             return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
         }
         mag_cap[dev] = want;
@@ -89,7 +103,7 @@ static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bia
     w16.bias_perm = nullptr;
     ADF_TRY(adf_split_weight(W, (long long)n, &w16, reinterpret_cast<unsigned int*>(buf[dev] + n * 4 + 16), s));
     const adf_lift lf = {mag[dev], mag_cap[dev]};
-    return adf_launch_gemm16(A, lda, &w16, bias, C, ldc, (int)M, N, K, 0, s, nullptr, 0, &lf);
+    return adf_launch_gemm16(A, lda, &w16, bias, C, ldc, (int)M, N, K, 0, s, nullptr, 0, &lf, nullptr, nullptr, nullptr, accumulate);
 }
 
 __global__ void tr_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
@@ -518,6 +532,9 @@ extern "C" int32_t adf_op_linear_bwd(const float* A, int32_t lda, const float* W
             if (!acc_dA) {
                 // dA = dC Wt^T through the same lifted f16x3 product (rows of dC are ~1e-6: the lift keeps both fp16 terms)
                 ADF_TRY(tr_gemm(dC, ldc, Wt, nullptr, dA, ldda, M, K, N, s));
+            } else if (tr_gemm16_ok(ldc, M, N) && (ldda & 3) == 0 && (K & 3) == 0 && (reinterpret_cast<uintptr_t>(dA) & 15) == 0) {
+                // dA += dC Wt^T in the product's own epilogue (until round 5: a temporary [M, K] + an add pass, 2 ms per step)
+                ADF_TRY(tr_gemm(dC, ldc, Wt, nullptr, dA, ldda, M, K, N, s, 1));
             } else {
                 float* tmp = part + (size_t)64 * ((size_t)N * K + N);  // [M,K]
                 ADF_TRY(tr_gemm(dC, ldc, Wt, nullptr, tmp, K, M, K, N, s));
