@@ -577,8 +577,9 @@ int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad,
     eq_ptrs mb, rs;
     for (int m = 0; m <= EQ_MAX_M; ++m) { mb.p[m] = m <= h->d.M ? mbuf[m] : nullptr; rs.p[m] = (rsp && m <= h->d.M) ? rsp[m] : nullptr; }
     const int bd = (2 * h->d.C + 63) / 64 * 64;
-    if (bd > 256) { adf_set_error("rotate_in: more than 128 sphere channels"); return ADF_EINVAL; }
-    const bool m2 = h->d.M == 2 && !getenv("ADF_EQV2_ROTIN_GENERIC");   // compile-time-M fast path (M = 2: the shipped models)
+    if (bd > 256) { adf_set_error("rotate_in: more than 128 sphere channels (one thread per input channel, 256-thread workgroups; INTEGRATION.md 5)"); return ADF_EINVAL; }
+    static const bool generic_ri = getenv("ADF_EQV2_ROTIN_GENERIC") != nullptr;   // read once, not per launch
+    const bool m2 = h->d.M == 2 && !generic_ri;   // compile-time-M fast path (M = 2: the shipped models)
 #define EQ_RI_(LT_, MT_)                                                                                               \
     if (presplit)                                                                                                      \
         hipLaunchKernelGGL((eq_rotate_in_kernel<LT_, true, MT_>), dim3((unsigned)Eub), dim3(bd), 0, s, y, rad, h->wig, h->eptr, \
@@ -1070,8 +1071,9 @@ int32_t eq_launch_rotate_out(const adf_eqv2* h, float* const* z, const float* al
     eq_ptrs zm;
     for (int m = 0; m <= h->d.M; ++m) zm.p[m] = z[m];
     const int bd = (h->d.HV + 63) / 64 * 64;
-    if (bd > 256) { adf_set_error("rotate_out: more than 256 value channels"); return ADF_EINVAL; }
-    const bool m2 = h->d.M == 2 && !getenv("ADF_EQV2_ROTOUT_GENERIC");   // the compile-time-M fast path (M = 2: the shipped models)
+    if (bd > 256) { adf_set_error("rotate_out: num_heads * attn_value_channels > 256 (one thread per value channel; INTEGRATION.md 5)"); return ADF_EINVAL; }
+    static const bool generic_ro = getenv("ADF_EQV2_ROTOUT_GENERIC") != nullptr;   // read once, not per launch
+    const bool m2 = h->d.M == 2 && !generic_ro;   // the compile-time-M fast path (M = 2: the shipped models)
 #define EQ_RO_(LT_, MT_)                                                                                               \
     if (only_l1)                                                                                                       \
         hipLaunchKernelGGL((eq_rotate_out_kernel<LT_, true, MT_>), dim3(n1 - n0), dim3(bd), 0, s, z[0], zm, alpha, h->wig, \

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void tr_wgrad128_kernel(const float* __restric
             if (nz) nzblk[par][lc >> 5] = 1u;  // benign race: every writer stores 1
             if (tid < 4) nzblk[par ^ 1][tid] = 0u;  // the other parity's flags were last read before the barrier above
         }
+        if (m0 + 32 < mend) load_chunk(m0 + 32);   // the next chunk's rows: in flight behind this chunk's MFMAs
         __syncthreads();
         if (colsum) {
 #pragma unroll

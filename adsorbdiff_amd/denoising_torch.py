@@ -263,6 +263,10 @@ class Denoiser:
                             sink.abort()
                             writer.join()
                             sink.close()
+                            if writer.error is not None:
+                                # the writer died first (disk full, ...): the push error ('ring was aborted') is only
+                                # its echo - surface the real cause
+                                raise writer.error
                         raise
                     if writer is not None:
                         applied = int(state[3].item())

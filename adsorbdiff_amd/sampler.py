@@ -39,12 +39,28 @@ def shard_batch(batch, rank: int, world: int):
     return Batch.from_data_list([data[i] for i in mine]), mine
 
 
-def adsorbate_sites(batch) -> torch.Tensor:
+def _exchange_device(via: str = "torch") -> torch.device:
+    """Where a rank WITHOUT systems must put its (empty) message so that the collective accepts it: the current ROCm device
+    under backend nccl (= RCCL) or ``via="rccl"`` - every other rank is already waiting in the all-gather with a device
+    tensor, and a CPU tensor there raises on this rank while the others block until the NCCL time-out -, the host
+    otherwise (gloo)."""
+    on_dev = via == "rccl"
+    if not on_dev:
+        import torch.distributed as dist
+
+        on_dev = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    if on_dev and torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def adsorbate_sites(batch, device=None) -> torch.Tensor:
     """[B, A, 3] positions of each system's adsorbate (tag==2) atoms, NaN-padded to the largest
     adsorbate in the batch.  A rank that was dealt no system (more ranks than systems) passes None or an empty batch and
-    gets a [0, 1, 3] tensor: it still takes part in the exchange with an all-padding message."""
+    gets a [0, 1, 3] tensor on ``device`` (default: where the exchange of this process group runs, ``_exchange_device``):
+    it still takes part in the exchange with an all-padding message."""
     if batch is None or not hasattr(batch, "pos"):
-        return torch.empty(0, 1, 3, dtype=torch.float32)
+        return torch.empty(0, 1, 3, dtype=torch.float32, device=device if device is not None else _exchange_device())
     tags, bidx = batch.tags, batch.batch
     B = int(batch.natoms.shape[0])
     m = tags == 2
@@ -121,7 +137,7 @@ def shard_bounds(batch, world: int):
     return max(len(p) for p in parts), max(int(counts.max().item()), 1)
 
 
-def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=None, local=None) -> torch.Tensor:
+def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=None, local=None, device=None) -> torch.Tensor:
     """All ranks' adsorbate sites: [sum_r B_r, A_max, 3] (NaN padded), rank-major — or, when every rank passes the
     global ids of its systems (``system_ids``, what ``shard_batch`` returns), in global system order.
 
@@ -131,8 +147,9 @@ def gather_sites(batch, world: int, via: str = "torch", system_ids=None, bounds=
 
     via="torch": ``torch.distributed.all_gather`` (backend nccl = RCCL over xGMI; gloo in the CPU tests);
     via="rccl":  the library's C-ABI entry ``adf_allgather_sites`` (one GPU per rank)."""
-    if local is None:   # (``local``: the sites already extracted - what a rank without systems passes, on its device)
-        local = adsorbate_sites(batch)
+    if local is None:   # (``local``: the sites already extracted)
+        # a rank without systems (batch None): an empty message on ``device``, or where this group's collective runs
+        local = adsorbate_sites(batch, device if device is not None else _exchange_device(via))
     if world <= 1:
         return local
     import torch.distributed as dist

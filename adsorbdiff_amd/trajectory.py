@@ -110,8 +110,10 @@ class TrajectoryWriter(threading.Thread):
             return self._aborted
 
     def _cleanup_tmp(self) -> None:
-        for pth in list(self.traj_dir.glob("*.npz_tmp")) + [self.batch_stem.with_suffix(".frames.npy_tmp"),
-                                                            self.batch_stem.with_suffix(".json_tmp")]:
+        # only THIS writer's temporary files: traj_dir is shared (one directory, files named by sid, as in the reference
+        # layout), and another batch's writer - or another rank - may be publishing its own `<sid>.npz_tmp` right now
+        own = [self.traj_dir / f"{name}.npz_tmp" for name in (str(n) for n in self.meta["names"])]
+        for pth in own + [self.batch_stem.with_suffix(".frames.npy_tmp"), self.batch_stem.with_suffix(".json_tmp")]:
             try:
                 pth.unlink()
             except OSError:

@@ -237,3 +237,37 @@ def test_two_gpu_nccl_training_step_averages_gradients(tmp_path):
     mp.spawn(_nccl_train_worker, args=(2, 29671, str(tmp_path)), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "n0.pt"), torch.load(tmp_path / "n1.pt")
     assert torch.equal(a["g"], b["g"]) and bool(torch.isfinite(a["g"]).all()) and float(a["g"].abs().max()) > 0
+
+
+_EMPTY_RANK_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, {root!r})
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29683", HSA_ENABLE_IPC_MODE_LEGACY="0")
+from adsorbdiff_amd.sampler import adsorbate_sites, gather_sites
+assert not adsorbate_sites(None).is_cuda                      # no process group: host
+assert gather_sites(None, 1, via="rccl").is_cuda              # the library's RCCL entry wants device memory
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+e = adsorbate_sites(None)
+assert e.is_cuda and tuple(e.shape) == (0, 1, 3), (e.device, e.shape)
+g = gather_sites(None, 1)
+assert g.is_cuda
+# the message an empty rank sends: all padding, on the device the collective runs on
+from adsorbdiff_amd.sampler import pack_sites
+p = pack_sites(e, [], (3, 2))
+assert p.is_cuda and bool((p[:, 0] == -1).all())
+outs = [torch.empty_like(p)]
+dist.all_gather(outs, p)                                      # RCCL accepts it (a CPU tensor raises here)
+assert torch.equal(outs[0], p)
+dist.destroy_process_group()
+print("EMPTY_RANK_OK")
+"""
+
+
+def test_rank_without_systems_sends_its_message_from_the_device_under_nccl():
+    """`gather_sites(None, ...)` without `local=` built its empty message on the host; under backend nccl (and
+    via="rccl") that raises on the empty rank while the others wait in the all-gather.  One-rank nccl group in a child."""
+    res = subprocess.run([sys.executable, "-c", _EMPTY_RANK_SCRIPT.format(root=str(ROOT))], capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0 and "EMPTY_RANK_OK" in res.stdout, res.stderr[-2000:]

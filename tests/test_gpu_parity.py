@@ -504,6 +504,144 @@ def test_sampling_50_steps_teacher_forced_vs_oracle(tmp_path):
     print(f"50-step teacher-forced check: worst error / tolerance = {worst:.3f}")
 
 
+def _bench_model():
+    """The model the headline is quoted on (bench.py::bench_painn_model: H = 512 x 6, 10 A, K = 50, seed 0, shipped scale
+    factors, the last linear map of both heads x 100)."""
+    import bench
+
+    return bench.bench_painn_model()
+
+
+def test_bench_workload_model_teacher_forced_vs_oracle(tmp_path):
+    """the HEADLINE workload's own model (heads x 100) on the 50-step schedule of the benchmark, four
+    systems of the seed-1000 batch, fused loop with every frame kept.  On 12 steps spread over the schedule and for two
+    of the systems the CPU oracle starts from the sampler's own previous frame (teacher forcing) and must (1) give the
+    per-system translation / rotation scores the HIP forward gives on that frame (row-wise 1e-4) and (2) land on the
+    sampler's next frame."""
+    from adsorbdiff_amd.data import Batch
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc, schedule_coefs
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+    from oracle import painn_oracle as O
+
+    m = _bench_model()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sf = m.scale_factors()
+    B, T = 4, 50
+    b = make_batch(B, seed=1000)
+    torch.manual_seed(0)
+    noise = torch.rand(B, 3)
+    params = dict(num_steps=T, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+                  early_stop=False)
+    den = Denoiser(b.clone(), DiffTorchCalc(DenoisingTrainer(m, device=DEV)), dict(params, placement_noise=noise), device=DEV,
+                   save_full_traj=True, traj_dir=tmp_path, traj_names=[str(i) for i in range(B)])
+    den.run()
+    assert den.steps_applied == T
+    allf = torch.from_numpy(np.load(tmp_path / "batch_0.frames.npy"))   # [T, 800, 3]: the batch after every step
+    assert allf.shape == (T, 800, 3)
+    start = O.initial_placement(b.pos.clone(), b.cell, b.tags, b.batch, noise)
+    coefs = schedule_coefs(params)
+    eng = m.engine()
+    bd = b.clone().to(DEV)
+    prep = eng.prepare(bd)
+    f1 = torch.empty(800, 3, device=DEV)
+    f2 = torch.empty(800, 3, device=DEV)
+    data = b.to_data_list()
+    worst_s = worst_p = 0.0
+    for t in (0, 1, 2, 3, 5, 8, 12, 20, 30, 40, 45, 49):
+        p_in = start if t == 0 else allf[t - 1]
+        eng.forward_prepared(prep, p_in.to(DEV).contiguous(), f1, f2)
+        s_hip = O.ads_mean(f1.cpu(), b.tags, b.batch, B)
+        r_hip = O.ads_mean(f2.cpu() * (b.fixed != 1).float()[:, None], b.tags, b.batch, B)
+        for k in (1, 3):
+            one = Batch.from_data_list([data[k]])
+            sl = slice(200 * k, 200 * (k + 1))
+            o1, o2 = O.painn_forward(sd, p_in[sl], one.atomic_numbers, one.cell, one.natoms, cutoff=10.0, max_neighbors=50,
+                                     scale_factors=sf)
+            s_o = O.ads_mean(o1, one.tags, one.batch, 1)
+            r_o = O.ads_mean(o2 * (one.fixed != 1).float()[:, None], one.tags, one.batch, 1)
+            es, er = row_rel_err(s_hip[k : k + 1], s_o), row_rel_err(r_hip[k : k + 1], r_o)
+            worst_s = max(worst_s, es, er)
+            assert es < REL_TOL and er < REL_TOL, (t, k, es, er)
+            want, _, _, _ = O.reverse_step(p_in[sl], one.cell, one.tags, one.batch, o1, o2, one.fixed, t, params)
+            tol = 1e-4 * abs(coefs[t].coef_tr) * float(s_o.abs().max()) + 2e-5
+            err = float((allf[t][sl] - want).abs().max())
+            worst_p = max(worst_p, err / tol)
+            assert err < tol, (t, k, err, tol)
+    print(f"bench workload, teacher-forced: worst score row error {worst_s:.2e}, worst position error / tolerance {worst_p:.3f}")
+
+
+def test_bench_workload_model_each_step_vs_reference_fixture():
+    """The same model on the REAL reference (tests/golden/stepper_bench_gain.npz, oracle/make_golden.py section 11: the
+    reference's Denoiser.run on the first two systems of the seed-1000 batch; its cumulative early stop ends the run after
+    35 applied steps): teacher forcing on the reference's recorded positions, per step the per-system scores (1e-4
+    row-wise), the rotation vector, the wrapped COM displacement and the positions afterwards."""
+    from adsorbdiff_amd.denoising_torch import schedule_coefs
+
+    fx = load_npz("stepper_bench_gain.npz")
+    m = _bench_model().to(DEV).eval()
+    eng = m.engine()
+    params = _params(fx)
+    T, calls, applied = params["num_steps"], int(fx["model_calls"]), int(fx["steps_applied"])
+    coefs = schedule_coefs(params)
+    b = batch_from_fixture(fx, pos_key="pos_in", device=DEV)
+    prep = eng.prepare(b)
+    B, N = prep.num_systems, prep.num_atoms
+    torch.manual_seed(int(fx["seed"]))
+    noise = torch.rand(B, 3)
+    pos = b.pos.clone().contiguous()
+    eng.init_placement(prep, pos, noise.to(DEV))
+    log = torch.from_numpy(fx["pos_log"])  # [calls, N, 3] positions before each model call
+    np.testing.assert_allclose(pos.cpu().numpy(), log[0].numpy(), rtol=0, atol=2e-6)
+    f1 = torch.empty(N, 3, device=DEV)
+    f2 = torch.empty(N, 3, device=DEV)
+    tags = torch.from_numpy(fx["tags"])
+    ads = (b.tags == 2)
+    keep = (b.fixed != 1).float()[:, None]
+    cnt = torch.zeros(B, device=DEV).index_add_(0, b.batch[ads], torch.ones(int(ads.sum()), device=DEV))[:, None]
+    worst = 0.0
+    for t in range(calls):
+        pos = log[t].to(DEV).contiguous()
+        eng.forward_prepared(prep, pos, f1, f2)
+        s_tr = torch.zeros(B, 3, device=DEV).index_add_(0, b.batch[ads], f1[ads]) / cnt
+        s_rot = torch.zeros(B, 3, device=DEV).index_add_(0, b.batch[ads], (f2 * keep)[ads]) / cnt
+        e1, e2 = row_rel_err(s_tr.cpu(), fx["ref_score_tr"][t]), row_rel_err(s_rot.cpu(), fx["ref_score_rot"][t])
+        worst = max(worst, e1, e2)
+        assert e1 < REL_TOL and e2 < REL_TOL, (t, e1, e2)
+        if t >= applied:
+            continue   # the reference broke out of its loop before applying this step
+        state = torch.tensor([0, 0, 1, 0, 0, 0, 0, 0], dtype=torch.int32, device=DEV)
+        dcom = torch.empty(B, 3, device=DEV)
+        drot = torch.empty(B, 3, device=DEV)
+        eng.sde_step(prep, pos, f1, f2, coefs[t], state, None, None, early_stop_count=0, dcom=dcom, drot=drot)
+        assert rel_err(drot.cpu(), fx["ref_drot"][t]) < REL_TOL, t
+        raw_step = abs(coefs[t].coef_tr) * float(np.abs(fx["ref_score_tr"][t]).max())
+        tol_com = 1e-4 * raw_step + 2e-5
+        assert float((dcom.cpu() - torch.from_numpy(fx["ref_dcom"][t])).abs().max()) < tol_com, (t, tol_com)
+        want = log[t + 1] if t + 1 < calls else torch.from_numpy(fx["pos_final"])
+        tol = tol_com + 1e-4 * float(np.abs(fx["ref_drot"][t]).max()) * 2.0 + 1e-5
+        diff = (pos.cpu() - want).abs()
+        assert float(diff.max()) < tol, (t, float(diff.max()), tol)
+        assert float(diff[tags != 2].max()) == 0.0
+    print(f"bench workload vs the reference's own run: worst per-system score error {worst:.2e} over {calls} model calls")
+
+
+def test_bench_workload_model_early_stop_matches_the_reference_run():
+    """The reference's Denoiser.run on that fixture stopped after 35 applied steps (ten steps with |dcom| <= 1e-3 A on both
+    systems): `Denoiser.run()` with its defaults stops at the same step and ends on the same positions (the trajectory is
+    well conditioned at this gain: |dcom| <= 0.07 A per step)."""
+    fx = load_npz("stepper_bench_gain.npz")
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    b = batch_from_fixture(fx, pos_key="pos_in")
+    tr = DenoisingTrainer(_bench_model(), device=DEV)   # (built BEFORE seeding: the model's initialisers draw from the stream)
+    torch.manual_seed(int(fx["seed"]))
+    den = Denoiser(b, DiffTorchCalc(tr), _params(fx), device=DEV)
+    out = den.run()
+    assert den.steps_applied == int(fx["steps_applied"]), (den.steps_applied, int(fx["steps_applied"]))
+    np.testing.assert_allclose(out.pos.cpu().numpy(), fx["pos_final"], rtol=0, atol=2e-4)
+
+
 def test_denoiser_end_to_end_vs_reference_fixture(tmp_path):
     fx = load_npz("stepper_ode8.npz")
     out, den = _run_denoiser(fx, traj_dir=tmp_path)

@@ -290,3 +290,44 @@ def test_two_rank_training_step_equals_full_batch(tmp_path):
     for key in fx:
         if key.startswith("grad::"):
             assert rel_err(got[key[6:]], fx[key]) < 1e-4, key
+
+
+_WGRAD_F32_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from adsorbdiff_amd.train_step import _Ops
+ops = _Ops("cuda:0")
+torch.manual_seed(11)
+worst = 0.0
+for (M, N, K) in ((4096 + 17, 128, 128), (3000, 256, 128), (33, 128, 256)):
+    A = torch.randn(M, K, device="cuda:0"); W = torch.randn(N, K, device="cuda:0") * 0.05
+    dC = torch.randn(M, N, device="cuda:0")
+    dW = torch.zeros(N, K, device="cuda:0"); db = torch.zeros(N, device="cuda:0")
+    dA = ops.linear_bwd(A, W, dC, M, N, K, dW, db)
+    torch.cuda.synchronize()
+    rW = dC.double().t() @ A.double(); rb = dC.double().sum(0); rA = dC.double() @ W.double()
+    for got, ref in ((dW, rW), (db, rb), (dA, rA)):
+        worst = max(worst, float((got.double() - ref).norm() / ref.norm()))
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("mode", ["f32", "default"])
+def test_linear_backward_weight_gradient_kernels_vs_torch(mode):
+    """the exact-f32 weight-gradient kernel (ADF_WGRAD=f32, tr_wgrad128_kernel) staged only the first
+    32-row chunk of every split.  ADF_WGRAD is read once per process, hence the child process; M >> 32 and ragged."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parent.parent)
+    env = dict(os.environ)
+    env.pop("ADF_WGRAD", None)
+    if mode == "f32":
+        env["ADF_WGRAD"] = "f32"
+    res = subprocess.run([sys.executable, "-c", _WGRAD_F32_SCRIPT.format(root=root)], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    worst = float(res.stdout.strip().split("WORST")[-1])
+    assert worst < 1e-5, worst

@@ -124,6 +124,34 @@ def test_oracle_step_quantities_vs_reference_records(name):
         assert O.cell_repeats(b.cell, 6.0)[:2] == [2, 2]
 
 
+def test_oracle_on_the_bench_workload_model_vs_reference_records():
+    """tests/golden/stepper_bench_gain.npz: the HEADLINE workload's model (bench.py::bench_painn_model: H = 512 x 6, 10 A /
+    50 neighbours, seed 0, heads x 100; weights rebuilt from the seed, not stored) run by the reference's Denoiser on the first
+    two systems of the seed-1000 batch.  The oracle, teacher-forced on the recorded positions, against the reference's own
+    per-step scores / displacement / rotation vector at three steps of the schedule (CPU: ~2 s per forward)."""
+    import bench
+
+    fx = load_npz("stepper_bench_gain.npz")
+    m = bench.bench_painn_model()
+    assert float(fx["head_gain"]) == bench.HEAD_GAIN
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    b = batch_from_fixture(fx, pos_key="pos_in")
+    B, T = len(b.natoms), int(fx["num_steps"])
+    assert (T, int(fx["model_calls"]), int(fx["steps_applied"])) == (50, fx["pos_log"].shape[0], fx["ref_drot"].shape[0])
+    assert int(fx["model_calls"]) == int(fx["steps_applied"]) + 1 < T   # the reference's cumulative early stop ended the run
+    params = dict(num_steps=T, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True)
+    log = torch.from_numpy(fx["pos_log"])
+    for t in (0, 17, int(fx["steps_applied"]) - 1):
+        f1, f2 = O.painn_forward(sd, log[t], b.atomic_numbers, b.cell, b.natoms, cutoff=10.0, max_neighbors=50,
+                                 scale_factors=m.scale_factors())
+        assert rel_err(O.ads_mean(f1, b.tags, b.batch, B), fx["ref_score_tr"][t]) < 1e-5
+        assert rel_err(O.ads_mean(f2 * (b.fixed != 1).float()[:, None], b.tags, b.batch, B), fx["ref_score_rot"][t]) < 1e-5
+        pos, dcom, drot, _ = O.reverse_step(log[t], b.cell, b.tags, b.batch, f1, f2, b.fixed, t, params)
+        assert rel_err(drot, fx["ref_drot"][t]) < 1e-5
+        np.testing.assert_allclose(dcom.numpy(), fx["ref_dcom"][t], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(pos.numpy(), log[t + 1].numpy(), rtol=0, atol=2e-5)
+
+
 def test_early_stop_rule():
     """Cumulative (not consecutive) count, break before applying the 10th converged step."""
     fx = load_npz("stepper_ode_early.npz")
