@@ -14,7 +14,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libadsorbdiff_hip.so"
-SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "graph.hip", "message.hip", "message_bwd.hip", "rbf_wgrad.hip", "nodewise.hip", "stepper.hip", "peaks.hip", "collect.hip", "frames.hip", "train.hip", "incremental.hip", "eqv2_kernels.hip", "eqv2_gemm16.hip", "eqv2_api.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm16.hip", "mlp16.hip", "graph.hip", "message.hip", "message_bwd.hip", "rbf_wgrad.hip", "nodewise.hip", "stepper.hip", "peaks.hip", "collect.hip", "frames.hip", "train.hip", "incremental.hip", "eqv2_kernels.hip", "eqv2_gemm16.hip", "eqv2_api.hip"]
 
 
 def _hipcc() -> str:

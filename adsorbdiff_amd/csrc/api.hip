@@ -145,6 +145,11 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         if (st == ADF_OK) st = dev_alloc(&h->w16_scales, 256);
         if (st == ADF_OK) st = dev_alloc(&h->w16_bias_perm, (size_t)L * 2 * 3 * H);
         if (st == ADF_OK) st = dev_alloc(&h->w16_scratch, 1);
+        {   // form of the x_proj / xvec_proj pairs: the two-kernel form unless asked otherwise (mlp16.hip: measured slower)
+            const char* ef = getenv("ADF_FUSED_MLP");
+            h->fused_mlp = ef ? atoi(ef) : 0;
+            if (h->fused_mlp < 0 || h->fused_mlp > 2) h->fused_mlp = 0;
+        }
         const char* e = getenv("ADF_GEMM");
         h->gemm_f32 = e && strcmp(e, "f32") == 0;
         const char* el = getenv("ADF_LIFT");
@@ -210,12 +215,37 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->flags) (void)hipFree(h->flags);
     if (h->kcount) (void)hipFree(h->kcount);
     if (h->w16_arena) (void)hipFree(h->w16_arena);
+    if (h->wfrag_arena) (void)hipFree(h->wfrag_arena);
     if (h->w16_scales) (void)hipFree(h->w16_scales);
     if (h->w16_bias_perm) (void)hipFree(h->w16_bias_perm);
     if (h->w16_scratch) (void)hipFree(h->w16_scratch);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
     delete h->prof_cat;
     delete h;
+    return ADF_OK;
+}
+
+// Fragment images of the four MLP weights of every layer for the fused two-layer kernel (mlp16.hip): 9 H^2 x 4 bytes per
+// layer, allocated and packed only when that form is asked for (ADF_FUSED_MLP / adf_painn_set_fused_mlp); H = 512 only.
+static int32_t pack_fragment_images(adf_painn* h, hipStream_t s) {
+    const long long H = h->hp.hidden_channels, HH = H * H;
+    const int L = h->hp.num_layers;
+    if (H != 512) return ADF_OK;   // (use_fused_mlp then never picks the fused form)
+    if (!h->wfrag_arena) ADF_TRY(dev_alloc(&h->wfrag_arena, (size_t)L * 9 * HH * 2 * sizeof(uint16_t)));
+    unsigned char* fc = h->wfrag_arena;
+    auto frag = [&](const adf_w16* w, int N, int K, void** out) -> int32_t {
+        *out = fc;
+        fc += (size_t)N * K * 4;
+        return adf_pack_frag(w, N, K, *out, s);
+    };
+    for (int l = 0; l < L; ++l) {
+        adf_layer_weights& lw = h->layer[l];
+        ADF_TRY(frag(&lw.xp0_16, (int)H, (int)H, &lw.xp0_f));
+        ADF_TRY(frag(&lw.xp2_16, (int)(3 * H), (int)H, &lw.xp2_f));
+        ADF_TRY(frag(&lw.xv0_16, (int)H, (int)(2 * H), &lw.xv0_f));
+        ADF_TRY(frag(&lw.xv2_16, (int)(3 * H), (int)H, &lw.xv2_f));
+    }
+    h->wfrag_valid = true;
     return ADF_OK;
 }
 
@@ -286,6 +316,8 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
             ADF_TRY(split(b1.vec1_w, HH / 4, &b1.vec1_16));
             ADF_TRY(split(b1.un0_w, HH / 2, &b1.un0_16));
         }
+        h->wfrag_valid = false;
+        if (h->fused_mlp != 0) ADF_TRY(pack_fragment_images(h, s));
         if ((size_t)(cur - h->w16_arena) > h->w16_bytes || nscale > 256) {
             adf_set_error("internal: fp16 weight arena overflow");
             return ADF_EINVAL;
@@ -468,6 +500,15 @@ static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
 
 // Gather records of layer l for the n rows (x, vec): xh = x_proj(LayerNorm(x)) (painn_denoising.py:531), packed with
 // vec for the message kernel.  row_map != null: row r of (x, vec) is atom row_map[r] of the record table.
+// The fused two-layer kernel (mlp16.hip) or the two-kernel form of the x_proj / xvec_proj pairs?  Same bits either way.
+// By size (mode 2): a 64-row tile per CU wants at least two rounds of tiles on the chip; below that the 128 x 192 tiles of
+// the two-kernel form spread a small batch over more CUs (B = 1: 200 rows are 4 fused tiles against 16 workgroups).
+static bool use_fused_mlp(const adf_painn* h, int rows) {
+    if (!h->wfrag_valid || h->gemm_f32 || h->fused_mlp == 0) return false;
+    if (h->fused_mlp == 1) return true;
+    return rows >= 2 * 64 * h->num_cus;
+}
+
 static int32_t make_records(adf_painn* h, int l, int n, const float* x, const float* vec, bool vec_is_zero, float* rec,
                             const int32_t* row_map, hipStream_t s) {
     const int H = h->hp.hidden_channels;
@@ -480,6 +521,16 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
     const bool em = lift && emit;
     // row magnitudes travel with the rows: LayerNorm -> x_proj.0 -> (its epilogue) -> x_proj.2
     ADF_TRY(adf_nodewise_layernorm(x, w.ln_w, w.ln_b, h->y, n, H, s, em ? h->mag_a : nullptr, h->rows_dev));
+    if (use_fused_mlp(h, n) && (em || !lift)) {   // x_proj.0 -> x_proj.2 -> records in one kernel (mlp16.hip), same bits
+        adf_epi ep = {};
+        ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
+        ep.row_map = row_map; ep.m_dev = h->rows_dev; ep.lift_y = lift ? 1 : 0;
+        ep.rec_rows = row_map ? (long long)h->inc_capN : (long long)n;   // mapped rows index the whole kept table
+        ADF_TRY(adf_launch_mlp16(h->y, nullptr, H, em ? h->mag_a : nullptr, w.xp0_f, &w.xp0_16, w.xp0_b, w.xp2_f, &w.xp2_16, n,
+                                 H, 1, &ep, s));
+        adf_prof_end(h, s);
+        return ADF_OK;
+    }
     ADF_TRY(adf_linear(h, h->y, H, w.xp0_w, &w.xp0_16, w.xp0_b, h->cat, H, n, H, H, 1, s, em ? h->mag_a : nullptr,
                        em ? h->mag_b : nullptr));
     if (h->gemm_f32) {
@@ -529,6 +580,20 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
         // half-wave, 4 atomicMax per target and channel slice: measuring passes -11 ms, message kernel +9 ms per 10 full
         // steps of 1000 systems: a wash, not kept.)
         ADF_TRY(adf_launch_gemm16_fused(vec, H, &w.vp_16, N, H, H, 3, &ep, s, lf));
+        if (use_fused_mlp(h, N)) {   // xvec_proj.0 -> xvec_proj.2 -> gating in one kernel (mlp16.hip), same bits
+            const float* rm = nullptr;
+            if (lf) {
+                if (N > lf->cap) { adf_set_error("mlp16: lift scratch holds %lld rows, need %d", lf->cap, N); return ADF_EINVAL; }
+                ADF_TRY(adf_launch_rowmag(x, H, H, h->cat, H, N, lf->buf, s, h->rows_dev, 1));
+                rm = lf->buf;
+            }
+            adf_epi e2 = {};
+            e2.x = x; e2.vec = vec; e2.dot = h->dot; e2.vv = h->vv; e2.scale = h->scale[l]; e2.H = H;
+            e2.m_dev = h->rows_dev; e2.lift_y = h->lift_on ? 1 : 0;
+            const int32_t stf = adf_launch_mlp16(x, h->cat, H, rm, w.xv0_f, &w.xv0_16, w.xv0_b, w.xv2_f, &w.xv2_16, N, H, 2, &e2, s);
+            adf_prof_end(h, s);
+            return stf;
+        }
         ADF_TRY(adf_launch_gemm16(x, H, &w.xv0_16, w.xv0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H, lf, nullptr,
                                   h->lift_on ? h->mag_b : nullptr, h->rows_dev));
     }
@@ -901,6 +966,16 @@ extern "C" int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32) {
 // Incremental layers (see incremental.hip): 1 = keep per-layer node state across the forwards of a static-atom promise
 // and recompute only rows whose inputs changed (default; bit-identical outputs), 0 = every forward computes every row.
 // Resets the row counters reported by adf_get_counters.
+extern "C" int32_t adf_painn_set_fused_mlp(adf_painn_t h, int32_t mode) {
+    if (!h || mode < 0 || mode > 2) { adf_set_error("set_fused_mlp: mode must be 0 (never), 1 (always) or 2 (by size)"); return ADF_EINVAL; }
+    h->fused_mlp = mode;
+    if (mode != 0 && h->weights_set && !h->wfrag_valid) {   // first use: build the fragment images from the split weights
+        ADF_TRY(pack_fragment_images(h, (hipStream_t)0));
+        ADF_HIP_CHECK(hipStreamSynchronize((hipStream_t)0));
+    }
+    return ADF_OK;
+}
+
 extern "C" int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on) {
     if (!h) { adf_set_error("null handle"); return ADF_EINVAL; }
     if ((on != 0) != h->inc_on) {

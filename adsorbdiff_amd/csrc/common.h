@@ -68,6 +68,8 @@ struct adf_epi {
     // min(M, *m_dev); the launch is sized for M.  null = M.
     const int32_t* m_dev;
     int accumulate;          // EPI 0: C += A W^T (+ bias) instead of C = (the training step's accumulated data gradients)
+    int lift_y;              // mlp16.hip: lift the intermediate rows by their own power of two (= the engine's lift_on)
+    long long rec_rows;      // mlp16.hip EPI 1: rows of the record table the (mapped) rows are written into (0 = the launch's rows)
 };
 // scratch for the row magnitudes a launcher measures itself (adf_launch_rowmag) when the caller has none to hand over
 struct adf_lift {
@@ -78,6 +80,8 @@ struct adf_layer_weights {
     const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
     const float *vp_w, *xv0_w, *xv0_b, *xv2_w, *xv2_b;
     adf_w16 xp0_16, xp2_16, vp_16, xv0_16, xv2_16;
+    // fragment-ordered images of the same split weights for the fused two-layer kernel (mlp16.hip); null unless H == 512
+    void *xp0_f, *xp2_f, *xv0_f, *xv2_f;
 };
 struct adf_block_weights {
     const float *vec1_w, *vec2_w, *un0_w, *un0_b, *un2_w, *un2_b;
@@ -106,6 +110,9 @@ struct adf_painn {
     float* w16_scales;
     float* w16_bias_perm;  // [L][2][3H] row-permuted biases of x_proj.2 / xvec_proj.2
     unsigned int* w16_scratch;
+    unsigned char* wfrag_arena;   // the layers' fragment images (mlp16.hip); allocated on first use
+    bool wfrag_valid;             // ... and packed from the current weights
+    int fused_mlp;                // 0 never (default), 1 always, 2 by size: adf_painn_set_fused_mlp / ADF_FUSED_MLP
     bool gemm_f32;
     bool msg_f32;
     // per-row power-of-two lifts of the f16x3 products' A operands (default on; ADF_LIFT=0 = the unlifted split of rounds 1-2)
@@ -226,6 +233,11 @@ static inline int32_t adf_linear(const adf_painn* h, const float* A, int lda, co
     return adf_launch_gemm16(A, lda, W16, bias, C, ldc, M, N, K, act, s, nullptr, 0, h->lift_on ? &h->lift : nullptr,
                              h->lift_on ? premag : nullptr, h->lift_on ? out_mag : nullptr, h->rows_dev);
 }
+// mlp16.hip: fragment image of a split weight [N, K]; the fused two-layer product (see the kernel comment)
+int32_t adf_pack_frag(const adf_w16* w, int N, int K, void* out, hipStream_t s);
+int32_t adf_launch_mlp16(const float* A1, const float* A2, int lda, const float* rmag, const void* W0f, const adf_w16* W0,
+                         const float* bias0, const void* W2f, const adf_w16* W2, int M, int H, int epi, const adf_epi* ep,
+                         hipStream_t s);
 int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s);
 // incremental.hip
 size_t adf_inc_temp_bytes(int64_t n);

@@ -243,6 +243,11 @@ class PaiNNEngine:
         static-atom promise and recompute only rows whose inputs changed.  Bit-identical outputs; default on."""
         _lib.check(self.lib.adf_painn_set_incremental(self.handle, 1 if on else 0))
 
+    def set_fused_mlp(self, mode: int = 2) -> None:
+        """Form of the x_proj / xvec_proj pairs (adf_painn_set_fused_mlp): 0 two kernels per pair, 1 the fused two-layer
+        kernel (csrc/mlp16.hip), 2 by size (default).  Bit-identical results."""
+        _lib.check(self.lib.adf_painn_set_fused_mlp(self.handle, int(mode)))
+
     def build_graph(self, data, prep=None):
         """Graph only; returns the number of symmetrised edges.  ``prep``: an already prepared batch of ``data``."""
         if prep is None:

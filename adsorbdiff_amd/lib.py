@@ -21,7 +21,7 @@ class NumericRangeError(ArithmeticError):
 
 EXPORTS = (
     "adf_painn_create", "adf_painn_destroy", "adf_painn_set_weights", "adf_graph_build", "adf_graph_set_moving",
-    "adf_check_flags", "adf_painn_set_arithmetic", "adf_painn_set_incremental",
+    "adf_check_flags", "adf_painn_set_arithmetic", "adf_painn_set_incremental", "adf_painn_set_fused_mlp",
     "adf_graph_export", "adf_painn_forward", "adf_painn_forward_subset", "adf_linear_forward", "adf_painn_message_layer", "adf_painn_update_layer",
     "adf_sde_init_placement", "adf_sde_step", "adf_sde_step_scheduled", "adf_sample", "adf_sample_traj",
     "adf_frames_create", "adf_frames_destroy", "adf_frames_push", "adf_frames_wait", "adf_frames_release", "adf_frames_pushed", "adf_frames_abort",
@@ -118,6 +118,7 @@ def load():
         "adf_check_flags": [vp, vp],
         "adf_painn_set_arithmetic": [vp, i32],
         "adf_painn_set_incremental": [vp, i32],
+        "adf_painn_set_fused_mlp": [vp, i32],
         "adf_graph_export": [vp, vp, vp, vp, i64, vp, vp, vp, vp, C.POINTER(i64), vp],
         "adf_painn_forward": [vp, C.POINTER(BatchDesc), vp, vp, vp],
         "adf_painn_forward_subset": [vp, C.POINTER(BatchDesc), vp, i32, vp, vp, vp],

@@ -139,6 +139,14 @@ int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32);
  * Calling this (with either value) drops the kept state and zeroes the counters adf_get_counters reports. */
 int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on);
 
+/* Form of the two node MLP pairs of a layer (x_proj: painn_denoising.py:531; xvec_proj: :614-623) at hidden width 512 in the
+ * f16x3 arithmetic: mode 0 (default) = two kernels per pair (product + ScaledSiLU, then product + fused epilogue;
+ * csrc/gemm16.hip), 1 = one kernel per pair with the [rows, 512] intermediate kept in LDS and the weights streamed as MFMA
+ * fragments (csrc/mlp16.hip; round 6: bit-identical results, measured 5-10 % slower per pair on MI355X - its epilogues'
+ * HBM traffic does not overlap its matrix phases at one workgroup per CU, profiles/NOTES.md), 2 = mode 1 from 2 x 64 rows per
+ * CU on.  ADF_FUSED_MLP sets the initial mode.  The fragment images (9 H^2 x 4 bytes per layer) are built on first use. */
+int32_t adf_painn_set_fused_mlp(adf_painn_t h, int32_t mode);
+
 /* Read the device-side error flags of the last graph build (candidate overflow,
  * empty image).  Synchronises the stream.  adf_painn_forward does not check
  * them itself so that a sampling loop stays free of host round trips. */

@@ -504,6 +504,41 @@ def test_sampling_50_steps_teacher_forced_vs_oracle(tmp_path):
     print(f"50-step teacher-forced check: worst error / tolerance = {worst:.3f}")
 
 
+def test_fused_two_layer_mlp_is_bit_identical_to_the_two_kernel_form():
+    """csrc/mlp16.hip (x_proj.0 -> x_proj.2 -> gather records, xvec_proj.0 -> xvec_proj.2 -> gating in one kernel each, the
+    [rows, 512] intermediate in LDS) against the two-kernel form of csrc/gemm16.hip: same lifts, same product order, same
+    epilogue expressions -> the SAME BITS, on a full forward (ragged last 64-row tile), on a subset forward and through
+    the sampler's incremental lists (device-side row counts, mapped record rows).  The fused form is opt-in
+    (adf_painn_set_fused_mlp: measured slower in round 6); the identity keeps it a drop-in."""
+    from adsorbdiff_amd.denoising_torch import Denoiser, DiffTorchCalc
+    from adsorbdiff_amd.trainer import DenoisingTrainer
+
+    torch.manual_seed(0)
+    m = PaiNN(None, 50, 1, hidden_channels=512, num_layers=3, num_rbf=128, cutoff=10.0, max_neighbors=50,
+              scale_file={f"upd_out_scalar_scale_{i}": s for i, s in enumerate((1.1, 0.9, 1.05))}, so3_denoising=True).eval().to(DEV)
+    eng = m.engine()
+    b = make_batch(3, n_slab=205, n_ads=4, seed=1000).to(DEV)   # 627 rows: nine full 64-row tiles + 51 rows
+    out = {}
+    for mode in (0, 1):
+        eng.set_fused_mlp(mode)
+        f1, f2 = m(b.clone())
+        idx = torch.nonzero(b.tags == 2).reshape(-1).to(torch.int32)
+        prep = eng.prepare(b)
+        g1 = torch.zeros_like(f1)
+        g2 = torch.zeros_like(f2)
+        eng.forward_prepared(prep, b.pos.clone().contiguous(), g1, g2, idx)
+        torch.manual_seed(5)
+        params = dict(num_steps=6, ads_std_low=0.1, ads_std_high=10, rot_std_low=0.01, rot_std_high=1.55, ode=True,
+                      early_stop=False, placement_noise=torch.rand(3, 3))
+        pos = Denoiser(b.clone(), DiffTorchCalc(DenoisingTrainer(m, device=DEV)), params, device=DEV).run().pos
+        out[mode] = (f1.clone(), f2.clone(), g1[idx.long()].clone(), g2[idx.long()].clone(), pos.clone())
+    eng.set_fused_mlp(0)
+    assert bool(torch.isfinite(out[1][0]).all()) and float(out[1][0].abs().max()) > 0
+    for a, c, what in zip(out[0], out[1], ("f1", "f2", "subset f1", "subset f2", "sampled positions")):
+        assert torch.equal(a, c), (what, float((a - c).abs().max()))
+    assert torch.equal(out[0][0][idx.long()], out[0][2])   # subset rows == full rows (both forms)
+
+
 def _bench_model():
     """The model the headline is quoted on (bench.py::bench_painn_model: H = 512 x 6, 10 A, K = 50, seed 0, shipped scale
     factors, the last linear map of both heads x 100)."""
