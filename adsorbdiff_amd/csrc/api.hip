@@ -181,13 +181,13 @@ static void inc_free(adf_painn* h) {
 }
 
 static void free_workspaces(adf_painn* h) {
-    void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->scan_tmp,
+    void* ptrs[] = {h->nbr_cnt, h->nbr_src, h->nbr_shift, h->deg, h->nptr, h->cursor, h->img_cnt, h->sys_slow, h->scan_tmp,
                     h->e_src, h->e_geom, h->x, h->vecA, h->vecB, h->y, h->xh, h->vv, h->cat, h->dot, h->sys, h->rec, h->lift.buf, h->mag_a, h->mag_b, h->mag_v3,
                     h->cache_d2, h->cache_cid, h->cache_cnt, h->prev_nptr, h->prev_src, h->prev_geom};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     h->prev_nptr = h->prev_src = nullptr; h->prev_geom = nullptr; h->inc_valid = false;
-    h->nbr_cnt = h->nbr_src = h->nbr_shift = h->deg = h->nptr = h->cursor = h->img_cnt = h->e_src = nullptr;
+    h->nbr_cnt = h->nbr_src = h->nbr_shift = h->deg = h->nptr = h->cursor = h->img_cnt = h->sys_slow = h->e_src = nullptr;
     h->scan_tmp = nullptr; h->scan_tmp_bytes = 0;
     h->e_geom = nullptr;
     h->x = h->vecA = h->vecB = h->y = h->xh = h->vv = h->cat = h->dot = h->sys = h->rec = nullptr;
@@ -353,6 +353,7 @@ static int32_t ensure_capacity(adf_painn* h, int64_t N, int64_t B) {
     ALLOC(nptr, capN + 1);
     ALLOC(cursor, capN);
     ALLOC(img_cnt, capB);
+    ALLOC(sys_slow, capB);
     ALLOC(e_src, capE);
     ALLOC(e_geom, capE);
     if (h->inc_on) {  // previous build's CSR (incremental layers); swapped with the live one per build

@@ -131,6 +131,7 @@ struct adf_painn {
     int32_t* nptr;       // [N+1] exclusive scan = CSR row pointer over targets
     int32_t* cursor;     // [N]   fill cursors
     int32_t* img_cnt;    // [B]   directed edges per image (empty-image check)
+    int32_t* sys_slow;   // [B]   1 = the system does not fit the per-system LDS kernels of the CSR build (graph.hip)
     void* scan_tmp;      // hipcub scan workspace
     size_t scan_tmp_bytes;
     // static-atom cache of the top-K kernel (adf_graph_set_moving)

@@ -47,28 +47,43 @@ struct TopkLds {
     int32_t kept[4][ADF_MAX_K];
 };
 
-// rank selection among entries with (id & skip_mask) == 0; returns per-lane keep bits for e = lane + 64 t
+// rank selection among entries with (id & skip_mask) == 0; returns per-lane keep bits for e = lane + 64 t.
+// Order: (d^2, candidate index).  d^2 > 1e-4 > 0, so its bit pattern orders like the float and the pair packs into one
+// 64-bit key: one compare per pair instead of three (round 6; the graph build of a reverse step spent 0.85 ms here).
+// Lists of at most 64 entries (the static-atom path: K cached + the moving atoms' candidates) take the one-entry-per-lane
+// form; longer ones keep four entries per lane.
 __device__ __forceinline__ unsigned int topk_select(const TopkLds& L, int w, int lane, int M, int K, int skip_mask) {
     const int T = (M + 63) >> 6;  // <= 16
     unsigned int keepbits = 0;
+    auto key_of = [&](int e) -> unsigned long long {
+        return ((unsigned long long)__float_as_uint(L.d2[w][e]) << 32) | (unsigned int)(L.id[w][e] & ~MOVBIT);
+    };
+    if (T == 1) {
+        const int raw = lane < M ? L.id[w][lane] : 0;
+        const bool use = lane < M && (raw & skip_mask) == 0;
+        const unsigned long long kq = use ? key_of(lane) : ~0ull;
+        int rank = 0;
+        for (int f = 0; f < M; ++f) {
+            if (L.id[w][f] & skip_mask) continue;  // wave-uniform
+            rank += key_of(f) < kq ? 1 : 0;
+        }
+        return (use && rank < K) ? 1u : 0u;
+    }
     for (int t0 = 0; t0 < T; t0 += 4) {  // 4 entries of this lane at a time
-        float d[4]; int id[4]; int rank[4]; bool use[4];
+        unsigned long long kq[4]; int rank[4]; bool use[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = lane + 64 * (t0 + u);
             const int raw = e < M ? L.id[w][e] : 0;
             use[u] = e < M && (raw & skip_mask) == 0;
-            d[u] = use[u] ? L.d2[w][e] : 3.0e38f;
-            id[u] = raw & ~MOVBIT;
+            kq[u] = use[u] ? key_of(e) : ~0ull;
             rank[u] = 0;
         }
         for (int f = 0; f < M; ++f) {
-            const int rawf = L.id[w][f];
-            if (rawf & skip_mask) continue;  // wave-uniform
-            const float df = L.d2[w][f];
-            const int idf = rawf & ~MOVBIT;
+            if (L.id[w][f] & skip_mask) continue;  // wave-uniform
+            const unsigned long long kf = key_of(f);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rank[u] += ((df < d[u]) || (df == d[u] && idf < id[u])) ? 1 : 0;
+            for (int u = 0; u < 4; ++u) rank[u] += kf < kq[u] ? 1 : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -220,11 +235,13 @@ __device__ __forceinline__ bool edge_kept(int j, int i, int c, int r0, int r1, i
     return (sa < 0.f) || (sa == 0.f && sb < 0.f) || (sa == 0.f && sb == 0.f && sc < 0.f);
 }
 
-__global__ void adf_count_kernel(GraphParams p, int32_t* deg) {
+// only: null = every system; else the systems flagged in it (the ones the per-system LDS kernels below passed on)
+__global__ void adf_count_kernel(GraphParams p, int32_t* deg, const int32_t* __restrict__ only) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = (int)(t / p.K);
     const int k = (int)(t - (long long)i * p.K);
     if (i >= p.N || k >= p.nbr_cnt[i]) return;
+    if (only && !only[p.batch[i]]) return;
     const int j = p.nbr_src[(size_t)i * p.K + k];
     const int c = p.nbr_shift[(size_t)i * p.K + k];
     if (!edge_kept(j, i, c, p.r0, p.r1, p.r2)) return;
@@ -241,11 +258,12 @@ __global__ void adf_validate_kernel(const int32_t* nptr, int N, long long capE, 
 }
 
 __global__ void adf_fill_kernel(GraphParams p, const int32_t* nptr, int32_t* cursor, int32_t* e_src, float4* e_geom,
-                                long long capE) {
+                                long long capE, const int32_t* __restrict__ only) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int i = (int)(t / p.K);
     const int k = (int)(t - (long long)i * p.K);
     if (i >= p.N || k >= p.nbr_cnt[i]) return;
+    if (only && !only[p.batch[i]]) return;
     const int j = p.nbr_src[(size_t)i * p.K + k];
     const int c = p.nbr_shift[(size_t)i * p.K + k];
     if (!edge_kept(j, i, c, p.r0, p.r1, p.r2)) return;
@@ -285,12 +303,14 @@ __device__ __forceinline__ bool edge_before(const float4& h, int sf, const float
 }
 
 __global__ __launch_bounds__(256) void adf_sort_edges_kernel(const int32_t* nptr, int32_t* e_src, float4* e_geom,
-                                                              int N, int32_t* flags) {
+                                                              int N, int32_t* flags, const int32_t* __restrict__ only,
+                                                              const int32_t* __restrict__ batch) {
     __shared__ float4 s_geo[4][SORT_MAX];
     __shared__ int32_t s_src[4][SORT_MAX];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + w;
     if (n >= N) return;
+    if (only && !only[batch[n]]) return;
     const int e0 = nptr[n];
     int deg = nptr[n + 1] - e0;
     // In-degree = own kept entries (<= K) + every centre that lists this atom, so only sum(deg) <= 2NK is bounded:
@@ -340,6 +360,177 @@ __global__ __launch_bounds__(256) void adf_sort_edges_kernel(const int32_t* nptr
     }
 }
 
+// ---- Round 6: count / fill / sort of a whole system out of LDS (one workgroup per system).
+// The global-memory pipeline above spends its time on atomics and scattered 20-byte stores (count 0.33 + fill 0.80 + sort
+// 0.39 ms per build of 1000 x 200 atoms).  A system of <= CSR_SYS_MAX atoms fits a workgroup: its kept directed entries
+// are dealt to their SOURCE atom's bucket in LDS (16-bit references: owner of the list, slot), and one wave per target then
+// forms the target's records - its own kept entries plus the reversed copies of the bucket's - with the fill kernel's
+// arithmetic, ranks them with the sort kernel's order and writes the segment once, coalesced.  Same nptr / e_src / e_geom,
+// bit for bit (tests/test_gpu_parity.py graph fixtures, test_system_csr_kernels_equal_the_global_pipeline).  A system
+// that does not fit (more atoms, longer lists or more lattice shifts than the 16-bit references hold, a bucket beyond
+// CSR_REF_CAP, a target beyond CSR_SEG_MAX records) is flagged and goes through the global-memory kernels, which skip
+// every other system.  The second kernel also keeps the system's directed lists and positions in LDS, so a target's
+// records are formed without a global load (first version, lists and positions from L2: 1.14 ms per build, no gain).
+#define CSR_SYS_MAX 256    // atoms per system
+#define CSR_K_MAX 64       // directed list length (max_neighbors)
+#define CSR_C_MAX 256      // lattice shifts (a reference is 8 bits of atom + 8 bits of shift)
+#define CSR_REF_CAP 96     // kept entries of OTHER atoms' lists naming one atom as their source
+#define CSR_SEG_MAX 128    // records of one target the per-wave sorter holds
+
+__device__ __forceinline__ bool csr_fits(const GraphParams& p, int n) {
+    return n <= CSR_SYS_MAX && p.K <= CSR_K_MAX && (2 * p.r0 + 1) * (2 * p.r1 + 1) * (2 * p.r2 + 1) <= CSR_C_MAX;
+}
+
+__global__ __launch_bounds__(256) void adf_count_sys_kernel(GraphParams p, int32_t* __restrict__ deg, int32_t* __restrict__ slow) {
+    __shared__ int32_t cnt[CSR_SYS_MAX];
+    const int b = blockIdx.x;
+    const int a0 = p.atom_offset[b], n = p.atom_offset[b + 1] - a0;
+    if (!csr_fits(p, n)) {
+        if (threadIdx.x == 0) slow[b] = 1;   // adf_count_kernel takes this system
+        return;
+    }
+    if (threadIdx.x == 0) slow[b] = 0;
+    for (int t = threadIdx.x; t < n; t += 256) cnt[t] = 0;
+    __syncthreads();
+    const int K = p.K;
+    for (int sl = threadIdx.x; sl < n * K; sl += 256) {
+        const int il = sl / K, k = sl - il * K, i = a0 + il;
+        if (k >= p.nbr_cnt[i]) continue;
+        const int j = p.nbr_src[(size_t)i * K + k];
+        const int c = p.nbr_shift[(size_t)i * K + k];
+        if (!edge_kept(j, i, c, p.r0, p.r1, p.r2)) continue;
+        atomicAdd(&cnt[il], 1);
+        atomicAdd(&cnt[j - a0], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n; t += 256) deg[a0 + t] = cnt[t];
+}
+
+struct CsrLds {
+    unsigned short ent[CSR_SYS_MAX][CSR_K_MAX];     // directed lists of the system: (local source << 8) | shift
+    unsigned short refs[CSR_SYS_MAX][CSR_REF_CAP];  // per source atom: (local owner of the list << 8) | shift, kept entries only
+    int32_t rcnt[CSR_SYS_MAX];
+    unsigned char ncnt[CSR_SYS_MAX];
+    float pos[CSR_SYS_MAX * 3];
+    float4 s_geo[16][CSR_SEG_MAX];
+    int32_t s_src[16][CSR_SEG_MAX];
+    unsigned long long s_key[16][CSR_SEG_MAX];      // (distance bits << 32) | source: the leading two fields of the sort order
+    int32_t bad;
+};
+
+// the record of directed entry (centre i, source j, shift c) as adf_fill_kernel forms it: (unit vector i -> j, distance);
+// il, jl: local indices into the LDS copy of the system's positions (the same floats)
+__device__ __forceinline__ float4 csr_edge_geom(const GraphParams& p, const float* __restrict__ cl, const float* spos, int il,
+                                                int jl, int c) {
+    float sa, sb, sc;
+    decode_shift(c, p.r0, p.r1, p.r2, sa, sb, sc);
+    const float ox = __fadd_rn(__fadd_rn(__fmul_rn(sa, cl[0]), __fmul_rn(sb, cl[3])), __fmul_rn(sc, cl[6]));
+    const float oy = __fadd_rn(__fadd_rn(__fmul_rn(sa, cl[1]), __fmul_rn(sb, cl[4])), __fmul_rn(sc, cl[7]));
+    const float oz = __fadd_rn(__fadd_rn(__fmul_rn(sa, cl[2]), __fmul_rn(sb, cl[5])), __fmul_rn(sc, cl[8]));
+    const float vx = __fadd_rn(__fsub_rn(spos[3 * jl], spos[3 * il]), ox);
+    const float vy = __fadd_rn(__fsub_rn(spos[3 * jl + 1], spos[3 * il + 1]), oy);
+    const float vz = __fadd_rn(__fsub_rn(spos[3 * jl + 2], spos[3 * il + 2]), oz);
+    float d = sqrtf(fmaf(vz, vz, fmaf(vy, vy, vx * vx)));
+    if (fabsf(d) <= 1.0e-3f) d = 1.0e-3f;
+    return make_float4(vx / d, vy / d, vz / d, d);
+}
+
+__global__ __launch_bounds__(1024) void adf_fill_sort_sys_kernel(GraphParams p, const int32_t* __restrict__ nptr,
+                                                                  int32_t* __restrict__ e_src, float4* __restrict__ e_geom,
+                                                                  long long capE, int32_t* __restrict__ slow) {
+    __shared__ CsrLds L;
+    const int b = blockIdx.x;
+    if (slow[b]) return;   // does not fit: the global-memory kernels build this system
+    const int a0 = p.atom_offset[b], n = p.atom_offset[b + 1] - a0;
+    const int K = p.K, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const float* cl = p.cell + 9 * b;
+    for (int t = tid; t < n; t += 1024) { L.rcnt[t] = 0; L.ncnt[t] = (unsigned char)p.nbr_cnt[a0 + t]; }
+    for (int t = tid; t < 3 * n; t += 1024) L.pos[t] = p.pos[3 * (size_t)a0 + t];
+    if (tid == 0) L.bad = 0;
+    __syncthreads();
+    // 1. the system's directed lists -> LDS; every kept entry (i, k) also -> the bucket of its source j
+    for (int sl = tid; sl < n * K; sl += 1024) {
+        const int il = sl / K, k = sl - il * K, i = a0 + il;
+        if (k >= (int)L.ncnt[il]) continue;
+        const int j = p.nbr_src[(size_t)i * K + k];
+        const int c = p.nbr_shift[(size_t)i * K + k];
+        L.ent[il][k] = (unsigned short)(((j - a0) << 8) | c);
+        if (!edge_kept(j, i, c, p.r0, p.r1, p.r2)) continue;
+        const int r = atomicAdd(&L.rcnt[j - a0], 1);
+        if (r < CSR_REF_CAP) L.refs[j - a0][r] = (unsigned short)((il << 8) | c);
+        else L.bad = 1;
+    }
+    // a segment beyond the per-wave sorter, or beyond the edge capacity (flag 2 is raised by adf_validate_kernel)
+    for (int t = tid; t < n; t += 1024) {
+        const int dg = nptr[a0 + t + 1] - nptr[a0 + t];
+        if (dg > CSR_SEG_MAX || (long long)nptr[a0 + t + 1] > capE) L.bad = 1;
+    }
+    __syncthreads();
+    if (L.bad) {
+        if (tid == 0) slow[b] = 1;   // adf_fill_kernel + adf_sort_edges_kernel take this system
+        return;
+    }
+    // 2. one wave per target: gather, rank, write
+    for (int tl = w; tl < n; tl += 16) {
+        const int t = a0 + tl;
+        const int e0 = nptr[t], dg = nptr[t + 1] - e0;
+        // own kept entries: edge j -> t, compacted by ballot (the order inside a segment is settled by the ranks)
+        int m = 0;
+        const int own = (int)L.ncnt[tl];
+        for (int k0 = 0; k0 < own; k0 += 64) {
+            const int k = k0 + lane;
+            bool keep = false;
+            int jl = 0, c = 0;
+            if (k < own) {
+                const int e = L.ent[tl][k];
+                jl = e >> 8; c = e & 255;
+                keep = edge_kept(a0 + jl, t, c, p.r0, p.r1, p.r2);
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const int at = m + __popcll(bal & ((1ull << lane) - 1ull));
+                const float4 g = csr_edge_geom(p, cl, L.pos, tl, jl, c);
+                L.s_geo[w][at] = g;
+                L.s_src[w][at] = a0 + jl;
+                L.s_key[w][at] = ((unsigned long long)__float_as_uint(g.w) << 32) | (unsigned int)(a0 + jl);
+            }
+            m += __popcll(bal);
+        }
+        // reversed copies of the entries that name t as their source: src = the list's owner, negated unit vector
+        const int nr = L.rcnt[tl];
+        for (int r = lane; r < nr; r += 64) {
+            const int ref = L.refs[tl][r];
+            const int il = ref >> 8, c = ref & 255;
+            const float4 g = csr_edge_geom(p, cl, L.pos, il, tl, c);
+            L.s_geo[w][m + r] = make_float4(-g.x, -g.y, -g.z, g.w);
+            L.s_src[w][m + r] = a0 + il;
+            L.s_key[w][m + r] = ((unsigned long long)__float_as_uint(g.w) << 32) | (unsigned int)(a0 + il);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int q = lane; q < dg; q += 64) {
+            const float4 g = L.s_geo[w][q];
+            const int sj = L.s_src[w][q];
+            // rank on the 64-bit (distance, source) key (distances are positive: their bit patterns order like the floats);
+            // only records that share both - lattice images of one atom at one distance - need the full comparison
+            const unsigned long long kq = L.s_key[w][q];
+            int rank = 0, eq = 0;
+            for (int f = 0; f < dg; ++f) {
+                const unsigned long long kf = L.s_key[w][f];
+                rank += kf < kq ? 1 : 0;
+                eq += kf == kq ? 1 : 0;
+            }
+            if (eq > 1) {
+                rank = 0;
+                for (int f = 0; f < dg; ++f) rank += edge_before(L.s_geo[w][f], L.s_src[w][f], g, sj) ? 1 : 0;
+            }
+            e_geom[e0 + rank] = g;
+            e_src[e0 + rank] = sj;
+        }
+        __builtin_amdgcn_wave_barrier();   // the wave's scratch is refilled by its next target
+    }
+}
+
 // The directed strict top-K stage alone (the EquiformerV2 path uses it without the symmetrisation): mode 0 full
 // evaluation, 1 full + fill the static-atom cache, 2 rebuild static centres from the cache.
 int32_t adf_topk_launch(const GraphParams& p, int mode, hipStream_t s) {
@@ -379,16 +570,27 @@ int32_t adf_graph_build_impl(adf_painn* h, const adf_batch* b, hipStream_t s) {
     }
     const long long slots = (long long)N * K;
     const unsigned nb = (unsigned)((slots + 255) / 256);
-    hipLaunchKernelGGL(adf_count_kernel, dim3(nb), dim3(256), 0, s, p, h->deg);
+    // count / fill / sort: per system out of LDS (above); systems that do not fit go through the global-memory kernels
+    static int sys_csr = -1;
+    if (sys_csr < 0) { const char* e = getenv("ADF_GRAPH_SYS_CSR"); sys_csr = (e && atoi(e) == 0) ? 0 : 1; }
+    const int32_t* only = nullptr;
+    if (sys_csr) {
+        hipLaunchKernelGGL(adf_count_sys_kernel, dim3(B), dim3(256), 0, s, p, h->deg, h->sys_slow);
+        only = h->sys_slow;
+    }
+    hipLaunchKernelGGL(adf_count_kernel, dim3(nb), dim3(256), 0, s, p, h->deg, only);
     size_t tmp = h->scan_tmp_bytes;
     ADF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(h->scan_tmp, tmp, h->deg, h->nptr, N + 1, s));
     const int vb = (max(B, 1) + 255) / 256;
     hipLaunchKernelGGL(adf_validate_kernel, dim3(vb), dim3(256), 0, s, h->nptr, N, (long long)h->capE, h->img_cnt, B,
                        h->flags);
+    if (only)
+        hipLaunchKernelGGL(adf_fill_sort_sys_kernel, dim3(B), dim3(1024), 0, s, p, h->nptr, h->e_src, h->e_geom,
+                           (long long)h->capE, h->sys_slow);
     hipLaunchKernelGGL(adf_fill_kernel, dim3(nb), dim3(256), 0, s, p, h->nptr, h->cursor, h->e_src, h->e_geom,
-                       (long long)h->capE);
+                       (long long)h->capE, only);
     hipLaunchKernelGGL(adf_sort_edges_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->nptr, h->e_src, h->e_geom, N,
-                       h->flags);
+                       h->flags, only, p.batch);
     ADF_HIP_CHECK(hipGetLastError());
     h->lastN = N; h->lastB = B;
     h->last_reps[0] = p.r0; h->last_reps[1] = p.r1; h->last_reps[2] = p.r2;

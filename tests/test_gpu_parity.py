@@ -987,6 +987,72 @@ def test_hub_atom_with_many_incoming_edges():
     assert rel_err(f1.cpu(), o1) < REL_TOL and rel_err(f2.cpu(), o2) < REL_TOL
 
 
+_CSR_SCRIPT = r"""
+import math, sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from adsorbdiff_amd.data import Batch
+from adsorbdiff_amd.painn_denoising import PaiNN
+from adsorbdiff_amd.synthetic import make_batch, make_system
+out = {{}}
+def export(name, b, **hp):
+    torch.manual_seed(0)
+    m = PaiNN(None, 50, 1, hidden_channels=128, num_layers=1, so3_denoising=True, **hp).to("cuda:0").eval()
+    eng = m.engine()
+    E = eng.build_graph(b.clone().to("cuda:0"))
+    cnt, src, sh, es, ed, dist, vec = eng.export_graph()
+    for k, v in (("es", es), ("ed", ed), ("dist", dist), ("vec", vec)):
+        out[name + "_" + k] = v.cpu().numpy()
+    out[name + "_E"] = np.int64(E)
+# (a) benchmark-shaped systems; (b) small cells with many periodic images; (c) a system of 300 atoms (> 256: global path)
+#     between two that fit; (d) the hub atom: one segment beyond the per-wave sorter
+export("bench", make_batch(5, seed=1000), cutoff=10.0, max_neighbors=50)
+export("img", make_batch(4, n_slab=9, n_ads=4, seed=60), cutoff=6.0, max_neighbors=20)
+g = torch.Generator().manual_seed(3)
+export("mixed", Batch.from_data_list([make_system(g, 196, 4, "0"), make_system(g, 296, 4, "1"), make_system(g, 100, 4, "2")]),
+       cutoff=10.0, max_neighbors=50)
+torch.manual_seed(11)
+n = 900
+r = torch.exp(torch.rand(n - 1) * math.log(11.0 / 0.02)) * 0.02
+pos = torch.zeros(n, 3)
+pos[1:] = torch.nn.functional.normalize(torch.randn(n - 1, 3), dim=1) * r[:, None]
+b = Batch()
+b.pos = (pos + 50.0).float(); b.atomic_numbers = torch.randint(1, 80, (n,)).float()
+b.tags = torch.ones(n, dtype=torch.long); b.fixed = torch.zeros(n, dtype=torch.long)
+b.cell = (torch.eye(3) * 100.0).reshape(1, 3, 3); b.natoms = torch.tensor([n]); b.batch = torch.zeros(n, dtype=torch.long)
+b.sid = ["hub"]
+export("hub", b, cutoff=12.0, max_neighbors=120)
+small = Batch.from_data_list(make_batch(2, seed=7).to_data_list() + [b.to_data_list()[0]])
+export("hubmixed", small, cutoff=12.0, max_neighbors=120)
+np.savez({dst!r}, **out)
+"""
+
+
+def test_system_csr_kernels_equal_the_global_pipeline(tmp_path):
+    """Round 6: count / fill / sort of a system out of LDS (graph.hip, one workgroup per system) against the global-memory
+    pipeline it replaces (ADF_GRAPH_SYS_CSR=0; the switch is read once per process, hence two children): the exported
+    symmetrised graph - edge order inside every target's segment included - must be the SAME BYTES, for systems that fit,
+    for one that does not (300 atoms between two that do), and for a hub atom whose segment exceeds the per-wave sorter."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parent.parent)
+    res = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, ADF_GRAPH_SYS_CSR=mode)
+        dst = str(tmp_path / f"csr{mode}.npz")
+        r = subprocess.run([sys.executable, "-c", _CSR_SCRIPT.format(root=root, dst=dst)], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = dict(np.load(dst))
+    assert set(res["0"]) == set(res["1"])
+    for k in sorted(res["0"]):
+        a, b_ = res["0"][k], res["1"][k]
+        assert a.shape == b_.shape and a.tobytes() == b_.tobytes(), k
+    assert int(res["1"]["bench_E"]) > 40000 and int(np.bincount(res["1"]["hub_ed"]).max()) > 256
+
+
 def test_calculator_single_structure_api():
     """AdsorbDiffCalculator.run_diffusion on one structure against the CPU oracle's reverse loop on the same system with the
     same placement noise (the calculator seeds torch's CPU generator, the Denoiser draws torch.rand(1, 3) from it -
