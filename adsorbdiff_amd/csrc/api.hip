@@ -145,6 +145,7 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         if (st == ADF_OK) st = dev_alloc(&h->w16_scales, 256);
         if (st == ADF_OK) st = dev_alloc(&h->w16_bias_perm, (size_t)L * 2 * 3 * H);
         if (st == ADF_OK) st = dev_alloc(&h->w16_scratch, 1);
+        if (st == ADF_OK) st = dev_alloc(&h->vpfrag_arena, (size_t)L * 2 * HH * 2 * sizeof(uint16_t));
         {   // form of the x_proj / xvec_proj pairs: the two-kernel form unless asked otherwise (mlp16.hip: measured slower)
             const char* ef = getenv("ADF_FUSED_MLP");
             h->fused_mlp = ef ? atoi(ef) : 0;
@@ -216,6 +217,7 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->kcount) (void)hipFree(h->kcount);
     if (h->w16_arena) (void)hipFree(h->w16_arena);
     if (h->wfrag_arena) (void)hipFree(h->wfrag_arena);
+    if (h->vpfrag_arena) (void)hipFree(h->vpfrag_arena);
     if (h->w16_scales) (void)hipFree(h->w16_scales);
     if (h->w16_bias_perm) (void)hipFree(h->w16_bias_perm);
     if (h->w16_scratch) (void)hipFree(h->w16_scratch);
@@ -318,6 +320,10 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
         }
         h->wfrag_valid = false;
         if (h->fused_mlp != 0) ADF_TRY(pack_fragment_images(h, s));
+        for (int l = 0; l < L; ++l) {   // vec_proj streams its weights as MFMA fragments (gemm16.hip, WR)
+            h->layer[l].vp_f = h->vpfrag_arena + (size_t)l * 2 * HH * 4;
+            ADF_TRY(adf_pack_frag(&h->layer[l].vp_16, (int)(2 * H), (int)H, h->layer[l].vp_f, s));
+        }
         if ((size_t)(cur - h->w16_arena) > h->w16_bytes || nscale > 256) {
             adf_set_error("internal: fp16 weight arena overflow");
             return ADF_EINVAL;
@@ -575,6 +581,7 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
               // xvec_proj.0 then reads its [x | |v2|] input from the two arrays
         adf_epi ep = {};
         ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H; ep.m_dev = h->rows_dev;
+        ep.wfrag = w.vp_f;
         const adf_lift* lf = h->lift_on ? &h->lift : nullptr;
         // vec rows and the [x | |v2|] rows are measured by a pass of their own; xvec_proj.0 hands its output rows' on.
         // (Measured alternative: the message kernel emitting the magnitudes of its vec_out rows - DPP maxima per

@@ -78,7 +78,10 @@ __device__ __forceinline__ float adf_row16_max(float v) {
 //   its 32 atoms; the two column blocks are v1 and v2 of the same 32 channels (weights row-permuted: column
 //   g*64 + part*32 + q  <->  row part*H + 32g + q).  dot = sum_xyz v1*v2 / sqrt(H) and |v2| ([N,H] each) are formed
 //   on the accumulators: v2 (1.2 GB per layer at N = 200k) never goes to HBM and the separate reduction pass is gone.
-template <int ACT, int MI, int NJ, int EPI>
+//   WR (round 6, vec_proj): the weights are NOT staged through LDS - every wave loads the MFMA B fragments of its own columns
+//   straight from a fragment-ordered image (adf_pack_frag, mlp16.hip; `Whi` then points at that image) one K tile ahead; LDS
+//   holds the A tile only.  Same products in the same order: same bits.
+template <int ACT, int MI, int NJ, int EPI, bool WR = false>
 __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const float* __restrict__ A, int lda, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ C, int ldc, int Mh, int N,
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     constexpr int TM = 64 * MI;   // rows per workgroup
     constexpr int TN = 64 * NJ;   // columns per workgroup
     constexpr int NA = TM / 32;   // float4 A loads per thread
-    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * HLD];
+    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * HLD];   // (WR: the W half is only the epilogues' scratch)
     __shared__ float rinv[TM];  // 1 / lift of every staged A row
     _Float16* Ahi = lds;
     _Float16* Alo = Ahi + TM * HLD;
@@ -150,11 +153,25 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     half8 rwh[NJ], rwl[NJ];
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(A1b + a_goff[i]);
+    if constexpr (!WR) {
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) {
-        rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i]);
-        rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i]);
+        for (int i = 0; i < NJ; ++i) {
+            rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i]);
+            rwl[i] = *reinterpret_cast<const half8*>(Wlo + w_src[i]);
+        }
     }
+    // WR: B fragments of one 16-deep k-step for this wave's NJ column blocks: [column block][hi | lo]; two register sets
+    half8 wfa[NJ][2], wfb[NJ][2];
+    const half8* const wfr = reinterpret_cast<const half8*>(Whi) + (size_t)((n0 + wn) / 32) * (K / 16) * 128 + lane;
+    auto load_wf = [&](int s_, half8 (&wf)[NJ][2]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const size_t base = ((size_t)j * (K / 16) + s_) * 128;
+            wf[j][0] = wfr[base];
+            wf[j][1] = wfr[base + 64];
+        }
+    };
+    if constexpr (WR) load_wf(0, wfa);
 
     f32x16 acc[MI][NJ];
 #pragma unroll
@@ -167,8 +184,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const int nk = K / HK;
     const int fa = (wm + (lane & 31)) * HLD + (lane >> 5) * 8;
     const int fb = (wn + (lane & 31)) * HLD + (lane >> 5) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
+    auto stage_a = [&](int boff = 0) {   // boff: halves; WR: the A buffer being filled (0 or 2 TM HLD)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const float sx = ra[i].x * a_rs[i], sy = ra[i].y * a_rs[i], sz = ra[i].z * a_rs[i], sw = ra[i].w * a_rs[i];
@@ -176,9 +192,55 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             h[0] = (_Float16)sx; h[1] = (_Float16)sy; h[2] = (_Float16)sz; h[3] = (_Float16)sw;
             l[0] = (_Float16)(sx - (float)h[0]); l[1] = (_Float16)(sy - (float)h[1]);
             l[2] = (_Float16)(sz - (float)h[2]); l[3] = (_Float16)(sw - (float)h[3]);
-            *reinterpret_cast<half4*>(Ahi + a_off[i]) = h;
-            *reinterpret_cast<half4*>(Alo + a_off[i]) = l;
+            *reinterpret_cast<half4*>(Ahi + boff + a_off[i]) = h;
+            *reinterpret_cast<half4*>(Alo + boff + a_off[i]) = l;
         }
+    };
+    auto request_a = [&](int kt1) {
+        const int k1 = kt1 * HK;
+        const char* ab = ((ep.K1 > 0 && k1 >= ep.K1) ? A2b : A1b) + (size_t)k1 * 4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ab + a_goff[i]);
+    };
+    if constexpr (WR) {
+        // one K tile: A through LDS as before; the B fragments of a k-step are requested one k-step ahead, right behind the
+        // barrier resp. in front of the second k-step's products (sched_barrier: hipcc would sink the requests to their first
+        // use, mlp16.hip).  (A whole tile ahead - four register sets - spills 28 registers beside the 96 accumulators.)
+        auto kstep = [&](int boff, int ks, const half8 (&cur)[NJ][2]) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const half8 ah = *reinterpret_cast<const half8*>(Ahi + boff + fa + i * 32 * HLD + ks * 16);
+                const half8 al = *reinterpret_cast<const half8*>(Alo + boff + fa + i * 32 * HLD + ks * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, cur[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur[j][0], acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        // (Measured and dropped: two A buffers in the LDS the W tiles no longer need and ONE barrier per K tile, tile kt + 1
+        // converted behind tile kt's products - node products 1829-1833 ms per pass against 1812 with this form and 1825-1829
+        // with the weights staged through LDS: the conversion then sits behind every wave's own products instead of beside
+        // the other workgroup's.)
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();
+            stage_a();
+            __syncthreads();
+            request_a(min(kt + 1, nk - 1));          // (behind the last tile: a re-read nobody uses; no branch around the loads)
+            load_wf(2 * kt + 1, wfb);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(0, 0, wfa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_wf(min(2 * kt + 2, 2 * nk - 1), wfa);
+            __builtin_amdgcn_sched_barrier(0);
+            kstep(0, 1, wfb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        stage_a();
 #pragma unroll
         for (int i = 0; i < NJ; ++i) {
             *reinterpret_cast<half8*>(Bhi + w_off[i]) = rwh[i];
@@ -187,9 +249,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         __syncthreads();
         if (kt + 1 < nk) {
             const int k1 = (kt + 1) * HK;
-            const char* ab = ((ep.K1 > 0 && k1 >= ep.K1) ? A2b : A1b) + (size_t)k1 * 4;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ab + a_goff[i]);
+            request_a(kt + 1);
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
                 rwh[i] = *reinterpret_cast<const half8*>(Whi + w_src[i] + k1);
@@ -217,6 +277,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 }
             }
         }
+    }
     }
 
     const float isc = *inv_scale;
@@ -673,6 +734,13 @@ int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
     if (epi == 3) {  // vec_proj: A = vec [N,3,H], weights [2H, K] permuted in (v1, v2) pairs; M = atoms
         const int tn = 2 * H / 128, tm8 = ((M + 63) / 64 + 7) / 8 * 8;
+        static int wreg = -1;   // ADF_GEMM_WREG=0: weights staged through LDS as in rounds 1-5
+        if (wreg < 0) { const char* e = getenv("ADF_GEMM_WREG"); wreg = (e && atoi(e) == 0) ? 0 : 1; }
+        if (wreg && ep->wfrag)
+            hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 3, true>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
+                               (const _Float16*)ep->wfrag, (const _Float16*)nullptr, W->inv_scale, (const float*)nullptr,
+                               (float*)nullptr, 0, M, 2 * H, K, tn, *ep);
+        else
         hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 3>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
                            (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, (const float*)nullptr,
                            (float*)nullptr, 0, M, 2 * H, K, tn, *ep);
