@@ -145,7 +145,7 @@ extern "C" int32_t adf_painn_create(const adf_painn_hparams* hp, adf_painn_t* ou
         if (st == ADF_OK) st = dev_alloc(&h->w16_scales, 256);
         if (st == ADF_OK) st = dev_alloc(&h->w16_bias_perm, (size_t)L * 2 * 3 * H);
         if (st == ADF_OK) st = dev_alloc(&h->w16_scratch, 1);
-        if (st == ADF_OK) st = dev_alloc(&h->vpfrag_arena, (size_t)L * 2 * HH * 2 * sizeof(uint16_t));
+        if (st == ADF_OK) st = dev_alloc(&h->wfrag_arena, h->w16_bytes);
         {   // form of the x_proj / xvec_proj pairs: the two-kernel form unless asked otherwise (mlp16.hip: measured slower)
             const char* ef = getenv("ADF_FUSED_MLP");
             h->fused_mlp = ef ? atoi(ef) : 0;
@@ -217,37 +217,12 @@ extern "C" int32_t adf_painn_destroy(adf_painn_t h) {
     if (h->kcount) (void)hipFree(h->kcount);
     if (h->w16_arena) (void)hipFree(h->w16_arena);
     if (h->wfrag_arena) (void)hipFree(h->wfrag_arena);
-    if (h->vpfrag_arena) (void)hipFree(h->vpfrag_arena);
     if (h->w16_scales) (void)hipFree(h->w16_scales);
     if (h->w16_bias_perm) (void)hipFree(h->w16_bias_perm);
     if (h->w16_scratch) (void)hipFree(h->w16_scratch);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
     delete h->prof_cat;
     delete h;
-    return ADF_OK;
-}
-
-// Fragment images of the four MLP weights of every layer for the fused two-layer kernel (mlp16.hip): 9 H^2 x 4 bytes per
-// layer, allocated and packed only when that form is asked for (ADF_FUSED_MLP / adf_painn_set_fused_mlp); H = 512 only.
-static int32_t pack_fragment_images(adf_painn* h, hipStream_t s) {
-    const long long H = h->hp.hidden_channels, HH = H * H;
-    const int L = h->hp.num_layers;
-    if (H != 512) return ADF_OK;   // (use_fused_mlp then never picks the fused form)
-    if (!h->wfrag_arena) ADF_TRY(dev_alloc(&h->wfrag_arena, (size_t)L * 9 * HH * 2 * sizeof(uint16_t)));
-    unsigned char* fc = h->wfrag_arena;
-    auto frag = [&](const adf_w16* w, int N, int K, void** out) -> int32_t {
-        *out = fc;
-        fc += (size_t)N * K * 4;
-        return adf_pack_frag(w, N, K, *out, s);
-    };
-    for (int l = 0; l < L; ++l) {
-        adf_layer_weights& lw = h->layer[l];
-        ADF_TRY(frag(&lw.xp0_16, (int)H, (int)H, &lw.xp0_f));
-        ADF_TRY(frag(&lw.xp2_16, (int)(3 * H), (int)H, &lw.xp2_f));
-        ADF_TRY(frag(&lw.xv0_16, (int)H, (int)(2 * H), &lw.xv0_f));
-        ADF_TRY(frag(&lw.xv2_16, (int)(3 * H), (int)H, &lw.xv2_f));
-    }
-    h->wfrag_valid = true;
     return ADF_OK;
 }
 
@@ -284,47 +259,51 @@ extern "C" int32_t adf_painn_set_weights(adf_painn_t h, int32_t n_weights, const
         hipStream_t s = (hipStream_t)stream;
         const long long H = h->hp.hidden_channels, HH = H * H;
         unsigned char* cur = h->w16_arena;
+        unsigned char* fcur = h->wfrag_arena;
         int nscale = 0;
         float* bperm = h->w16_bias_perm;
-        auto split = [&](const float* w, long long n, adf_w16* out, const float* fused_bias = nullptr,
+        // w [rows, K] -> hi / lo planes (+ the permutations of the fused layers) and their fragment-ordered image
+        auto split = [&](const float* w, long long rows, long long K, adf_w16* out, const float* fused_bias = nullptr,
                          bool pair_perm = false) -> int32_t {
+            const long long n = rows * K;
             out->hi = cur; cur += n * 2;
             out->lo = cur; cur += n * 2;
             out->inv_scale = h->w16_scales + nscale++;
             out->bias_perm = nullptr;
+            out->frag = nullptr;
             if (fused_bias) {  // 3H-wide layer feeding a fused epilogue: rows permuted (gemm16.hip)
                 out->bias_perm = bperm; bperm += 3 * H;
-                return adf_split_weight(w, n, out, h->w16_scratch, s, (int)H, (int)H, fused_bias);
+                ADF_TRY(adf_split_weight(w, n, out, h->w16_scratch, s, (int)H, (int)H, fused_bias));
+            } else if (pair_perm) {  // vec_proj [2H, H]: (v1, v2) rows of the same channels side by side (gemm16.hip EPI 3)
+                ADF_TRY(adf_split_weight(w, n, out, h->w16_scratch, s, (int)H, (int)H, nullptr, 2));
+            } else {
+                ADF_TRY(adf_split_weight(w, n, out, h->w16_scratch, s));
             }
-            if (pair_perm)  // vec_proj [2H, H]: (v1, v2) rows of the same channels side by side (gemm16.hip EPI 3)
-                return adf_split_weight(w, n, out, h->w16_scratch, s, (int)H, (int)H, nullptr, 2);
-            return adf_split_weight(w, n, out, h->w16_scratch, s);
+            if (rows % 32 == 0 && K % 16 == 0) {
+                out->frag = fcur; fcur += n * 4;
+                ADF_TRY(adf_pack_frag(out, (int)rows, (int)K, out->frag, s));
+            }
+            return ADF_OK;
         };
         for (int l = 0; l < L; ++l) {
             adf_layer_weights& lw = h->layer[l];
-            ADF_TRY(split(lw.xp0_w, HH, &lw.xp0_16));
-            ADF_TRY(split(lw.xp2_w, 3 * HH, &lw.xp2_16, lw.xp2_b));
-            ADF_TRY(split(lw.vp_w, 2 * HH, &lw.vp_16, nullptr, true));
-            ADF_TRY(split(lw.xv0_w, 2 * HH, &lw.xv0_16));
-            ADF_TRY(split(lw.xv2_w, 3 * HH, &lw.xv2_16, lw.xv2_b));
+            ADF_TRY(split(lw.xp0_w, H, H, &lw.xp0_16));
+            ADF_TRY(split(lw.xp2_w, 3 * H, H, &lw.xp2_16, lw.xp2_b));
+            ADF_TRY(split(lw.vp_w, 2 * H, H, &lw.vp_16, nullptr, true));
+            ADF_TRY(split(lw.xv0_w, H, 2 * H, &lw.xv0_16));
+            ADF_TRY(split(lw.xv2_w, 3 * H, H, &lw.xv2_16, lw.xv2_b));
         }
         for (int hd = 0; hd < h->hp.num_heads; ++hd) {
             adf_block_weights& b0 = h->head[hd][0];
             adf_block_weights& b1 = h->head[hd][1];
-            ADF_TRY(split(b0.vec1_w, HH, &b0.vec1_16));
-            ADF_TRY(split(b0.vec2_w, HH / 2, &b0.vec2_16));
-            ADF_TRY(split(b0.un0_w, 2 * HH, &b0.un0_16));
-            ADF_TRY(split(b0.un2_w, HH, &b0.un2_16));
-            ADF_TRY(split(b1.vec1_w, HH / 4, &b1.vec1_16));
-            ADF_TRY(split(b1.un0_w, HH / 2, &b1.un0_16));
+            ADF_TRY(split(b0.vec1_w, H, H, &b0.vec1_16));
+            ADF_TRY(split(b0.vec2_w, H / 2, H, &b0.vec2_16));
+            ADF_TRY(split(b0.un0_w, H, 2 * H, &b0.un0_16));
+            ADF_TRY(split(b0.un2_w, H, H, &b0.un2_16));
+            ADF_TRY(split(b1.vec1_w, H / 2, H / 2, &b1.vec1_16));
+            ADF_TRY(split(b1.un0_w, H / 2, H, &b1.un0_16));
         }
-        h->wfrag_valid = false;
-        if (h->fused_mlp != 0) ADF_TRY(pack_fragment_images(h, s));
-        for (int l = 0; l < L; ++l) {   // vec_proj streams its weights as MFMA fragments (gemm16.hip, WR)
-            h->layer[l].vp_f = h->vpfrag_arena + (size_t)l * 2 * HH * 4;
-            ADF_TRY(adf_pack_frag(&h->layer[l].vp_16, (int)(2 * H), (int)H, h->layer[l].vp_f, s));
-        }
-        if ((size_t)(cur - h->w16_arena) > h->w16_bytes || nscale > 256) {
+        if ((size_t)(cur - h->w16_arena) > h->w16_bytes || (size_t)(fcur - h->wfrag_arena) > h->w16_bytes || nscale > 256) {
             adf_set_error("internal: fp16 weight arena overflow");
             return ADF_EINVAL;
         }
@@ -511,7 +490,7 @@ static int32_t zero_pad_rows(adf_painn* h, int N, hipStream_t s) {
 // By size (mode 2): a 64-row tile per CU wants at least two rounds of tiles on the chip; below that the 128 x 192 tiles of
 // the two-kernel form spread a small batch over more CUs (B = 1: 200 rows are 4 fused tiles against 16 workgroups).
 static bool use_fused_mlp(const adf_painn* h, int rows) {
-    if (!h->wfrag_valid || h->gemm_f32 || h->fused_mlp == 0) return false;
+    if (h->hp.hidden_channels != 512 || h->gemm_f32 || h->fused_mlp == 0) return false;
     if (h->fused_mlp == 1) return true;
     return rows >= 2 * 64 * h->num_cus;
 }
@@ -533,7 +512,7 @@ static int32_t make_records(adf_painn* h, int l, int n, const float* x, const fl
         ep.vec_in = vec; ep.rec = rec ? rec : h->rec; ep.H = H; ep.vec_is_zero = vec_is_zero ? 1 : 0;
         ep.row_map = row_map; ep.m_dev = h->rows_dev; ep.lift_y = lift ? 1 : 0;
         ep.rec_rows = row_map ? (long long)h->inc_capN : (long long)n;   // mapped rows index the whole kept table
-        ADF_TRY(adf_launch_mlp16(h->y, nullptr, H, em ? h->mag_a : nullptr, w.xp0_f, &w.xp0_16, w.xp0_b, w.xp2_f, &w.xp2_16, n,
+        ADF_TRY(adf_launch_mlp16(h->y, nullptr, H, em ? h->mag_a : nullptr, w.xp0_16.frag, &w.xp0_16, w.xp0_b, w.xp2_16.frag, &w.xp2_16, n,
                                  H, 1, &ep, s));
         adf_prof_end(h, s);
         return ADF_OK;
@@ -581,7 +560,6 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
               // xvec_proj.0 then reads its [x | |v2|] input from the two arrays
         adf_epi ep = {};
         ep.v1 = h->vv; ep.dotw = h->dot; ep.cat = h->cat; ep.H = H; ep.m_dev = h->rows_dev;
-        ep.wfrag = w.vp_f;
         const adf_lift* lf = h->lift_on ? &h->lift : nullptr;
         // vec rows and the [x | |v2|] rows are measured by a pass of their own; xvec_proj.0 hands its output rows' on.
         // (Measured alternative: the message kernel emitting the magnitudes of its vec_out rows - DPP maxima per
@@ -598,7 +576,7 @@ static int32_t update_layer(adf_painn* h, int l, int N, float* x, float* vec, hi
             adf_epi e2 = {};
             e2.x = x; e2.vec = vec; e2.dot = h->dot; e2.vv = h->vv; e2.scale = h->scale[l]; e2.H = H;
             e2.m_dev = h->rows_dev; e2.lift_y = h->lift_on ? 1 : 0;
-            const int32_t stf = adf_launch_mlp16(x, h->cat, H, rm, w.xv0_f, &w.xv0_16, w.xv0_b, w.xv2_f, &w.xv2_16, N, H, 2, &e2, s);
+            const int32_t stf = adf_launch_mlp16(x, h->cat, H, rm, w.xv0_16.frag, &w.xv0_16, w.xv0_b, w.xv2_16.frag, &w.xv2_16, N, H, 2, &e2, s);
             adf_prof_end(h, s);
             return stf;
         }
@@ -944,7 +922,7 @@ extern "C" int32_t adf_linear_forward(const float* A, const float* W, const floa
     unsigned char* buf = nullptr;
     const size_t n = (size_t)N * K;
     ADF_TRY(dev_alloc(&buf, n * 4 + 64));
-    adf_w16 w16;
+    adf_w16 w16 = {};
     w16.hi = buf; w16.lo = buf + n * 2; w16.inv_scale = reinterpret_cast<float*>(buf + n * 4);
     unsigned int* scratch = reinterpret_cast<unsigned int*>(buf + n * 4 + 16);
     int32_t st = adf_split_weight(W, (long long)n, &w16, scratch, s);
@@ -977,10 +955,6 @@ extern "C" int32_t adf_painn_set_arithmetic(adf_painn_t h, int32_t exact_f32) {
 extern "C" int32_t adf_painn_set_fused_mlp(adf_painn_t h, int32_t mode) {
     if (!h || mode < 0 || mode > 2) { adf_set_error("set_fused_mlp: mode must be 0 (never), 1 (always) or 2 (by size)"); return ADF_EINVAL; }
     h->fused_mlp = mode;
-    if (mode != 0 && h->weights_set && !h->wfrag_valid) {   // first use: build the fragment images from the split weights
-        ADF_TRY(pack_fragment_images(h, (hipStream_t)0));
-        ADF_HIP_CHECK(hipStreamSynchronize((hipStream_t)0));
-    }
     return ADF_OK;
 }
 

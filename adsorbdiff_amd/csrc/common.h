@@ -41,6 +41,8 @@ struct adf_w16 {
     void* lo;
     float* inv_scale;  // device scalar: 1 / (power-of-two scale applied before the split)
     float* bias_perm;  // row-permuted bias of the fused 3H-wide layers (else null)
+    void* frag;        // fragment-ordered image of hi / lo (adf_pack_frag, mlp16.hip): the B operands of v_mfma_f32_32x32x16_f16
+                       // as the lanes load them, for the kernels that stream weights straight into registers (null: none)
 };
 // operands of the fused GEMM epilogues (gemm16.hip)
 struct adf_epi {
@@ -69,7 +71,6 @@ struct adf_epi {
     const int32_t* m_dev;
     int accumulate;          // EPI 0: C += A W^T (+ bias) instead of C = (the training step's accumulated data gradients)
     int lift_y;              // mlp16.hip: lift the intermediate rows by their own power of two (= the engine's lift_on)
-    const void* wfrag;       // EPI 3: fragment-ordered image of the weights (adf_pack_frag): stream them to registers, no LDS staging
     long long rec_rows;      // mlp16.hip EPI 1: rows of the record table the (mapped) rows are written into (0 = the launch's rows)
 };
 // scratch for the row magnitudes a launcher measures itself (adf_launch_rowmag) when the caller has none to hand over
@@ -81,9 +82,6 @@ struct adf_layer_weights {
     const float *ln_w, *ln_b, *xp0_w, *xp0_b, *xp2_w, *xp2_b, *rbf_w, *rbf_b;
     const float *vp_w, *xv0_w, *xv0_b, *xv2_w, *xv2_b;
     adf_w16 xp0_16, xp2_16, vp_16, xv0_16, xv2_16;
-    // fragment-ordered images of the same split weights for the fused two-layer kernel (mlp16.hip); null unless H == 512
-    void *xp0_f, *xp2_f, *xv0_f, *xv2_f;
-    void* vp_f;   // vec_proj's fragment image (gemm16.hip WR variant), always built
 };
 struct adf_block_weights {
     const float *vec1_w, *vec2_w, *un0_w, *un0_b, *un2_w, *un2_b;
@@ -112,9 +110,7 @@ struct adf_painn {
     float* w16_scales;
     float* w16_bias_perm;  // [L][2][3H] row-permuted biases of x_proj.2 / xvec_proj.2
     unsigned int* w16_scratch;
-    unsigned char* vpfrag_arena;  // fragment images of vec_proj [L][2H, H] (gemm16.hip WR variant)
-    unsigned char* wfrag_arena;   // the layers' fragment images (mlp16.hip); allocated on first use
-    bool wfrag_valid;             // ... and packed from the current weights
+    unsigned char* wfrag_arena;   // fragment images of every split weight (adf_w16::frag), same size as w16_arena
     int fused_mlp;                // 0 never (default), 1 always, 2 by size: adf_painn_set_fused_mlp / ADF_FUSED_MLP
     bool gemm_f32;
     bool msg_f32;

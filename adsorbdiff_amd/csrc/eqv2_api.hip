@@ -1170,7 +1170,7 @@ extern "C" int32_t adf_eqv2_linear_forward(const float* A, const float* W, const
     unsigned char* buf = nullptr;
     const size_t n = (size_t)N * K, ma = (size_t)M * K;
     ADF_TRY(eq_alloc(&buf, n * 4 + 64 + (size_t)M * 4 + (mode == 2 ? ma * 4 : 0) + 64));
-    adf_w16 w16;
+    adf_w16 w16 = {};
     w16.hi = buf; w16.lo = buf + n * 2; w16.inv_scale = reinterpret_cast<float*>(buf + n * 4); w16.bias_perm = nullptr;
     unsigned int* scratch = reinterpret_cast<unsigned int*>(buf + n * 4 + 16);
     float* mag = reinterpret_cast<float*>(buf + n * 4 + 64);

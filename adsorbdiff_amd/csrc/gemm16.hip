@@ -31,6 +31,11 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #define EPI_ABL 0   // timing experiments only (wrong results): bit 0 = EPI 1 without its epilogue, bit 1 = EPI 2 without,
                     // bit 2 = EPI 1/2 without their global loads, bit 3 = without their global stores
 #endif
+#ifndef G16_ABL
+#define G16_ABL 0   // timing experiments only (wrong results; harness builds): 1 = vec_proj epilogue without its global stores,
+                    // 2 = A tile staged without the fp32 -> hi/lo conversion, 4 = A rows all read from row 0 (cache-hot),
+                    // 8 = no products (staging + epilogue only)
+#endif
 #define HK 32
 // Row strides (floats) of the epilogues' transposition buffers.  Unpadded on purpose: with the lane groups of
 // ds_read_b128 ({0-3,12-15,20-27}, ...) a stride of 96 (= 32 mod 64 banks) resp. 64 puts the four rows a group
@@ -81,16 +86,25 @@ __device__ __forceinline__ float adf_row16_max(float v) {
 //   WR (round 6, vec_proj): the weights are NOT staged through LDS - every wave loads the MFMA B fragments of its own columns
 //   straight from a fragment-ordered image (adf_pack_frag, mlp16.hip; `Whi` then points at that image) one K tile ahead; LDS
 //   holds the A tile only.  Same products in the same order: same bits.
-template <int ACT, int MI, int NJ, int EPI, bool WR = false>
-__global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
+//   NWN (WR only): waves along N.  2 (default): 4 waves, tile columns 64 NJ.  4: 8 waves as 2(M) x 4(N), 512 threads, tile
+//   columns 128 NJ - the A tile (staged, lifted and split once per workgroup) then serves twice the columns: half the L2 reads
+//   and half the conversions of the A panel (vec_proj: the panel was re-staged by 8 column tiles; staging + epilogue alone
+//   took 1.14 of the kernel's 2.2 ms in the stand-alone harness).
+template <int ACT, int MI, int NJ, int EPI, bool WR = false, int NWN = 2>
+__global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const float* __restrict__ A, int lda, const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo,
     const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ C, int ldc, int Mh, int N,
     int K, int tiles_n, adf_epi ep) {
     const int M = ep.m_dev ? min(Mh, (int)*ep.m_dev) : Mh;  // rows: the host's bound, or fewer by a device-side count
-    constexpr int TM = 64 * MI;   // rows per workgroup
-    constexpr int TN = 64 * NJ;   // columns per workgroup
-    constexpr int NA = TM / 32;   // float4 A loads per thread
-    __shared__ __attribute__((aligned(16))) _Float16 lds[(2 * TM + 2 * TN) * HLD];   // (WR: the W half is only the epilogues' scratch)
+    static_assert(NWN == 2 || WR, "eight waves only with the register-streamed weights");
+    constexpr int NT = 128 * NWN;        // threads
+    constexpr int TM = 64 * MI;          // rows per workgroup
+    constexpr int TN = 32 * NJ * NWN;    // columns per workgroup
+    constexpr int NA = TM * 8 / NT;      // float4 A loads per thread
+    static_assert(TM * 8 % NT == 0, "A staging: whole float4s per thread");
+    // (WR: no W tiles; two A buffers, reused as the epilogues' scratch of NT / 64 waves x 3200 floats)
+    constexpr int LDS_WR = 4 * TM * HLD > NT / 64 * 6400 ? 4 * TM * HLD : NT / 64 * 6400;   // two A buffers (hi + lo) | the scratch
+    __shared__ __attribute__((aligned(16))) _Float16 lds[WR ? LDS_WR : (2 * TM + 2 * TN) * HLD];
     __shared__ float rinv[TM];  // 1 / lift of every staged A row
     _Float16* Ahi = lds;
     _Float16* Alo = Ahi + TM * HLD;
@@ -99,8 +113,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave >> 1) * (32 * MI);
-    const int wn = (wave & 1) * (32 * NJ);
+    const int wm = (wave / NWN) * (32 * MI);
+    const int wn = (wave % NWN) * (32 * NJ);
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     };
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int f = tid + 256 * i;
+        const int f = tid + NT * i;
         const int row = f >> 3, kq = f & 7;
         const unsigned int grow = global_row(row);
         a_goff[i] = (grow * (unsigned int)lda + kq * 4) * 4u;
@@ -184,9 +198,14 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
     const int nk = K / HK;
     const int fa = (wm + (lane & 31)) * HLD + (lane >> 5) * 8;
     const int fb = (wn + (lane & 31)) * HLD + (lane >> 5) * 8;
-    auto stage_a = [&](int boff = 0) {   // boff: halves; WR: the A buffer being filled (0 or 2 TM HLD)
+    auto stage_a = [&](int boff = 0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
+            if (G16_ABL & 2) {   // move the bytes, skip the split
+                *reinterpret_cast<float2*>(Ahi + boff + a_off[i]) = make_float2(ra[i].x, ra[i].y);
+                *reinterpret_cast<float2*>(Alo + boff + a_off[i]) = make_float2(ra[i].z, ra[i].w);
+                continue;
+            }
             const float sx = ra[i].x * a_rs[i], sy = ra[i].y * a_rs[i], sz = ra[i].z * a_rs[i], sw = ra[i].w * a_rs[i];
             half4 h, l;
             h[0] = (_Float16)sx; h[1] = (_Float16)sy; h[2] = (_Float16)sz; h[3] = (_Float16)sw;
@@ -200,13 +219,14 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         const int k1 = kt1 * HK;
         const char* ab = ((ep.K1 > 0 && k1 >= ep.K1) ? A2b : A1b) + (size_t)k1 * 4;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ab + a_goff[i]);
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ab + ((G16_ABL & 4) ? (a_goff[i] & 127u) : a_goff[i]));
     };
     if constexpr (WR) {
         // one K tile: A through LDS as before; the B fragments of a k-step are requested one k-step ahead, right behind the
         // barrier resp. in front of the second k-step's products (sched_barrier: hipcc would sink the requests to their first
         // use, mlp16.hip).  (A whole tile ahead - four register sets - spills 28 registers beside the 96 accumulators.)
         auto kstep = [&](int boff, int ks, const half8 (&cur)[NJ][2]) {
+            if (G16_ABL & 8) { asm volatile("" :: "v"(cur[0][0]), "v"(cur[0][1]), "v"(cur[NJ - 1][0]), "v"(cur[NJ - 1][1])); return; }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const half8 ah = *reinterpret_cast<const half8*>(Ahi + boff + fa + i * 32 * HLD + ks * 16);
@@ -219,23 +239,65 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
                 }
             }
         };
-        // (Measured and dropped: two A buffers in the LDS the W tiles no longer need and ONE barrier per K tile, tile kt + 1
-        // converted behind tile kt's products - node products 1829-1833 ms per pass against 1812 with this form and 1825-1829
-        // with the weights staged through LDS: the conversion then sits behind every wave's own products instead of beside
-        // the other workgroup's.)
-        for (int kt = 0; kt < nk; ++kt) {
+        // (First form of the pipeline, measured and dropped: the conversion of tile kt + 1 BEHIND tile kt's products instead of
+        // between them - node products 1829-1833 ms per pass against 1812 with two barriers per tile and no second buffer.)
+        {
+            // Software-pipelined staging: two A buffers, one barrier per K tile, and the conversion of tile kt + 1 is dealt
+            // BETWEEN the products of tile kt's second k-step (sched_group_barrier: 1 MFMA, 4 VALU), where the matrix pipe hides
+            // it; its rows were requested two tiles ahead (two register sets).  With eight waves (the only workgroup of its
+            // CU) nothing else could fill the staging time; with four it adds to the overlap between the CU's two workgroups.
+            constexpr int BUF = 2 * TM * HLD;
+            float4 rb[NA];
+            auto request_b = [&](int kt1) {
+                const int k1 = kt1 * HK;
+                const char* ab = ((ep.K1 > 0 && k1 >= ep.K1) ? A2b : A1b) + (size_t)k1 * 4;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) rb[i] = *reinterpret_cast<const float4*>(ab + a_goff[i]);
+            };
+            auto stage_from = [&](const float4 (&src)[NA], int boff) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const float sx = src[i].x * a_rs[i], sy = src[i].y * a_rs[i], sz = src[i].z * a_rs[i], sw = src[i].w * a_rs[i];
+                    half4 h, l;
+                    h[0] = (_Float16)sx; h[1] = (_Float16)sy; h[2] = (_Float16)sz; h[3] = (_Float16)sw;
+                    l[0] = (_Float16)(sx - (float)h[0]); l[1] = (_Float16)(sy - (float)h[1]);
+                    l[2] = (_Float16)(sz - (float)h[2]); l[3] = (_Float16)(sw - (float)h[3]);
+                    *reinterpret_cast<half4*>(Ahi + boff + a_off[i]) = h;
+                    *reinterpret_cast<half4*>(Alo + boff + a_off[i]) = l;
+                }
+            };
+            // tile kt: products on buffer `cur` with the registers `nxt_regs` (tile kt + 1) converted into the other buffer
+            auto tile = [&](int kt, int cur, const float4 (&nxt_regs)[NA]) {
+                load_wf(2 * kt + 1, wfb);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(cur, 0, wfa);
+                __builtin_amdgcn_sched_barrier(0);
+                load_wf(min(2 * kt + 2, 2 * nk - 1), wfa);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(cur, 1, wfb);
+                stage_from(nxt_regs, BUF - cur);   // (behind the last tile: a copy nobody reads)
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MI, 0);
+#pragma unroll
+                for (int u = 0; u < 3 * MI * NJ; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+                    if (u % 3 == 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            __syncthreads();   // (rinv)
+            stage_a(0);                       // tile 0 (requested in the prologue)
+            request_a(min(1, nk - 1));        // tile 1 -> ra
+            request_b(min(2, nk - 1));        // tile 2 -> rb
             __syncthreads();
-            stage_a();
-            __syncthreads();
-            request_a(min(kt + 1, nk - 1));          // (behind the last tile: a re-read nobody uses; no branch around the loads)
-            load_wf(2 * kt + 1, wfb);
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(0, 0, wfa);
-            __builtin_amdgcn_sched_barrier(0);
-            load_wf(min(2 * kt + 2, 2 * nk - 1), wfa);
-            __builtin_amdgcn_sched_barrier(0);
-            kstep(0, 1, wfb);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int kt = 0; kt < nk; kt += 2) {   // (nk is even: checked by the launcher)
+                tile(kt, 0, ra);
+                request_a(min(kt + 3, nk - 1));
+                __syncthreads();
+                tile(kt + 1, BUF, rb);
+                request_b(min(kt + 4, nk - 1));
+                __syncthreads();
+            }
         }
     } else {
     for (int kt = 0; kt < nk; ++kt) {
@@ -358,7 +420,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         const float inv_sqrt_h = 1.0f / sqrtf((float)H);
         __syncthreads();  // all waves are done reading the operand tiles
         float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][TLD3] floats
-        const int a0 = m0 + (wave >> 1) * 32;                    // first atom of this wave
+        const int a0 = m0 + (wave / NWN) * 32;                   // first atom of this wave
         float dv[16], nv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -385,8 +447,11 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             if (n < M) {
                 float* vo = ep.v1 + (size_t)n * 3 * H + 32 * g + 4 * c4;
 #pragma unroll
-                for (int ax = 0; ax < 3; ++ax)
-                    *reinterpret_cast<float4*>(vo + ax * H) = *reinterpret_cast<const float4*>(T + lr * TLD3 + ax * 32 + 4 * c4);
+                for (int ax = 0; ax < 3; ++ax) {
+                    const float4 tv_ = *reinterpret_cast<const float4*>(T + lr * TLD3 + ax * 32 + 4 * c4);
+                    if (G16_ABL & 1) asm volatile("" :: "v"(tv_.x), "v"(tv_.w)); else
+                    *reinterpret_cast<float4*>(vo + ax * H) = tv_;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -403,8 +468,12 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
             const int lr = it * 8 + (lane >> 3), c4 = lane & 7;
             const int n = a0 + lr, c = 32 * g + 4 * c4;
             if (n < M) {
-                *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * TLD3 + 4 * c4);
-                *reinterpret_cast<float4*>(ep.cat + (size_t)n * H + c) = *reinterpret_cast<const float4*>(T + lr * TLD3 + 32 + 4 * c4);
+                const float4 dv_ = *reinterpret_cast<const float4*>(T + lr * TLD3 + 4 * c4);
+                const float4 nv_ = *reinterpret_cast<const float4*>(T + lr * TLD3 + 32 + 4 * c4);
+                if (G16_ABL & 1) { asm volatile("" :: "v"(dv_.x), "v"(nv_.w)); } else {
+                *reinterpret_cast<float4*>(ep.dotw + (size_t)n * H + c) = dv_;
+                *reinterpret_cast<float4*>(ep.cat + (size_t)n * H + c) = nv_;
+                }
             }
         }
     } else if constexpr (EPI == 4) {
@@ -416,7 +485,7 @@ __global__ __launch_bounds__(256, (MI == 4 ? 1 : 2)) void adf_gemm_f16x3_kernel(
         const int cb = n0 + wn;
         __syncthreads();  // all waves are done reading the operand tiles
         float* T = reinterpret_cast<float*>(lds) + wave * 3200;  // [32 atoms][TLD2] floats used
-        const int a0 = m0 + (wave >> 1) * 32;
+        const int a0 = m0 + (wave / NWN) * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -686,6 +755,31 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
         ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));
         ep.out_mag = reinterpret_cast<unsigned int*>(out_mag);
     }
+    // Round 6: weights streamed as fragments, eight waves per workgroup, 192 x 256 tile, software-pipelined staging (see the
+    // kernel comment: WR, NWN = 4).  Needs the fragment image, N a multiple of 256 and an even number of K tiles.
+    static int w8 = -1;     // ADF_GEMM_W8_PLAIN=0: the 128 x 256 tile with LDS-staged weights of rounds 1-5
+    if (w8 < 0) { const char* e = getenv("ADF_GEMM_W8_PLAIN"); w8 = (e && atoi(e) == 0) ? 0 : 1; }
+    // (the same pipeline with four waves - 192 x 128 tile, two workgroups per CU - measured 1.3 % slower on the node products
+    // and 2.3 % on the heads; a 128 x 256 four-wave tile spills 36-46 registers)
+    // One such workgroup per CU: with few, long tiles the last round matters.  A launch of fewer than four rounds whose last
+    // round would fill under 30 % of the chip (25 000 rows: 131 x 2 = 262 workgroups on 256 CUs) keeps the 128 x 256 tile,
+    // two workgroups per CU (392 on 512 slots).
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
+    const long long wg8 = (long long)((M + 191) / 192) * (N / 256 > 0 ? N / 256 : 1);
+    const bool ragged = wg8 < 4ll * ncu && wg8 % ncu != 0 && wg8 % ncu < (3 * ncu) / 10 && wg8 > ncu;
+    if (w8 == 1 && W->frag && N % 256 == 0 && (K / HK) % 2 == 0 && mi == 2 && !ragged) {
+        const int tn8 = N / 256, tmw8 = ((M + 191) / 192 + 7) / 8 * 8;
+        dim3 g8((unsigned)(tmw8 * tn8));
+        if (act_ssilu)
+            hipLaunchKernelGGL((adf_gemm_f16x3_kernel<1, 3, 2, 0, true, 4>), g8, dim3(512), 0, s, A, lda, (const _Float16*)W->frag,
+                               (const _Float16*)nullptr, W->inv_scale, bias, C, ldc, M, N, K, tn8, ep);
+        else
+            hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 0, true, 4>), g8, dim3(512), 0, s, A, lda, (const _Float16*)W->frag,
+                               (const _Float16*)nullptr, W->inv_scale, bias, C, ldc, M, N, K, tn8, ep);
+        ADF_HIP_CHECK(hipGetLastError());
+        return ADF_OK;
+    }
 #define LAUNCH16(ACT_, MI_)                                                                                  \
     hipLaunchKernelGGL((adf_gemm_f16x3_kernel<ACT_, MI_, 4, 0>), grid, dim3(256), 0, s, A, lda,              \
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, bias, C, ldc, M, N, K, \
@@ -707,6 +801,15 @@ int32_t adf_launch_gemm16_vecnorm(const float* A, int lda, const adf_w16* W, flo
     ep.cat = nrm;
     ADF_TRY(lift_mags(A, lda, K, nullptr, 0, 3ll * M, lf, premag, &ep.rmag, s));
     const int tn = (N + 127) / 128, tm8 = ((M + 63) / 64 + 7) / 8 * 8;
+    static int w8 = -1;
+    if (w8 < 0) { const char* e = getenv("ADF_GEMM_W8"); w8 = (e && atoi(e) == 0) ? 0 : 1; }
+    if (w8 && W->frag && N % 256 == 0 && (K / HK) % 2 == 0) {   // weights streamed as fragments, eight waves (see the kernel comment)
+        hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 4, true, 4>), dim3((unsigned)(tm8 * (N / 256))), dim3(512), 0, s, A, lda,
+                           (const _Float16*)W->frag, (const _Float16*)nullptr, W->inv_scale, (const float*)nullptr,
+                           (float*)nullptr, 0, M, N, K, N / 256, ep);
+        ADF_HIP_CHECK(hipGetLastError());
+        return ADF_OK;
+    }
     hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 4>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
                        (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, (const float*)nullptr,
                        (float*)nullptr, 0, M, N, K, tn, ep);
@@ -736,14 +839,34 @@ int32_t adf_launch_gemm16_fused(const float* A, int lda, const adf_w16* W, int M
         const int tn = 2 * H / 128, tm8 = ((M + 63) / 64 + 7) / 8 * 8;
         static int wreg = -1;   // ADF_GEMM_WREG=0: weights staged through LDS as in rounds 1-5
         if (wreg < 0) { const char* e = getenv("ADF_GEMM_WREG"); wreg = (e && atoi(e) == 0) ? 0 : 1; }
-        if (wreg && ep->wfrag)
-            hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 3, true>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
-                               (const _Float16*)ep->wfrag, (const _Float16*)nullptr, W->inv_scale, (const float*)nullptr,
-                               (float*)nullptr, 0, M, 2 * H, K, tn, *ep);
+        static int w8 = -1;     // ADF_GEMM_W8=0: four waves per workgroup (128 columns) instead of eight (256)
+        if (w8 < 0) { const char* e = getenv("ADF_GEMM_W8"); w8 = (e && atoi(e) == 0) ? 0 : 1; }
+        // (four waves, two workgroups per CU, same pipeline: node products 1748 ms per pass against 1679)
+        if (wreg && W->frag && w8 == 1 && (2 * H) % 256 == 0 && (K / HK) % 2 == 0)
+            hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 3, true, 4>), dim3((unsigned)(tm8 * (2 * H / 256))), dim3(512), 0, s,
+                               A, lda, (const _Float16*)W->frag, (const _Float16*)nullptr, W->inv_scale, (const float*)nullptr,
+                               (float*)nullptr, 0, M, 2 * H, K, 2 * H / 256, *ep);
         else
         hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 3, 2, 3>), dim3((unsigned)(tm8 * tn)), dim3(256), 0, s, A, lda,
                            (const _Float16*)W->hi, (const _Float16*)W->lo, W->inv_scale, (const float*)nullptr,
                            (float*)nullptr, 0, M, 2 * H, K, tn, *ep);
+        ADF_HIP_CHECK(hipGetLastError());
+        return ADF_OK;
+    }
+    static int wf = -1;   // ADF_GEMM_WR_FUSED: 0 = LDS-staged weights (rounds 1-5), 2 / 4 = streamed fragments with 4 / 8 waves
+    if (wf < 0) { const char* e = getenv("ADF_GEMM_WR_FUSED"); wf = e ? atoi(e) : 2; }
+    // (measured: 4 waves 1656 ms of node products per pass, LDS-staged weights 1702, 8 waves 1741 - the record / gating
+    // epilogues are HBM-heavy and want the CU's second workgroup beside them)
+    if (wf && W->frag && (K / HK) % 2 == 0 && (wf == 2 || N % 384 == 0)) {
+        const int tnw = wf == 4 ? N / 384 : tiles_n;
+        dim3 gw((unsigned)(tiles_m8 * tnw));
+#define LAUNCHWF(EPI_, NWN_)                                                                                                  \
+        hipLaunchKernelGGL((adf_gemm_f16x3_kernel<0, 2, 3, EPI_, true, NWN_>), gw, dim3(128 * NWN_), 0, s, A, lda,            \
+                           (const _Float16*)W->frag, (const _Float16*)nullptr, W->inv_scale, W->bias_perm, (float*)nullptr, 0, \
+                           M, N, K, tnw, *ep)
+        if (epi == 1) { if (wf == 4) LAUNCHWF(1, 4); else LAUNCHWF(1, 2); }
+        else { if (wf == 4) LAUNCHWF(2, 4); else LAUNCHWF(2, 2); }
+#undef LAUNCHWF
         ADF_HIP_CHECK(hipGetLastError());
         return ADF_OK;
     }

@@ -97,7 +97,7 @@ static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bia
         }
         mag_cap[dev] = want;
     }
-    adf_w16 w16;
+    adf_w16 w16 = {};
     w16.hi = buf[dev]; w16.lo = buf[dev] + n * 2;
     w16.inv_scale = reinterpret_cast<float*>(buf[dev] + n * 4);
     w16.bias_perm = nullptr;

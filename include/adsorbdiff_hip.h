@@ -144,7 +144,7 @@ int32_t adf_painn_set_incremental(adf_painn_t h, int32_t on);
  * csrc/gemm16.hip), 1 = one kernel per pair with the [rows, 512] intermediate kept in LDS and the weights streamed as MFMA
  * fragments (csrc/mlp16.hip; round 6: bit-identical results, measured 5-10 % slower per pair on MI355X - its epilogues'
  * HBM traffic does not overlap its matrix phases at one workgroup per CU, profiles/NOTES.md), 2 = mode 1 from 2 x 64 rows per
- * CU on.  ADF_FUSED_MLP sets the initial mode.  The fragment images (9 H^2 x 4 bytes per layer) are built on first use. */
+ * CU on.  ADF_FUSED_MLP sets the initial mode. */
 int32_t adf_painn_set_fused_mlp(adf_painn_t h, int32_t mode);
 
 /* Read the device-side error flags of the last graph build (candidate overflow,
