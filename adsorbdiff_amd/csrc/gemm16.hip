@@ -36,6 +36,9 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
                     // 2 = A tile staged without the fp32 -> hi/lo conversion, 4 = A rows all read from row 0 (cache-hot),
                     // 8 = no products (staging + epilogue only)
 #endif
+#ifndef G16_WDEEP
+#define G16_WDEEP 1   // WR kernels request their weight fragments two k-steps ahead (four register sets); 0: one k-step (node products 1699 -> 1681 ms per pass with 1)
+#endif
 #define HK 32
 // Row strides (floats) of the epilogues' transposition buffers.  Unpadded on purpose: with the lane groups of
 // ds_read_b128 ({0-3,12-15,20-27}, ...) a stride of 96 (= 32 mod 64 banks) resp. 64 puts the four rows a group
@@ -252,11 +255,16 @@ __global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_
                 const int k1 = kt1 * HK;
                 const char* ab = ((ep.K1 > 0 && k1 >= ep.K1) ? A2b : A1b) + (size_t)k1 * 4;
 #pragma unroll
-                for (int i = 0; i < NA; ++i) rb[i] = *reinterpret_cast<const float4*>(ab + a_goff[i]);
+                for (int i = 0; i < NA; ++i) rb[i] = *reinterpret_cast<const float4*>(ab + ((G16_ABL & 4) ? (a_goff[i] & 127u) : a_goff[i]));
             };
             auto stage_from = [&](const float4 (&src)[NA], int boff) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
+                    if (G16_ABL & 2) {   // move the bytes, skip the split
+                        *reinterpret_cast<float2*>(Ahi + boff + a_off[i]) = make_float2(src[i].x, src[i].y);
+                        *reinterpret_cast<float2*>(Alo + boff + a_off[i]) = make_float2(src[i].z, src[i].w);
+                        continue;
+                    }
                     const float sx = src[i].x * a_rs[i], sy = src[i].y * a_rs[i], sz = src[i].z * a_rs[i], sw = src[i].w * a_rs[i];
                     half4 h, l;
                     h[0] = (_Float16)sx; h[1] = (_Float16)sy; h[2] = (_Float16)sz; h[3] = (_Float16)sw;
@@ -267,6 +275,21 @@ __global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_
                 }
             };
             // tile kt: products on buffer `cur` with the registers `nxt_regs` (tile kt + 1) converted into the other buffer
+#if G16_WDEEP
+            // weight fragments TWO k-steps ahead: four register sets, a tile uses (w0, w1) and requests the next tile's into (w2, w3)
+            half8 wfc[NJ][2], wfd[NJ][2];
+            load_wf(1, wfb);
+            auto tile = [&](int kt, int cur, const float4 (&nxt_regs)[NA], const half8 (&w0)[NJ][2], const half8 (&w1)[NJ][2],
+                            half8 (&w2)[NJ][2], half8 (&w3)[NJ][2]) {
+                load_wf(min(2 * kt + 2, 2 * nk - 1), w2);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(cur, 0, w0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_wf(min(2 * kt + 3, 2 * nk - 1), w3);
+                __builtin_amdgcn_sched_barrier(0);
+                kstep(cur, 1, w1);
+                stage_from(nxt_regs, BUF - cur);
+#else
             auto tile = [&](int kt, int cur, const float4 (&nxt_regs)[NA]) {
                 load_wf(2 * kt + 1, wfb);
                 __builtin_amdgcn_sched_barrier(0);
@@ -276,6 +299,7 @@ __global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_
                 __builtin_amdgcn_sched_barrier(0);
                 kstep(cur, 1, wfb);
                 stage_from(nxt_regs, BUF - cur);   // (behind the last tile: a copy nobody reads)
+#endif
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * MI, 0);
 #pragma unroll
                 for (int u = 0; u < 3 * MI * NJ; ++u) {
@@ -291,10 +315,17 @@ __global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_
             request_b(min(2, nk - 1));        // tile 2 -> rb
             __syncthreads();
             for (int kt = 0; kt < nk; kt += 2) {   // (nk is even: checked by the launcher)
+#if G16_WDEEP
+                tile(kt, 0, ra, wfa, wfb, wfc, wfd);
+                request_a(min(kt + 3, nk - 1));
+                __syncthreads();
+                tile(kt + 1, BUF, rb, wfc, wfd, wfa, wfb);
+#else
                 tile(kt, 0, ra);
                 request_a(min(kt + 3, nk - 1));
                 __syncthreads();
                 tile(kt + 1, BUF, rb);
+#endif
                 request_b(min(kt + 4, nk - 1));
                 __syncthreads();
             }
@@ -768,6 +799,7 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
     const long long wg8 = (long long)((M + 191) / 192) * (N / 256 > 0 ? N / 256 : 1);
     const bool ragged = wg8 < 4ll * ncu && wg8 % ncu != 0 && wg8 % ncu < (3 * ncu) / 10 && wg8 > ncu;
+    // (256-row tiles, MI = 4 - every weight fragment reused by 128 rows - measured: no gain, 1672-1676 against 1670-1673 ms)
     if (w8 == 1 && W->frag && N % 256 == 0 && (K / HK) % 2 == 0 && mi == 2 && !ragged) {
         const int tn8 = N / 256, tmw8 = ((M + 191) / 192 + 7) / 8 * 8;
         dim3 g8((unsigned)(tmw8 * tn8));

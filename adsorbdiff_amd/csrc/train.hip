@@ -70,7 +70,9 @@ static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bia
         if (accumulate) { adf_set_error("internal: accumulating product needs the f16x3 path"); return ADF_EINVAL; }
         return adf_launch_gemm(A, lda, W, K, bias, C, ldc, (int)M, N, K, 0, s);
     }
-    const size_t n = (size_t)N * K, need = n * 4 + 256;
+    // (+ the fragment-ordered image of the split weight: the streamed-weights kernel of gemm16.hip, round 6)
+    const bool fragok = N % 32 == 0 && K % 16 == 0;
+    const size_t n = (size_t)N * K, need = n * 4 + 256 + (fragok ? n * 4 : 0);
     if (need > cap[dev]) {
         ADF_HIP_CHECK(hipDeviceSynchronize());
         if (buf[dev]) (void)hipFree(buf[dev]);
@@ -102,6 +104,10 @@ static int32_t tr_gemm(const float* A, int lda, const float* W, const float* bia
     w16.inv_scale = reinterpret_cast<float*>(buf[dev] + n * 4);
     w16.bias_perm = nullptr;
     ADF_TRY(adf_split_weight(W, (long long)n, &w16, reinterpret_cast<unsigned int*>(buf[dev] + n * 4 + 16), s));
+    if (fragok) {
+        w16.frag = buf[dev] + n * 4 + 256;
+        ADF_TRY(adf_pack_frag(&w16, N, K, w16.frag, s));
+    }
     const adf_lift lf = {mag[dev], mag_cap[dev]};
     return adf_launch_gemm16(A, lda, &w16, bias, C, ldc, (int)M, N, K, 0, s, nullptr, 0, &lf, nullptr, nullptr, nullptr, accumulate);
 }
