@@ -695,6 +695,12 @@ int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int 
 // row magnitudes for a launcher: the caller's (premag), or measured into lf->buf, or none.  (Measured alternative: every
 // workgroup measuring its own A panel in a prologue - no separate pass, same bits: 231.2 vs 233.5 sites/s at 1000 systems,
 // 473 vs 493 it/s at B = 1: the panel is re-read by each of its 2-8 column tiles and the prologue is serial; not kept.)
+// (Round 6: ONE pass over the vec rows and the x rows of a layer + norm(v2)'s row maxima raised from vec_proj's epilogue by
+// atomicMax, instead of the two passes (vec; [x | norm(v2)]): identical sites, node products 1672 / 1676 ms per pass with and
+// 1673 / 1677 without - the epilogue's atomics cost what the second pass did.)
+// (Round 6, again: the eight-wave vec_proj kernel measuring its own 192 rows in a prologue - one wave per row, eight rows in
+// flight - instead of the adf_rowmag pass over `vec`: identical sites, node products 1647 -> 2014 ms per pass.  At one workgroup
+// per CU nothing overlaps the prologue's three dependent HBM round trips.)
 static int32_t lift_mags(const float* A, int lda, int K1, const float* A2, int K2, long long rows, const adf_lift* lf,
                          const float* premag, const float** out, hipStream_t s, const int32_t* m_dev = nullptr, int m_mul = 1) {
     *out = premag;
