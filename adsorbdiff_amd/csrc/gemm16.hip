@@ -86,9 +86,11 @@ __device__ __forceinline__ float adf_row16_max(float v) {
 //   its 32 atoms; the two column blocks are v1 and v2 of the same 32 channels (weights row-permuted: column
 //   g*64 + part*32 + q  <->  row part*H + 32g + q).  dot = sum_xyz v1*v2 / sqrt(H) and |v2| ([N,H] each) are formed
 //   on the accumulators: v2 (1.2 GB per layer at N = 200k) never goes to HBM and the separate reduction pass is gone.
-//   WR (round 6, vec_proj): the weights are NOT staged through LDS - every wave loads the MFMA B fragments of its own columns
-//   straight from a fragment-ordered image (adf_pack_frag, mlp16.hip; `Whi` then points at that image) one K tile ahead; LDS
-//   holds the A tile only.  Same products in the same order: same bits.
+//   WR (round 6; every product of the PaiNN sampler): the weights are NOT staged through LDS - every wave loads the MFMA B
+//   fragments of its own columns straight from a fragment-ordered image (adf_pack_frag, mlp16.hip; `Whi` then points at that
+//   image) into a ring of register sets, two k-steps ahead; LDS holds two A buffers, there is one barrier per K tile, and the
+//   lift / split of the next A tile is dealt between the MFMAs of the current one (see the main loop).  Same products in the
+//   same order as the LDS-staged form (kept below, WR = false): same bits.
 //   NWN (WR only): waves along N.  2 (default): 4 waves, tile columns 64 NJ.  4: 8 waves as 2(M) x 4(N), 512 threads, tile
 //   columns 128 NJ - the A tile (staged, lifted and split once per workgroup) then serves twice the columns: half the L2 reads
 //   and half the conversions of the A panel (vec_proj: the panel was re-staged by 8 column tiles; staging + epilogue alone
@@ -225,9 +227,9 @@ __global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_
         for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4*>(ab + ((G16_ABL & 4) ? (a_goff[i] & 127u) : a_goff[i]));
     };
     if constexpr (WR) {
-        // one K tile: A through LDS as before; the B fragments of a k-step are requested one k-step ahead, right behind the
-        // barrier resp. in front of the second k-step's products (sched_barrier: hipcc would sink the requests to their first
-        // use, mlp16.hip).  (A whole tile ahead - four register sets - spills 28 registers beside the 96 accumulators.)
+        // The B fragments of a k-step are requested one or two k-steps ahead (G16_WDEEP), in front of the products of the k-step
+        // before (sched_barrier(0) between the request group and the product group: left alone, hipcc sinks the requests to
+        // their first use and every k-step waits out an L2 round trip - mlp16.hip's first build).
         auto kstep = [&](int boff, int ks, const half8 (&cur)[NJ][2]) {
             if (G16_ABL & 8) { asm volatile("" :: "v"(cur[0][0]), "v"(cur[0][1]), "v"(cur[NJ - 1][0]), "v"(cur[NJ - 1][1])); return; }
 #pragma unroll

@@ -18,8 +18,14 @@
 // wave's epilogue (global loads / stores) runs beside its partner's matrix phase.
 //
 // Arithmetic: bit-identical to the two-kernel path (same per-row lifts from the same row magnitudes, same order of the
-// three split products per 16-deep k-step, same epilogue expressions), so the engine may pick either form by size
-// (adf_painn_set_fused_mlp) without touching the reproducibility guarantees (sharded / incremental / subset runs).
+// three split products per 16-deep k-step, same epilogue expressions; tests/test_gpu_parity.py), so choosing it
+// (adf_painn_set_fused_mlp) does not touch the reproducibility guarantees (sharded / incremental / subset runs).
+//
+// STATUS (round 6): measured 5-12 % SLOWER than the two gemm16.hip products it replaces (2.06 / 2.09 ms per launch against
+// 1.83 / 2.04 at 1000 systems) and therefore OFF by default.  130 KB of LDS = one workgroup per CU, and a tile's phases that are
+// not matrix work (the load of its rows, the ScaledSiLU / row-maximum / split hand-off, the 1 MB of epilogue traffic at
+// 12 KB in flight per wave) have nothing to overlap with; profiles/NOTES.md has the phase times.  Its weight-fragment image
+// and its K loop (B fragments straight from L2 into registers, pinned prefetch) are what gemm16.hip's products now run on.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
