@@ -311,6 +311,9 @@ __global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
+            // (Measured and dropped: FOUR A buffers and one barrier per PAIR of K tiles for the eight-wave kernels - identical
+            // sites, node products 1662 -> 1714 ms per pass, heads 420 -> 442: the second tile staged in the prologue costs every
+            // workgroup another exposed HBM round trip, the barriers were not what the tiles were waiting for.)
             __syncthreads();   // (rinv)
             stage_a(0);                       // tile 0 (requested in the prologue)
             request_a(min(1, nk - 1));        // tile 1 -> ra
