@@ -71,6 +71,8 @@ struct adf_epi {
     const int32_t* m_dev;
     int accumulate;          // EPI 0: C += A W^T (+ bias) instead of C = (the training step's accumulated data gradients)
     int lift_y;              // mlp16.hip: lift the intermediate rows by their own power of two (= the engine's lift_on)
+    const float* gate;       // EPI 0 (heads): multiply output row r, column c by gate[(r / 3) * gate_ld + c]  (null: no gate)
+    int gate_ld;
     long long rec_rows;      // mlp16.hip EPI 1: rows of the record table the (mapped) rows are written into (0 = the launch's rows)
 };
 // scratch for the row magnitudes a launcher measures itself (adf_launch_rowmag) when the caller has none to hand over
@@ -215,7 +217,8 @@ int32_t adf_launch_gemm(const float* A, int lda, const float* W, int ldw, const 
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s, const float* A2 = nullptr, int K1 = 0,
                           const adf_lift* lf = nullptr, const float* premag = nullptr, float* out_mag = nullptr,
-                          const int32_t* m_dev = nullptr, int accumulate = 0);  // m_dev: see adf_epi::m_dev
+                          const int32_t* m_dev = nullptr, int accumulate = 0,   // m_dev: see adf_epi::m_dev
+                          const float* gate = nullptr, int gate_ld = 0);        // gate: see adf_epi::gate
 // m_dev / m_mul: rows = min(M, *m_dev * m_mul) when the count lives on the device (m_mul = 3: [N,3,K] vector rows)
 int32_t adf_launch_rowmag(const float* A, int lda, int K1, const float* A2, int K2, long long M, float* mag, hipStream_t s,
                           const int32_t* m_dev = nullptr, int m_mul = 1);

@@ -411,6 +411,10 @@ __global__ __launch_bounds__(128 * NWN, (MI == 4 || NWN == 4 ? 1 : 2)) void adf_
                         const int row = m0 + wm + 32 * i + lr, col = cb + 4 * c4;
                         float4 v = *reinterpret_cast<const float4*>(T + lr * TLD2 + 4 * c4);
                         if (row < M && col < N) {
+                            if (ep.gate) {   // heads: v' = g (x) vec2_proj(v) (painn_denoising.py:693-696): row = 3 atom + component
+                                const float4 g4 = *reinterpret_cast<const float4*>(ep.gate + (size_t)(row / 3) * ep.gate_ld + col);
+                                v.x = g4.x * v.x; v.y = g4.y * v.y; v.z = g4.z * v.z; v.w = g4.w * v.w;
+                            }
                             if (ep.accumulate) {   // (training: data gradients summed into their destination, no temporary + add pass)
                                 const float4 o = *reinterpret_cast<const float4*>(C + (size_t)row * ldc + col);
                                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -776,7 +780,8 @@ static int32_t check_a_span(long long rows, int lda) {
 
 int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float* bias, float* C, int ldc, int M,
                           int N, int K, int act_ssilu, hipStream_t s, const float* A2, int K1, const adf_lift* lf,
-                          const float* premag, float* out_mag, const int32_t* m_dev, int accumulate) {
+                          const float* premag, float* out_mag, const int32_t* m_dev, int accumulate, const float* gate,
+                          int gate_ld) {
     if (M <= 0) return ADF_OK;
     if (K % HK != 0 || (lda & 3) || (A2 && (K1 <= 0 || K1 % HK != 0 || K1 >= K))) {
         adf_set_error("gemm16: K=%d (K1=%d) must be multiples of %d and lda a multiple of 4", K, K1, HK);
@@ -792,6 +797,8 @@ int32_t adf_launch_gemm16(const float* A, int lda, const adf_w16* W, const float
     dim3 grid((unsigned)(tiles_m8 * tiles_n));
     adf_epi ep = {};
     ep.A2 = A2; ep.K1 = A2 ? K1 : 0; ep.m_dev = m_dev; ep.accumulate = accumulate;
+    ep.gate = gate; ep.gate_ld = gate_ld;
+    if (gate && ((N | ldc) & 3)) { adf_set_error("gemm16: the gate epilogue needs N and ldc multiples of 4"); return ADF_EINVAL; }
     ADF_TRY(lift_mags(A, lda, A2 ? K1 : K, A2, A2 ? K - K1 : 0, M, lf, premag, &ep.rmag, s, m_dev, 1));
     if (out_mag) {
         ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));

@@ -181,6 +181,19 @@ __global__ void adf_head_gate_kernel(const float* __restrict__ o, const float* _
     }
 }
 
+// x' = ssilu(o[:, :Cout]) only (the gate half of o multiplies vec2_proj's output in that product's epilogue, gemm16.hip)
+__global__ void adf_head_xact_kernel(const float* __restrict__ o, float* __restrict__ xout, int N, int Cout) {
+    const int c4 = Cout / 4;
+    const long long total = (long long)N * c4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / c4), c = (int)(i - (long long)n * c4);
+        const float4 xs = reinterpret_cast<const float4*>(o + (size_t)n * 2 * Cout)[c];
+        reinterpret_cast<float4*>(xout + (size_t)n * Cout)[c] =
+            make_float4(ssilu_d(xs.x), ssilu_d(xs.y), ssilu_d(xs.z), ssilu_d(xs.w));
+    }
+}
+
 // Last gated block (C -> 1), one wave per atom:
 //   vec2 = vec2_proj(v)  [3] ;  g = update_net.2(u)[1] ; out = g * vec2       (painn_denoising.py:690-694,650)
 __global__ __launch_bounds__(256) void adf_head_final_kernel(const float* __restrict__ u, const float* __restrict__ v,
@@ -282,11 +295,22 @@ int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const fl
     } else {  // ||vec1_proj(vec)|| straight from the accumulators into cat [N,H]
         ADF_TRY(adf_launch_gemm16_vecnorm(vec, H, &b0.vec1_16, h->cat, N, H, H, s, lf, vmag));
     }
-    ADF_TRY(adf_linear(h, vec, H, b0.vec2_w, &b0.vec2_16, nullptr, t2, H2, 3 * N, H2, H, 0, s, vmag));
+    // f16x3 path (round 6): vec2_proj runs AFTER the update net and multiplies its rows by the gate half of `o` in its own
+    // epilogue (same single fp32 multiplication per element as adf_head_gate_kernel: same bits); t2 never reaches HBM
+    static int fuse_gate = -1;
+    if (fuse_gate < 0) { const char* e = getenv("ADF_HEAD_GATE_FUSED"); fuse_gate = (e && atoi(e) == 0) ? 0 : 1; }
+    const bool fg = fuse_gate && !h->gemm_f32 && (H2 & 3) == 0;
+    if (!fg) ADF_TRY(adf_linear(h, vec, H, b0.vec2_w, &b0.vec2_16, nullptr, t2, H2, 3 * N, H2, H, 0, s, vmag));
     if (h->gemm_f32) ADF_TRY(adf_linear(h, h->cat, 2 * H, b0.un0_w, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s));
     else ADF_TRY(adf_launch_gemm16(x, H, &b0.un0_16, b0.un0_b, h->y, H, N, H, 2 * H, 1, s, h->cat, H,  // [x | norm]
                                    h->lift_on ? &h->lift : nullptr, nullptr, h->lift_on ? h->mag_b : nullptr));
     ADF_TRY(adf_linear(h, h->y, H, b0.un2_w, &b0.un2_16, b0.un2_b, o, H, N, H, H, 0, s, (h->lift_on && !h->gemm_f32) ? h->mag_b : nullptr));
+    if (fg) {
+        // (its epilogue also emits the magnitudes of the gated rows v1: block 1's vector-norm product needs no measuring pass)
+        ADF_TRY(adf_launch_gemm16(vec, H, &b0.vec2_16, nullptr, v1, H2, 3 * N, H2, H, 0, s, nullptr, 0, lf, vmag,
+                                  lift ? h->lift.buf : nullptr, nullptr, 0, o + H2, H));
+        hipLaunchKernelGGL(adf_head_xact_kernel, dim3(ew_grid((long long)N * H2 / 4)), dim3(256), 0, s, o, x1, N, H2);
+    } else
     hipLaunchKernelGGL(adf_head_gate_kernel, dim3(ew_grid((long long)N * H2 / 4)), dim3(256), 0, s, o, t2, x1, v1, N, H2);
     // block 1: H/2 -> 1
     if (h->gemm_f32) {
@@ -294,7 +318,8 @@ int32_t adf_head_forward(adf_painn* h, int head, int N, const float* x, const fl
         hipLaunchKernelGGL(adf_head_norm_cat_kernel, dim3(ew_grid((long long)N * H2 / 4)), dim3(256), 0, s, x1, t1b, cat1, N, H2);
         ADF_TRY(adf_linear(h, cat1, H, b1.un0_w, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s));
     } else {
-        ADF_TRY(adf_launch_gemm16_vecnorm(v1, H2, &b1.vec1_16, cat1, N, H2, H2, s, h->lift_on ? &h->lift : nullptr));
+        ADF_TRY(adf_launch_gemm16_vecnorm(v1, H2, &b1.vec1_16, cat1, N, H2, H2, s, h->lift_on ? &h->lift : nullptr,
+                                          (fg && lift) ? h->lift.buf : nullptr));
         ADF_TRY(adf_launch_gemm16(x1, H2, &b1.un0_16, b1.un0_b, h->y, H2, N, H2, H, 1, s, cat1, H2, h->lift_on ? &h->lift : nullptr));
     }
     hipLaunchKernelGGL(adf_head_final_kernel, dim3((N + 3) / 4), dim3(256), 0, s, h->y, v1, b1.vec2_w, b1.un2_w,
