@@ -89,6 +89,8 @@ struct adf_eqv2 {
     eq_norm final_norm;
     eq_attn force[2];
     unsigned char* w16_arena; size_t w16_bytes; float* w16_scales; unsigned int* w16_scratch;
+    unsigned char* wfrag_arena;   // fragment images (adf_w16::frag) of the split weights, for eq_launch_gemm16pw
+    bool conv1_wr;                // first convolution with the weights streamed as fragments (ADF_EQV2_CONV1_WR, default on)
     float* wt_arena; size_t wt_bytes;   // transposed first radial layers
     float* rtab_arena; size_t rtab_floats; bool rad_static;   // per-element-pair radial tables (see eq_radial_static)
     // graph
@@ -161,6 +163,10 @@ int32_t eq_launch_rotate_in(const adf_eqv2* h, const float* y, const float* rad,
                             float* const* mbuf, float* const* rsp, bool presplit, hipStream_t s);
 int32_t eq_launch_gemm16p(const void* Ahi, const void* Alo, const float* mag, const adf_w16* W, const float* bias, float* Cm,
                           int ldc, long long M, int N, int K, int act, hipStream_t s);
+// the same product with the weights streamed from their fragment image (W->frag); eq_gemm16pw_ok: shapes it takes
+bool eq_gemm16pw_ok(const adf_w16* W, int N, int K);
+int32_t eq_launch_gemm16pw(const void* Ahi, const void* Alo, const float* mag, const adf_w16* W, const float* bias, float* Cm,
+                           int ldc, long long M, int N, int K, int act, hipStream_t s);
 // rsp (optional): per-order arrays that receive the power-of-two lifts of the output rows (matrix-core version only;
 // *rs_written tells whether they were filled)
 int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, int extra, int gate_off, int n0, int n1,

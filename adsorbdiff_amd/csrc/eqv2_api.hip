@@ -122,6 +122,7 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     // instead of a separate pass over them: measured slower on MI355X (+8 ms vs -3 ms per forward at 256 k edges): off
     { const char* e2 = getenv("ADF_EQV2_S2_EMIT"); h->s2_emit_mag = e2 && atoi(e2) != 0; }
     { const char* e3 = getenv("ADF_EQV2_PRESPLIT"); h->presplit = !(e3 && atoi(e3) == 0); }
+    { const char* e4 = getenv("ADF_EQV2_CONV1_WR"); h->conv1_wr = !(e4 && atoi(e4) == 0); }
     { const char* e4 = getenv("ADF_EQV2_FOLD"); h->fold_on = !(e4 && atoi(e4) == 0); }
     { const char* e5 = getenv("ADF_EQV2_COMPACT"); h->no_compact = e5 && atoi(e5) == 0; }
     h->prof_ev = new std::vector<hipEvent_t>();
@@ -169,7 +170,7 @@ extern "C" int32_t adf_eqv2_destroy(adf_eqv2_t h) {
     { unsigned char* t = (unsigned char*)h->gtab_to; eq_free(t); h->gtab_to = nullptr; }
     { unsigned char* t = (unsigned char*)h->gtab_from; eq_free(t); h->gtab_from = nullptr; }
     eq_free(h->jd); eq_free(h->to_red); eq_free(h->from_red); eq_free(h->to_full); eq_free(h->from_full);
-    eq_free(h->w16_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena); eq_free(h->rtab_arena); eq_free(h->fold_arena);
+    eq_free(h->w16_arena); eq_free(h->wfrag_arena); eq_free(h->w16_scales); eq_free(h->w16_scratch); eq_free(h->wt_arena); eq_free(h->rtab_arena); eq_free(h->fold_arena);
     if (h->prof_ev) { for (hipEvent_t e : *h->prof_ev) (void)hipEventDestroy(e); delete h->prof_ev; }
     delete h->prof_cat;
     delete h;
@@ -352,21 +353,28 @@ static int32_t eq_split_weights(adf_eqv2* h, hipStream_t s) {
     }
     if (h->w16_bytes < halves * 2 + 64) {
         ADF_HIP_CHECK(hipDeviceSynchronize());
-        eq_free(h->w16_arena);
+        eq_free(h->w16_arena); eq_free(h->wfrag_arena);
         ADF_TRY(eq_alloc(&h->w16_arena, halves * 2 + 64));
+        ADF_TRY(eq_alloc(&h->wfrag_arena, halves * 2 + 64));
         h->w16_bytes = halves * 2 + 64;
     }
     eq_free(h->w16_scales);
     ADF_TRY(eq_alloc(&h->w16_scales, nmat + 1));
     if (!h->w16_scratch) ADF_TRY(eq_alloc(&h->w16_scratch, 4));
     unsigned char* p = h->w16_arena;
+    unsigned char* pf = h->wfrag_arena;
     size_t k = 0;
     for (eq_lin* l : v) {
         if (l->in % 32 != 0 || (l->out & 3)) continue;
         const size_t n = (size_t)l->out * l->in;
         l->w16.hi = p; l->w16.lo = p + n * 2; l->w16.inv_scale = h->w16_scales + k; l->w16.bias_perm = nullptr;
-        p += n * 4; ++k;
+        l->w16.frag = nullptr;
         ADF_TRY(adf_split_weight(l->w, (long long)n, &l->w16, h->w16_scratch, s));
+        if (l->out % 32 == 0) {   // the MFMA B operands in fragment order (eq_gemm16pw_kernel)
+            ADF_TRY(adf_pack_frag(&l->w16, l->out, l->in, pf, s));
+            l->w16.frag = pf;
+        }
+        p += n * 4; pf += n * 4; ++k;
         l->has16 = true;
     }
     return ADF_OK;
@@ -691,6 +699,7 @@ static eq_lin eq_lin_rows(const eq_lin& p, int row0, int n) {
     if (p.has16) {
         r.w16.hi = static_cast<unsigned char*>(p.w16.hi) + (size_t)row0 * p.in * 2;
         r.w16.lo = static_cast<unsigned char*>(p.w16.lo) + (size_t)row0 * p.in * 2;
+        r.w16.frag = nullptr;   // (the fragment image is ordered by 32-row blocks of the whole matrix)
     }
     return r;
 }
@@ -790,8 +799,12 @@ static int32_t eq_attention(adf_eqv2* h, const eq_attn* at, const float* y, cons
                     const eq_lin* W = m == 0 ? &at->c1_m0 : &at->c1_m[m - 1];
                     const long long rows = m == 0 ? Eub : 2 * Eub;
                     const _Float16* hi = reinterpret_cast<const _Float16*>(b.m[m]);
-                    ADF_TRY(eq_launch_gemm16p(hi, hi + (size_t)rows * W->in, b.rsb[m], &W->w16, m == 0 ? W->b : nullptr, b.y[m],
-                                              W->out, rows, W->out, W->in, 0, s));
+                    if (h->conv1_wr && eq_gemm16pw_ok(&W->w16, W->out, W->in))
+                        ADF_TRY(eq_launch_gemm16pw(hi, hi + (size_t)rows * W->in, b.rsb[m], &W->w16, m == 0 ? W->b : nullptr,
+                                                   b.y[m], W->out, rows, W->out, W->in, 0, s));
+                    else
+                        ADF_TRY(eq_launch_gemm16p(hi, hi + (size_t)rows * W->in, b.rsb[m], &W->w16, m == 0 ? W->b : nullptr, b.y[m],
+                                                  W->out, rows, W->out, W->in, 0, s));
                 }
             } else {
                 ADF_TRY(eq_gemm(h, b.m[0], at->c1_m0.in, nullptr, &at->c1_m0, true, b.y[0], at->c1_m0.out, nullptr, Eub, 0, false, s,
@@ -1169,7 +1182,8 @@ extern "C" int32_t adf_eqv2_linear_forward(const float* A, const float* W, const
     if (!eq_gemm16_ok(A, &am, Cm, &cm, N, K)) { adf_set_error("shape not taken by the f16x3 kernels"); return ADF_EINVAL; }
     unsigned char* buf = nullptr;
     const size_t n = (size_t)N * K, ma = (size_t)M * K;
-    ADF_TRY(eq_alloc(&buf, n * 4 + 64 + (size_t)M * 4 + (mode == 2 ? ma * 4 : 0) + 64));
+    if (mode == 3 && (N % 32 || K % 64 || N < 128)) { adf_set_error("mode 3 needs N %% 32 == 0, N >= 128 and K %% 64 == 0"); return ADF_EINVAL; }
+    ADF_TRY(eq_alloc(&buf, n * 4 + 64 + (size_t)M * 4 + 64 + (mode >= 2 ? ma * 4 : 0) + 64 + (mode == 3 ? n * 4 : 0)));
     adf_w16 w16 = {};
     w16.hi = buf; w16.lo = buf + n * 2; w16.inv_scale = reinterpret_cast<float*>(buf + n * 4); w16.bias_perm = nullptr;
     unsigned int* scratch = reinterpret_cast<unsigned int*>(buf + n * 4 + 16);
@@ -1177,9 +1191,14 @@ extern "C" int32_t adf_eqv2_linear_forward(const float* A, const float* W, const
     unsigned char* split = buf + n * 4 + 64 + (((size_t)M * 4 + 63) / 64) * 64;
     int32_t st = adf_split_weight(W, (long long)n, &w16, scratch, s);
     if (st == ADF_OK) st = eq_launch_rowscale(A, &am, M, K, mag, s);
-    if (st == ADF_OK && mode == 2) st = eq_launch_presplit(A, mag, M, K, split, split + ma * 2, s);
+    if (st == ADF_OK && mode >= 2) st = eq_launch_presplit(A, mag, M, K, split, split + ma * 2, s);
+    if (st == ADF_OK && mode == 3) {
+        w16.frag = split + ((ma * 4 + 63) / 64) * 64;
+        st = adf_pack_frag(&w16, N, K, w16.frag, s);
+    }
     for (int r = 0; r < (repeat > 0 ? repeat : 1) && st == ADF_OK; ++r) {
-        if (mode == 2) st = eq_launch_gemm16p(split, split + ma * 2, mag, &w16, bias, Cm, N, M, N, K, act, s);
+        if (mode == 3) st = eq_launch_gemm16pw(split, split + ma * 2, mag, &w16, bias, Cm, N, M, N, K, act, s);
+        else if (mode == 2) st = eq_launch_gemm16p(split, split + ma * 2, mag, &w16, bias, Cm, N, M, N, K, act, s);
         else st = eq_launch_gemm16(A, &am, mag, &w16, bias, Cm, &cm, M, N, K, act, false, s, nullptr);
     }
     (void)hipStreamSynchronize(s);

@@ -598,6 +598,221 @@ int32_t eq_launch_gemm16p(const void* Ahi, const void* Alo, const float* mag, co
     return ADF_OK;
 }
 
+// The same product with the WEIGHTS STREAMED AS MFMA FRAGMENTS (round 6; the form gemm16.hip's node products took this
+// round): every wave loads the B operands of its own two column blocks straight from the fragment-ordered image
+// (adf_pack_frag, mlp16.hip) into a ring of four register sets, two k-steps ahead; LDS holds only the A tile (two buffers,
+// hi + lo, 64-byte rows with the chunk XOR-swizzle of the kernel above), one barrier per K tile, the next tile's rows are
+// requested two tiles ahead in two register sets and copied into the other buffer between the products of the second
+// k-step.  Per K tile a CU's LDS moves (TM / 256) x (128 KB of fragment reads + 32 KB of writes) instead of 196 + 64 KB.
+// Same products in the same order as eq_gemm16p_kernel: same bits.
+//   NWN = 4: 8 waves as 2 (M) x 4 (N), tile (64 MI) x 256, one workgroup per CU.
+//   NWN = 2: 4 waves as 2 x 2, tile (64 MI) x 128, two workgroups per CU: the remainder columns of an N that is not a
+//   multiple of 256 (order 2 of config 4: 640 = 2 x 256 + 128) without idle column waves.
+// Columns [col0, col0 + tiles_n * TN) of C; needs K / 32 even and N % 32 == 0 (launcher).
+template <int ACT, int MI, int NWN>
+__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : 2) void eq_gemm16pw_kernel(
+    const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, const float* __restrict__ mag,
+    const half8* __restrict__ Wf, const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ Cm,
+    int ldc, long long M, int N, int K, int tiles_n, int col0) {
+    constexpr int NJ = 2, NT = 128 * NWN, TM = 64 * MI, TN = 64 * NWN, RB = 32;
+    constexpr int NA = TM * 8 / NT;          // 16-byte chunks per thread and K tile (hi and lo planes together)
+    constexpr int PLANE = TM * RB;           // halves per plane
+    constexpr int BUF = 2 * PLANE;           // halves per buffer
+    static_assert(TM * 8 % NT == 0, "whole chunks per thread");
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsw[];
+    __shared__ float rinv[TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / NWN) * (32 * MI), wn = (wave % NWN) * 64;
+    const int id = blockIdx.x, xcd = id & 7, qd = id >> 3;
+    const long long tile_m = (long long)(qd / tiles_n) * 8 + xcd;
+    const int tile_n = qd % tiles_n;
+    const long long m0 = tile_m * TM;
+    const int n0 = col0 + tile_n * TN;
+    if (m0 >= M) return;
+
+    // staging: chunk f = tid + NT i -> plane f / (4 TM), row (f % (4 TM)) >> 2, 16-byte part f & 3
+    const _Float16* a_src[NA];
+    int st_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + NT * i;
+        const int plane = f / (4 * TM), g = f % (4 * TM);
+        const int row = g >> 2, part = g & 3;
+        long long grow = m0 + row;
+        if (grow > M - 1) grow = M - 1;
+        a_src[i] = (plane ? Alo : Ahi) + (size_t)grow * K + part * 8;
+        st_off[i] = plane * PLANE + row * RB + ((part ^ ((row >> 2) & 3)) * 8);
+    }
+    if (tid < TM) {
+        long long grow = m0 + tid;
+        if (grow > M - 1) grow = M - 1;
+        rinv[tid] = 1.0f / eq16_lift(mag[grow]);
+    }
+    half8 ra[NA], rb[NA];
+    auto request = [&](half8 (&r)[NA], int kt1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) r[i] = *reinterpret_cast<const half8*>(a_src[i] + (size_t)kt1 * GK);
+    };
+    auto store = [&](const half8 (&r)[NA], int boff) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<half8*>(ldsw + boff + st_off[i]) = r[i];
+    };
+    // B fragments of one 16-deep k-step for this wave's two column blocks: [column block][hi | lo]; a column block past N
+    // (the dead half of a last tile) reads block 0 and is never stored
+    const int nks = K / 16;
+    const int cbw = (n0 + wn) / 32;
+    const half8* wfr[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) wfr[j] = Wf + (size_t)((cbw + j) * 32 < N ? cbw + j : 0) * nks * 128 + lane;
+    auto load_wf = [&](int s_, half8 (&wf)[NJ][2]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            wf[j][0] = wfr[j][(size_t)s_ * 128];
+            wf[j][1] = wfr[j][(size_t)s_ * 128 + 64];
+        }
+    };
+    half8 wfa[NJ][2], wfb[NJ][2], wfc[NJ][2], wfd[NJ][2];
+    request(ra, 0);
+    load_wf(0, wfa);
+    load_wf(1, wfb);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / GK;
+    const int frow = lane & 31, fsw = (frow >> 2) & 3, fkh = lane >> 5;
+    int foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = (wm + frow) * RB + (((2 * ks + fkh) ^ fsw) * 8);
+    auto kstep = [&](int boff, int ks, const half8 (&cur)[NJ][2]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const half8 ah = *reinterpret_cast<const half8*>(ldsw + boff + i * 32 * RB + foff[ks]);
+            const half8 al = *reinterpret_cast<const half8*>(ldsw + boff + PLANE + i * 32 * RB + foff[ks]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, cur[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cur[j][0], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    // tile kt: products on buffer `cur`; `nxt` (tile kt + 1, in registers) is copied into the other buffer between the
+    // products of the second k-step; (w0, w1) are this tile's fragments, the next tile's are requested into (w2, w3).
+    // sched_barrier(0) between request group and product group: left alone, hipcc sinks the requests to their first use.
+    auto tile = [&](int kt, int cur, const half8 (&nxt)[NA], const half8 (&w0)[NJ][2], const half8 (&w1)[NJ][2],
+                    half8 (&w2)[NJ][2], half8 (&w3)[NJ][2]) {
+        load_wf(min(2 * kt + 2, 2 * nk - 1), w2);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(cur, 0, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_wf(min(2 * kt + 3, 2 * nk - 1), w3);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(cur, 1, w1);
+        store(nxt, BUF - cur);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * MI, 0);
+#pragma unroll
+        for (int u = 0; u < 3 * MI * NJ; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            if (u % 3 == 2 && u / 3 < NA) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    store(ra, 0);                          // tile 0
+    request(ra, min(1, nk - 1));
+    request(rb, min(2, nk - 1));
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {   // (nk is even: launcher)
+        tile(kt, 0, ra, wfa, wfb, wfc, wfd);
+        request(ra, min(kt + 3, nk - 1));
+        __syncthreads();
+        tile(kt + 1, BUF, rb, wfc, wfd, wfa, wfb);
+        request(rb, min(kt + 4, nk - 1));
+        __syncthreads();
+    }
+
+    const float isc = *inv_scale;
+    const int q = lane & 31;
+    float* T = reinterpret_cast<float*>(ldsw) + wave * (32 * GTLD);  // [32 rows][64] floats per wave
+    const int cb = n0 + wn;
+    if (cb >= N) return;   // (no barrier below)
+    const float bv0 = (bias && cb + q < N) ? bias[cb + q] : 0.f;
+    const float bv1 = (bias && cb + 32 + q < N) ? bias[cb + 32 + q] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sc = isc * rinv[wm + 32 * i + lr];
+            float v0 = acc[i][0][r] * sc + bv0, v1 = acc[i][1][r] * sc + bv1;
+            if (ACT == 2) { v0 = eq16_silu(v0); v1 = eq16_silu(v1); }
+            T[lr * GTLD + q] = v0;
+            T[lr * GTLD + 32 + q] = v1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int item = lane + 64 * it;
+            const int lr = item >> 4, c4 = item & 15;
+            const long long row = m0 + wm + 32 * i + lr;
+            const int col = cb + 4 * c4;
+            if (row < M && col < N)
+                *reinterpret_cast<float4*>(Cm + row * (long long)ldc + col) = *reinterpret_cast<const float4*>(T + lr * GTLD + 4 * c4);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int ACT, int MI, int NWN>
+static int32_t eq_gemm16pw_go(const void* Ahi, const void* Alo, const float* mag, const adf_w16* W, const float* bias, float* Cm,
+                              int ldc, long long M, int N, int K, int col0, int ncols, hipStream_t s) {
+    constexpr int TM = 64 * MI, TN = 64 * NWN;
+    const int tiles_n = (ncols + TN - 1) / TN;
+    const long long tiles_m8 = ((M + TM - 1) / TM + 7) / 8 * 8;
+    const long long nb = tiles_m8 * tiles_n;
+    if (nb > 0x7fffffffLL) { adf_set_error("eq_gemm16pw: grid too large"); return ADF_EINVAL; }
+    // two A buffers; the epilogue's per-wave transposition scratch (2 NWN waves x 8 KB) lives in the same bytes
+    size_t dyn = (size_t)2 * 2 * TM * 32 * sizeof(_Float16);
+    const size_t scratch = (size_t)2 * NWN * 32 * GTLD * sizeof(float);
+    if (dyn < scratch) dyn = scratch;
+    auto kern = &eq_gemm16pw_kernel<ACT, MI, NWN>;
+    ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(128 * NWN), dyn, s, (const _Float16*)Ahi, (const _Float16*)Alo, mag,
+                       (const half8*)W->frag, W->inv_scale, bias, Cm, ldc, M, N, K, tiles_n, col0);
+    ADF_HIP_CHECK(hipGetLastError());
+    return ADF_OK;
+}
+
+// whether eq_launch_gemm16pw takes the shape (the weight needs its fragment image)
+bool eq_gemm16pw_ok(const adf_w16* W, int N, int K) { return W->frag && N % 32 == 0 && K % 64 == 0 && N >= 128; }
+
+int32_t eq_launch_gemm16pw(const void* Ahi, const void* Alo, const float* mag, const adf_w16* W, const float* bias, float* Cm,
+                           int ldc, long long M, int N, int K, int act, hipStream_t s) {
+    if (M <= 0 || N <= 0) return ADF_OK;
+    if (!eq_gemm16pw_ok(W, N, K)) { adf_set_error("eq_gemm16pw: shape or fragment image"); return ADF_EINVAL; }
+    static int mi = -1;   // rows per tile: 256 (default; 1.5 % faster than 192 on config 4's shapes), ADF_EQV2_PW_MI=3: 192
+    if (mi < 0) { const char* e = getenv("ADF_EQV2_PW_MI"); mi = (e && atoi(e) == 3) ? 3 : 4; }
+    // whole 256-column tiles on eight waves; a remainder of at most 128 columns on the four-wave form
+    const int rem = N % 256;
+    const int wide = (rem > 0 && rem <= 128) ? N - rem : N;
+#define EQ_PW(ACT_, MI_, NWN_, C0_, NC_) eq_gemm16pw_go<ACT_, MI_, NWN_>(Ahi, Alo, mag, W, bias, Cm, ldc, M, N, K, C0_, NC_, s)
+    if (wide > 0) {
+        if (act == 2) { if (mi == 4) ADF_TRY(EQ_PW(2, 4, 4, 0, wide)); else ADF_TRY(EQ_PW(2, 3, 4, 0, wide)); }
+        else { if (mi == 4) ADF_TRY(EQ_PW(0, 4, 4, 0, wide)); else ADF_TRY(EQ_PW(0, 3, 4, 0, wide)); }
+    }
+    if (wide < N) {
+        if (act == 2) ADF_TRY(EQ_PW(2, 3, 2, wide, N - wide)); else ADF_TRY(EQ_PW(0, 3, 2, wide, N - wide));
+    }
+#undef EQ_PW
+    return ADF_OK;
+}
+
 // A [M, K] fp32 + row magnitudes -> lifted fp16 hi / lo images (unit-test / benchmark path of eq_gemm16p_kernel; in the
 // model the producer kernel writes them directly)
 __global__ void eq_presplit_kernel(const float* __restrict__ A, const float* __restrict__ mag, long long M, int K,

@@ -666,45 +666,47 @@ typedef float eqf32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 eqhalf8 __attribute__((ext_vector_type(8)));
 
 
-// where the m-major reduced coefficient r of an SO(2) convolution's output lives: value = base[o1] + sg * base[o2] with
-// base = the edge's first row in the order-m buffer (m = 0: y0 + el * ld0)
-struct eq_rdesc { int m, o1, o2; float sg; };
+// Global-memory accesses through pointers the compiler cannot trace to a kernel argument (here: selected per lane) would be
+// FLAT instructions, which count on the LDS counter as well: every wait for an LDS read then drains the loads in flight.
+__device__ __forceinline__ float eq_ldg(const float* p) { return *(const __attribute__((address_space(1))) float*)p; }
+__device__ __forceinline__ void eq_stg(float* p, float v) { *(__attribute__((address_space(1))) float*)p = v; }
 
-template <int NBK>
+// Round 6: the item's 32 input loads are issued back to back.  Before, every coefficient row was fetched behind a branch
+// through pointers read from LDS: flat loads, each followed by `s_waitcnt vmcnt(0) lgkmcnt(0)` - 16 serial memory round
+// trips per item (3.9 ms per launch at 256 k edges; the kernel had been filed as VALU-bound).  Now: descriptors are packed
+// words in LDS (four per ds_read_b128), the order's row base is selected per lane among wave-uniform bases derived from the
+// kernel arguments, rows past Sr read a valid address and are zeroed by a select, the stores go the same way.
+//   input descriptor of coefficient r:  bits 0-2 m, 3-4 sign code (1: +1, 2: -1, else 0), 5-17 o1, 18-30 o2, 31 valid;
+//     value = base_m[o1] + sign * base_m[o2], base_m = the edge's first row in the order-m buffer (m = 0: y0 + el * ld0)
+//   output descriptor of coefficient r': bits 0-2 m, 3 valid, 4 row sign, 5-31 float offset from the edge's first output row
+// MT: compile-time bound of the order cut-off M (length of the select chains).
+template <int NBK, int MT>
 __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __restrict__ y0, int ld0, int off0, int gate_off,
                                                                eq_ptrs ym, const int32_t* __restrict__ eptr, int n0, int n1,
                                                                const eq_dims* __restrict__ dg, int Sr, int L, int M, int Hd,
                                                                const eqhalf8* __restrict__ tabs, int npb, float inv_sT,
                                                                float inv_sF, float gain_shift, eq_ptrs mb, eq_ptrs rs) {
     extern __shared__ eqhalf8 tab[];  // TA [npb][2 ks][hi|lo][64], then FA likewise
-    __shared__ eq_rdesc rdesc[32];    // input side, by coefficient r
-    __shared__ int4 odesc[32];        // output side, by coefficient r': (m, row sign, column base, -)
-    __shared__ const float* in_ptr[EQ_MAX_M + 1];
-    __shared__ float* out_ptr[EQ_MAX_M + 1];
-    __shared__ unsigned int* mag_ptr[EQ_MAX_M + 1];
+    __shared__ __attribute__((aligned(16))) unsigned int idesc[32];   // input side, by coefficient r
+    __shared__ __attribute__((aligned(16))) unsigned int odesc[32];   // output side, by coefficient r'
     __shared__ unsigned int wmag[16][2 * EQ_MAX_M + 2];  // per wave: magnitudes of the item's destination rows
     const int ntab = npb * 2 * 2 * 64;
     for (int t = threadIdx.x; t < 2 * ntab; t += 1024) tab[t] = tabs[t];
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + EQ_MAX_M + 1) {
-        const int m = threadIdx.x - 64;
-        in_ptr[m] = m == 0 ? y0 : ym.p[m <= M ? m : 0];
-        out_ptr[m] = mb.p[m <= M ? m : 0];
-        mag_ptr[m] = reinterpret_cast<unsigned int*>(rs.p[m <= M ? m : 0]);
-    }
     if (threadIdx.x < 32) {
         const int r = threadIdx.x;
-        eq_rdesc q = {-1, 0, 0, 0.f};
-        int4 o = make_int4(-1, 0, 0, 0);
+        unsigned int q = ((unsigned int)off0 << 5) | ((unsigned int)off0 << 18);   // not a coefficient: a valid address, zeroed
+        unsigned int o = 0u;
         if (r < Sr) {
             const int m = dg->r_m[r], l = dg->r_l[r], sg = dg->r_sgn[r];
             const int nm = L - m + 1, half = nm * Hd, W = 2 * half, c0 = (l - m) * Hd;
-            q.m = m;
-            if (m == 0) { q.o1 = off0 + l * Hd; q.o2 = q.o1; q.sg = 0.f; }
-            else if (sg == 0) { q.o1 = c0; q.o2 = W + half + c0; q.sg = -1.f; }
-            else { q.o1 = W + c0; q.o2 = half + c0; q.sg = 1.f; }
-            o = make_int4(m, sg, c0, m == 0 ? 0 : 2 * m - 1 + sg);
+            int o1, o2, code;
+            if (m == 0) { o1 = off0 + l * Hd; o2 = o1; code = 0; }
+            else if (sg == 0) { o1 = c0; o2 = W + half + c0; code = 2; }
+            else { o1 = W + c0; o2 = half + c0; code = 1; }
+            q = (unsigned int)m | ((unsigned int)code << 3) | ((unsigned int)o1 << 5) | ((unsigned int)o2 << 18) | 0x80000000u;
+            o = (unsigned int)m | 8u | ((unsigned int)sg << 4) | ((unsigned int)((m == 0 ? 0 : sg * half) + c0) << 5);
         }
-        rdesc[r] = q;
+        idesc[r] = q;
         odesc[r] = o;
     }
     __syncthreads();
@@ -715,32 +717,68 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
     const int cl = lane & 31, kh = lane >> 5;
     const long long ebase = eptr[n0];
     const long long Ec = eptr[n1] - ebase;
+    const bool emit = rs.p[0] != nullptr;
     // one wave per (edge, block of 32 hidden channels)
     // (Measured alternative: writing the outputs as the second convolution's pre-split operand rows - fp16 hi / lo lifted per
     // row, the two waves of an edge exchanging their row maxima through LDS - made that product 8 ms per forward faster at
-    // 256 k edges and this kernel 9 ms slower: 600 more VALU instructions per item in a VALU-bound kernel.  Not kept.)
+    // 256 k edges and this kernel 9 ms slower: 600 more VALU instructions per item.  Not kept.)
     const int nblk = Hd >> 5;
     for (long long item = (long long)blockIdx.x * 16 + wave; item < Ec * nblk; item += (long long)gridDim.x * 16) {
         const long long el = item / nblk;
         const int cb = (int)(item - el * nblk) * 32;
-        const float* base0 = y0 + (size_t)el * ld0;
+        // the edge's first row per order, input and output side (wave-uniform)
+        const float* bin[MT + 1];
+        float* bout[MT + 1];
+        bin[0] = y0 + (size_t)el * ld0;
+        bout[0] = mb.p[0] + (size_t)el * (L + 1) * Hd;
+#pragma unroll
+        for (int m = 1; m <= MT; ++m) {
+            const int nm = L - m + 1;
+            bin[m] = ym.p[m <= M ? m : 0] + (size_t)(2 * el) * (2 * nm * Hd);
+            bout[m] = mb.p[m <= M ? m : 0] + (size_t)(2 * el) * (nm * Hd);
+        }
         eqhalf8 b1h[NBK][2], b1l[NBK][2];
         float lift;
+        float gate[NBK];
         {
-            float vin[NBK][2][8];
+            uint4 dq[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dq[t] = *reinterpret_cast<const uint4*>(&idesc[16 * (t >> 1) + 8 * kh + 4 * (t & 1)]);
+            float va[NBK][2][8], vb[NBK][2][8];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint4 d4 = dq[2 * ks + (j >> 2)];
+                    const unsigned int d = (j & 3) == 0 ? d4.x : ((j & 3) == 1 ? d4.y : ((j & 3) == 2 ? d4.z : d4.w));
+                    const int m = (int)(d & 7u);
+                    const float* bp = bin[0];
+#pragma unroll
+                    for (int mm = 1; mm <= MT; ++mm) bp = m == mm ? bin[mm] : bp;
+                    const int o1 = (int)((d >> 5) & 0x1fffu), o2 = (int)((d >> 18) & 0x1fffu);
+#pragma unroll
+                    for (int nb = 0; nb < NBK; ++nb) {
+                        const int c = cb + 32 * nb + cl;
+                        va[nb][ks][j] = eq_ldg(bp + o1 + c);
+                        vb[nb][ks][j] = eq_ldg(bp + o2 + c);
+                    }
+                }
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) gate[nb] = eq_ldg(bin[0] + gate_off + cb + 32 * nb + cl);
             float mx = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const eq_rdesc q = rdesc[16 * ks + 8 * kh + j];
-                    const int nm = L - q.m + 1;
-                    const float* bp = q.m <= 0 ? base0 : in_ptr[q.m] + (size_t)(2 * el) * (2 * nm * Hd);
+                    const uint4 d4 = dq[2 * ks + (j >> 2)];
+                    const unsigned int d = (j & 3) == 0 ? d4.x : ((j & 3) == 1 ? d4.y : ((j & 3) == 2 ? d4.z : d4.w));
+                    const unsigned int code = (d >> 3) & 3u;
+                    const float sg = code == 1u ? 1.f : (code == 2u ? -1.f : 0.f);
 #pragma unroll
                     for (int nb = 0; nb < NBK; ++nb) {
-                        const int c = cb + 32 * nb + cl;
-                        const float v = q.m < 0 ? 0.f : bp[q.o1 + c] + q.sg * bp[q.o2 + c];
-                        vin[nb][ks][j] = v;
+                        float v = va[nb][ks][j] + sg * vb[nb][ks][j];
+                        v = (d & 0x80000000u) ? v : 0.f;
+                        va[nb][ks][j] = v;
                         mx = fmaxf(mx, fabsf(v));
                     }
                 }
@@ -753,7 +791,7 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float sv = vin[nb][ks][j] * lift;
+                        const float sv = va[nb][ks][j] * lift;
                         const _Float16 hh = (_Float16)sv;
                         b1h[nb][ks][j] = hh;
                         b1l[nb][ks][j] = (_Float16)(sv - (float)hh);
@@ -808,37 +846,45 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
         }
         const float sc2 = inv_sF / lift2;
         // outputs (row r' = (reg & 3) + 8 (reg >> 2) + 4 kh), the l = 0 row replaced by SiLU of the scalar gate
-        if (lane < 2 * EQ_MAX_M + 2) wmag[wave][lane] = 0u;
+        if (emit && lane < 2 * EQ_MAX_M + 2) wmag[wave][lane] = 0u;
+        uint4 oq[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) oq[t] = *reinterpret_cast<const uint4*>(&odesc[8 * t + 4 * kh]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int4 o = odesc[(r & 3) + 8 * (r >> 2) + 4 * kh];
-            if (o.x < 0) continue;
-            const int nm = L - o.x + 1;
-            const long long row = o.x == 0 ? el : 2 * el + o.y;
-            float* dst = out_ptr[o.x] + (size_t)row * nm * Hd + o.z;
+            const uint4 o4 = oq[r >> 2];
+            const unsigned int o = (r & 3) == 0 ? o4.x : ((r & 3) == 1 ? o4.y : ((r & 3) == 2 ? o4.z : o4.w));
+            const int m = (int)(o & 7u);
+            float* dp = bout[0];
+#pragma unroll
+            for (int mm = 1; mm <= MT; ++mm) dp = m == mm ? bout[mm] : dp;
+            float* dst = dp + (o >> 5);
             float mg = 0.f;
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb) {
                 const int c = cb + 32 * nb + cl;
                 float v = acc2[nb][r] * sc2;
-                if (r == 0 && kh == 0) v = eq_silu(base0[gate_off + c]);
-                dst[c] = v;
+                if (r == 0 && kh == 0) v = eq_silu(gate[nb]);
+                if (o & 8u) eq_stg(dst + c, v);
                 mg = fmaxf(mg, fabsf(v));
             }
             // magnitude of the destination row (zeroed by the launcher): the next product's power-of-two lift comes from it
-            if (mag_ptr[0]) {
+            if (emit) {
 #pragma unroll
                 for (int sh = 16; sh > 0; sh >>= 1) mg = fmaxf(mg, __shfl_xor(mg, sh));
-                if (cl == 0) atomicMax(&wmag[wave][o.x == 0 ? 0 : 2 * o.x - 1 + o.y], __float_as_uint(mg));
+                if (cl == 0 && (o & 8u)) atomicMax(&wmag[wave][m == 0 ? 0 : 2 * m - 1 + (int)((o >> 4) & 1u)], __float_as_uint(mg));
             }
         }
-        if (mag_ptr[0]) {
+        if (emit) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (lane < 2 * M + 1) {
                 const int m = (lane + 1) >> 1;
                 const long long row = m == 0 ? el : 2 * el + ((lane + 1) & 1);
-                atomicMax(mag_ptr[m] + row, wmag[wave][lane]);
+                float* mp = rs.p[0];
+#pragma unroll
+                for (int mm = 1; mm <= MT; ++mm) mp = m == mm ? rs.p[mm <= M ? mm : 0] : mp;
+                atomicMax(reinterpret_cast<unsigned int*>(mp) + row, wmag[wave][lane]);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -854,18 +900,24 @@ int32_t eq_launch_s2act(const adf_eqv2* h, const float* y0, float* const* ym, in
     eq_ptrs a, b;
     for (int m = 0; m <= d.M; ++m) { a.p[m] = ym[m]; b.p[m] = mbp[m]; }
     const int ld0 = extra + (d.L + 1) * d.Hd;
-    if (!h->exact_f32 && h->s2tab && d.Sr <= 32 && d.Hd % 32 == 0) {
+    // (the packed descriptors of the matrix-core kernel hold 13-bit column offsets)
+    if (!h->exact_f32 && h->s2tab && d.Sr <= 32 && d.Hd % 32 == 0 && ld0 <= 8192 && 4 * (d.L + 1) * d.Hd <= 8192) {
         eq_ptrs r;
         for (int m = 0; m <= EQ_MAX_M; ++m) r.p[m] = (rsp && m <= d.M) ? rsp[m] : nullptr;
         if (rsp)
             for (int m = 0; m <= d.M; ++m)
                 ADF_HIP_CHECK(hipMemsetAsync(rsp[m], 0, sizeof(float) * (size_t)(m == 0 ? Eub : 2 * Eub), s));
         const size_t dyn = (size_t)h->s2_npb * 2 * 2 * 64 * 16 * 2;
-        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_s2act_mfma_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(eq_s2act_mfma_kernel<1>, dim3(h->num_cus), dim3(1024), dyn, s, y0, ld0, extra, gate_off, a, h->eptr,
-                           n0, n1, h->d_dev, d.Sr, d.L, d.M, d.Hd, (const eqhalf8*)h->s2tab, h->s2_npb, h->s2_inv_sT,
-                           h->s2_inv_sF, h->s2_gain_shift, b, r);
+#define EQ_S2(MT_)                                                                                                          \
+    do {                                                                                                                    \
+        ADF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&eq_s2act_mfma_kernel<1, MT_>),                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                           \
+        hipLaunchKernelGGL((eq_s2act_mfma_kernel<1, MT_>), dim3(h->num_cus), dim3(1024), dyn, s, y0, ld0, extra, gate_off, a, \
+                           h->eptr, n0, n1, h->d_dev, d.Sr, d.L, d.M, d.Hd, (const eqhalf8*)h->s2tab, h->s2_npb,            \
+                           h->s2_inv_sT, h->s2_inv_sF, h->s2_gain_shift, b, r);                                             \
+    } while (0)
+        if (d.M <= 2) EQ_S2(2); else EQ_S2(EQ_MAX_M);
+#undef EQ_S2
         ADF_HIP_CHECK(hipGetLastError());
         *rs_written = rsp != nullptr;
         return ADF_OK;

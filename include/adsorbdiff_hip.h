@@ -507,8 +507,9 @@ int32_t adf_eqv2_sample_traj(adf_eqv2_t h, const adf_batch* b, float* pos, const
 /* Stand-alone torch.nn.functional.linear (+ optional SiLU, act = 2) through this path's dense-product kernels (unit tests
  * and micro-benchmarks of so2_ops.py:12-79,158-238 / so3.py:694-745 shapes).  A [M,K], W [N,K], bias [N] or NULL, C [M,N],
  * device pointers.  mode 0: exact f32; 1: f16x3 split with per-row power-of-two lifts (fp32 rows split in the kernel;
- * K % 32 == 0, N % 4 == 0); 2: the same product on rows pre-split into fp16 hi / lo images.  repeat > 1 re-runs the
- * product kernel alone.  Synchronises. */
+ * K % 32 == 0, N % 4 == 0); 2: the same product on rows pre-split into fp16 hi / lo images; 3: as 2 with the weights
+ * streamed from their MFMA-fragment image (the sampler's first SO(2) convolution; N % 32 == 0, N >= 128, K % 64 == 0;
+ * bit-identical to 2).  repeat > 1 re-runs the product kernel alone.  Synchronises. */
 int32_t adf_eqv2_linear_forward(const float* A, const float* W, const float* bias, float* C, int64_t M, int32_t N, int32_t K,
                                 int32_t act, int32_t mode, int32_t repeat, void* stream);
 

@@ -449,6 +449,38 @@ def test_eqv2_linear_f16x3_row_lifts_cover_the_activation_range(mode, scale):
     assert rel_err(out[:300].cpu(), ref2.cpu()) < 5e-6
 
 
+@pytest.mark.parametrize("shape", [(9000, 640, 512), (1000, 1024, 1792), (777, 768, 1536), (5000, 128, 128), (300, 160, 64)])
+def test_eqv2_first_convolution_with_streamed_weight_fragments_is_bit_identical(shape):
+    """The sampler's first SO(2) convolution (so2_ops.py:158-238) runs `eq_gemm16pw_kernel`: pre-split operand rows through
+    LDS, the weights streamed from their MFMA-fragment image into registers.  Same products in the same order as the
+    LDS-staged `eq_gemm16p_kernel` (mode 2): equal bit for bit, and within 5e-6 of float64 per row.  Shapes: config 4's
+    three orders (N = 1024 / 768 / 640: the last one splits into two eight-wave column tiles and a four-wave remainder),
+    a ragged last row tile, N below one tile."""
+    import ctypes as C
+
+    from adsorbdiff_amd import lib as L
+
+    lib = L.load()
+    torch.manual_seed(1)
+    M, N, K = shape
+    A = torch.randn(M, K, device=DEV)
+    A[::7] *= 1e-3
+    A[5] = 0.0
+    W = torch.randn(N, K, device=DEV) * 0.05
+    b = torch.randn(N, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ref = A.double() @ W.double().T + b.double()
+    for act in (0, 2):
+        o2 = torch.empty(M, N, device=DEV)
+        o3 = torch.full((M, N), float("nan"), device=DEV)
+        L.check(lib.adf_eqv2_linear_forward(A.data_ptr(), W.data_ptr(), b.data_ptr(), o2.data_ptr(), M, N, K, act, 2, 1, st))
+        L.check(lib.adf_eqv2_linear_forward(A.data_ptr(), W.data_ptr(), b.data_ptr(), o3.data_ptr(), M, N, K, act, 3, 1, st))
+        assert torch.equal(o2, o3)
+        r = torch.nn.functional.silu(ref) if act == 2 else ref
+        err = ((o3.double() - r).norm(dim=1) / r.norm(dim=1).clamp(min=1e-30))
+        assert float(err.max()) < 5e-6, float(err.max())
+
+
 @pytest.mark.parametrize("exact", [False, True])
 def test_eqv2_config4_width_vs_reference_fixture(exact):
     """BASELINE config 4 AT ITS STATED SHAPE (configs/denoising/eqv2_so3.yml:40-75 with lmax_list [6]: C=128, 8 heads,
