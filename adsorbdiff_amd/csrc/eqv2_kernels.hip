@@ -680,6 +680,21 @@ __device__ __forceinline__ void eq_stg(float* p, float v) { *(__attribute__((add
 //     value = base_m[o1] + sign * base_m[o2], base_m = the edge's first row in the order-m buffer (m = 0: y0 + el * ld0)
 //   output descriptor of coefficient r': bits 0-2 m, 3 valid, 4 row sign, 5-31 float offset from the edge's first output row
 // MT: compile-time bound of the order cut-off M (length of the select chains).
+// fp16 hi / lo terms of p0 s and p1 s (s a power of two: the products are exact), packed in the MFMA operand order:
+// hi = f16(p s), lo = f16(p s - hi), one v_fma_mix per term (the multiplication and the conversion in one instruction, the
+// subtrahend read as the fp16 half it is).  hipcc's own code for `sv = p * s; hh = (_Float16)sv; ll = (_Float16)(sv - (float)hh)`
+// forms hi twice (v_cvt_pk_f16_f32 for the operand, v_fma_mixlo for the residual) beside the multiply: 3.5 instructions per value.
+__device__ __forceinline__ void eq_split_pair(float p0, float p1, float s, unsigned int& hi, unsigned int& lo) {
+    unsigned int h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(p0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(p1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(p0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(p1), "v"(s), "v"(h));
+    hi = h;
+    lo = l;
+}
+typedef unsigned int equint4v __attribute__((ext_vector_type(4)));
+
 template <int NBK, int MT>
 __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __restrict__ y0, int ld0, int off0, int gate_off,
                                                                eq_ptrs ym, const int32_t* __restrict__ eptr, int n0, int n1,
@@ -788,14 +803,18 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks) {
+                    equint4v h4, l4;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float sv = va[nb][ks][j] * lift;
-                        const _Float16 hh = (_Float16)sv;
-                        b1h[nb][ks][j] = hh;
-                        b1l[nb][ks][j] = (_Float16)(sv - (float)hh);
+                    for (int j = 0; j < 8; j += 2) {
+                        unsigned int hw, lw;
+                        eq_split_pair(va[nb][ks][j], va[nb][ks][j + 1], lift, hw, lw);
+                        h4[j >> 1] = hw;
+                        l4[j >> 1] = lw;
                     }
+                    b1h[nb][ks] = __builtin_bit_cast(eqhalf8, h4);
+                    b1l[nb][ks] = __builtin_bit_cast(eqhalf8, l4);
+                }
         }
         const float lift2 = lift * gain_shift;  // SiLU outputs: |silu(g)| <= |g| <= gain * max|in|
         eqf32x16 acc2[NBK];
@@ -825,12 +844,20 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float g = acc1[nb][r] * sc1;
-                    const float sv = g * __builtin_amdgcn_rcpf(1.0f + __expf(-g)) * lift2;
-                    const _Float16 hh = (_Float16)sv;
-                    b2h[nb][r >> 3][r & 7] = hh;
-                    b2l[nb][r >> 3][r & 7] = (_Float16)(sv - (float)hh);
+                for (int ks = 0; ks < 2; ++ks) {
+                    equint4v h4, l4;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const float g0 = acc1[nb][8 * ks + j] * sc1, g1 = acc1[nb][8 * ks + j + 1] * sc1;
+                        const float p0 = g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0));
+                        const float p1 = g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1));
+                        unsigned int hw, lw;
+                        eq_split_pair(p0, p1, lift2, hw, lw);
+                        h4[j >> 1] = hw;
+                        l4[j >> 1] = lw;
+                    }
+                    b2h[nb][ks] = __builtin_bit_cast(eqhalf8, h4);
+                    b2l[nb][ks] = __builtin_bit_cast(eqhalf8, l4);
                 }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -1402,14 +1429,18 @@ __global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __
         const float lift = eq_pow2_lift(mx);
         eqhalf8 bh[4], bl[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
+            equint4v h4, l4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float sv = vin[ks][j] * lift;
-                const _Float16 hh = (_Float16)sv;
-                bh[ks][j] = hh;
-                bl[ks][j] = (_Float16)(sv - (float)hh);
+            for (int j = 0; j < 8; j += 2) {
+                unsigned int hw, lw;
+                eq_split_pair(vin[ks][j], vin[ks][j + 1], lift, hw, lw);
+                h4[j >> 1] = hw;
+                l4[j >> 1] = lw;
             }
+            bh[ks] = __builtin_bit_cast(eqhalf8, h4);
+            bl[ks] = __builtin_bit_cast(eqhalf8, l4);
+        }
         const float sc = inv_sT / lift;
         float* gr = g + (size_t)(n - n0) * G * F + f;
         float omx = 0.f;
@@ -1490,14 +1521,15 @@ __global__ __launch_bounds__(512, 1) void eq_from_grid_mfma_kernel(const float* 
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if (k0 + c < nkst) {
-                    eqhalf8 bh, bl;
+                    equint4v h4, l4;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float sv = v[c][j] * lift;
-                        const _Float16 hh = (_Float16)sv;
-                        bh[j] = hh;
-                        bl[j] = (_Float16)(sv - (float)hh);
+                    for (int j = 0; j < 8; j += 2) {
+                        unsigned int hw, lw;
+                        eq_split_pair(v[c][j], v[c][j + 1], lift, hw, lw);
+                        h4[j >> 1] = hw;
+                        l4[j >> 1] = lw;
                     }
+                    const eqhalf8 bh = __builtin_bit_cast(eqhalf8, h4), bl = __builtin_bit_cast(eqhalf8, l4);
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb) {
                         const eqhalf8 ah = tab[(((k0 + c) * 2 + sb) * 2 + 0) * 64 + lane];
