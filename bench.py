@@ -1097,7 +1097,7 @@ def main_eqv2(args, rank, world, dev, emit=True):
             "gpu_ms_per_pass": gpu_ms,
             "recomputed_block_rows_fraction": round(c.inc_rows / c.inc_rows_full, 4) if c.inc_rows_full else 1.0,
             "roofline": {
-                "kernel": "eq_gemm16_kernel (SO(2) convolution products of the %d attention blocks, f16x3 split)"
+                "kernel": "eq_gemm16pw_kernel + eq_gemm16_256_kernel (SO(2) convolution products of the %d attention blocks, f16x3 split)"
                           % (EQV2_HP["num_layers"] + 2),
                 "bound": "mfma",
                 "achieved": issued, "peak": PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -66,12 +66,12 @@ json.dump({"hbm_bytes_per_step_and_graph": (2.0 * tot_f + tot_w) * 1024.0 / step
                      "2 x FETCH_SIZE + WRITE_SIZE summed over every kernel of the two steps, KB -> bytes, per step and graph "
                      "(profiles/scripts/profile_r06.sh)"}, open(base + "train_step_pmc.json", "w"), indent=1)
 per, _, _ = hbm_table("eq_hbm", "eqv2_hbm_per_kernel.csv")
-conv = {k: v for k, v in per.items() if "eq_gemm16p_kernel" in k or "eq_gemm16_256_kernel" in k}
+conv = {k: v for k, v in per.items() if "eq_gemm16p" in k or "eq_gemm16_256_kernel" in k}   # (eq_gemm16p_kernel and eq_gemm16pw_kernel)
 kern, tot_b, tot_n = {}, 0.0, 0
 for k, v in conv.items():
     n = min(len(v["FETCH_SIZE"]), len(v["WRITE_SIZE"]))
     b = (2.0 * sum(v["FETCH_SIZE"]) + sum(v["WRITE_SIZE"])) * 1024.0
-    kern[k[:40]] = {"launches": n, "hbm_bytes_per_launch": b / max(n, 1)}
+    kern[k[:44]] = {"launches": n, "hbm_bytes_per_launch": b / max(n, 1)}
     tot_b += b; tot_n += n
 try:
     cfg = json.loads(open(base + "eq_hbm_FETCH_SIZE.log").read().strip().splitlines()[-1])["config"]
@@ -82,7 +82,7 @@ json.dump({"systems": 64, "edges": edges, "conv_launches": tot_n, "hbm_bytes_per
            "hbm_bytes_per_conv_launch_and_edge": tot_b / max(tot_n, 1) / edges, "kernels": kern,
            "note": "round 6. rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes over `bench.py --model eqv2 --systems 64 "
                    "--num-steps 2` (profiles/r06_eqv2_hbm_per_kernel.csv, counter unit KB); 2*FETCH + WRITE per launch (gfx950 correction of "
-                   "MI355X_MICROARCH.md), averaged over the launches of the two SO(2)-convolution product kernels (eq_gemm16p_kernel, "
+                   "MI355X_MICROARCH.md), averaged over the launches of the SO(2)-convolution product kernels (eq_gemm16pw_kernel / eq_gemm16p_kernel, "
                    "eq_gemm16_256_kernel); includes the cheaper launches of the force blocks"}, open(base + "eqv2_conv_pmc.json", "w"), indent=1)
 for f in glob.glob(base + "**/*kernel_trace.csv", recursive=True): os.remove(f)
 PY
