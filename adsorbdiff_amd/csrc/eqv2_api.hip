@@ -123,6 +123,7 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     { const char* e2 = getenv("ADF_EQV2_S2_EMIT"); h->s2_emit_mag = e2 && atoi(e2) != 0; }
     { const char* e3 = getenv("ADF_EQV2_PRESPLIT"); h->presplit = !(e3 && atoi(e3) == 0); }
     { const char* e4 = getenv("ADF_EQV2_CONV1_WR"); h->conv1_wr = !(e4 && atoi(e4) == 0); }
+    { const char* e5 = getenv("ADF_EQV2_CONV2_WR"); h->conv2_wr = !(e5 && atoi(e5) == 0); }
     { const char* e4 = getenv("ADF_EQV2_FOLD"); h->fold_on = !(e4 && atoi(e4) == 0); }
     { const char* e5 = getenv("ADF_EQV2_COMPACT"); h->no_compact = e5 && atoi(e5) == 0; }
     h->prof_ev = new std::vector<hipEvent_t>();
@@ -713,6 +714,14 @@ int32_t eq_gemm(const adf_eqv2* h, const float* A, int lda, const eq_rowmap* ama
     if (!h->exact_f32 && W->has16 && (rs_pre || M <= h->rs_cap) && eq_gemm16_ok(A, am, Cm, cm, W->out, W->in)) {
         // per-row power-of-two lift of A (eqv2_gemm16.hip; rs_pre: already written by the producer of A), then the product
         if (!rs_pre) ADF_TRY(eq_launch_rowscale(A, am, M, W->in, h->rs, s));
+        // Plain dense rows on both sides, whole 256-column tiles, an even number of K tiles: the sampler's streamed-fragment
+        // product kernel of gemm16.hip (eight waves, 192 x 256 tile, software-pipelined conversion; same lifts, same products
+        // in the same order: same bits) - the second SO(2) convolution's orders m >= 1 (N = 1536 / 1280 at config 4); edge-level
+        // launches only (node-level products measured no better there)
+        if (h->conv2_wr && !amap && !cmap && !accumulate && act == 0 && !out_mag && (!rs_pre || rs_div == 1) && W->w16.frag &&
+            W->out % 256 == 0 && (W->in / 32) % 2 == 0 && lda == W->in && M >= 65536 && M * (long long)lda * 4 < (1ll << 32) && M < (1ll << 31))
+            return adf_launch_gemm16(A, lda, &W->w16, use_bias ? W->b : nullptr, Cm, ldc, (int)M, W->out, W->in, 0, s, nullptr, 0,
+                                     nullptr, rs_pre ? rs_pre : h->rs, nullptr, nullptr, 0, nullptr, 0);
         if (out_mag) ADF_HIP_CHECK(hipMemsetAsync(out_mag, 0, sizeof(float) * (size_t)M, s));
         return eq_launch_gemm16(A, am, rs_pre ? rs_pre : h->rs, &W->w16, use_bias ? W->b : nullptr, Cm, cm, M, W->out, W->in,
                                 act, accumulate, s, out_mag, rs_pre ? rs_div : 1);

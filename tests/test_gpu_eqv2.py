@@ -213,6 +213,23 @@ def test_eqv2_folded_feed_forward_and_compact_force_blocks_equal_the_plain_evalu
         assert rel_err(xb[k].cpu(), yb[k].cpu()) < 2e-6, k
 
 
+def test_eqv2_second_convolution_through_the_streamed_fragment_kernel_is_bit_identical(monkeypatch):
+    """Edge-level plain products on whole 256-column tiles (the second SO(2) convolution's orders m >= 1 at config 4's head
+    widths: N = 1536 / 1280, K = 384 / 320; so2_ops.py:158-238) run gemm16.hip's streamed-fragment kernel with the row
+    magnitudes of this path.  ADF_EQV2_CONV2_WR=0 keeps them on `eq_gemm16_256_kernel`: both outputs and the node embeddings
+    after every block equal bit for bit.  The batch has more than 32 768 edges (the route takes launches of >= 65 536 rows)."""
+    m = make_model(6, 2, C=32, hidden=64, heads=8, alpha=16, value=16, ffn=32, ec=32, layers=2, cutoff=12.0).to(DEV)
+    b = safe_batch(9, 196, seed=17).to(DEV)
+    eng = m.engine()
+    f1, f2, xb = eng.forward(b, return_blocks=True)
+    assert int(eng.counters().num_edges) > 32768
+    monkeypatch.setenv("ADF_EQV2_CONV2_WR", "0")
+    m._engine.close()
+    m._engine = None
+    g1, g2, yb = m.engine().forward(b, return_blocks=True)
+    assert torch.equal(f1, g1) and torch.equal(f2, g2) and torch.equal(xb, yb)
+
+
 def test_eqv2_subset_forward_rows_are_bit_identical():
     """adf_eqv2_forward_subset: the force blocks on the listed targets' incoming edges only (what the sampler needs: the
     adsorbate rows).  Listed rows equal the full forward's bit for bit, the other rows are not written."""
