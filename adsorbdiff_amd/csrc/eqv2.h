@@ -91,6 +91,7 @@ struct adf_eqv2 {
     unsigned char* w16_arena; size_t w16_bytes; float* w16_scales; unsigned int* w16_scratch;
     unsigned char* wfrag_arena;   // fragment images (adf_w16::frag) of the split weights, for eq_launch_gemm16pw
     bool conv1_wr;                // first convolution with the weights streamed as fragments (ADF_EQV2_CONV1_WR, default on)
+    bool alpha_generic;           // attention logits by the one-head-at-a-time kernel for every width (ADF_EQV2_ALPHA_GENERIC=1)
     bool conv2_wr;                // plain products on whole 256-column tiles through gemm16.hip's streamed-fragment kernel (ADF_EQV2_CONV2_WR)
     float* wt_arena; size_t wt_bytes;   // transposed first radial layers
     float* rtab_arena; size_t rtab_floats; bool rad_static;   // per-element-pair radial tables (see eq_radial_static)

@@ -124,6 +124,7 @@ extern "C" int32_t adf_eqv2_create(const adf_eqv2_hparams* hp, adf_eqv2_t* out) 
     { const char* e3 = getenv("ADF_EQV2_PRESPLIT"); h->presplit = !(e3 && atoi(e3) == 0); }
     { const char* e4 = getenv("ADF_EQV2_CONV1_WR"); h->conv1_wr = !(e4 && atoi(e4) == 0); }
     { const char* e5 = getenv("ADF_EQV2_CONV2_WR"); h->conv2_wr = !(e5 && atoi(e5) == 0); }
+    { const char* e6 = getenv("ADF_EQV2_ALPHA_GENERIC"); h->alpha_generic = e6 && atoi(e6) != 0; }
     { const char* e4 = getenv("ADF_EQV2_FOLD"); h->fold_on = !(e4 && atoi(e4) == 0); }
     { const char* e5 = getenv("ADF_EQV2_COMPACT"); h->no_compact = e5 && atoi(e5) == 0; }
     h->prof_ev = new std::vector<hipEvent_t>();

@@ -230,6 +230,23 @@ def test_eqv2_second_convolution_through_the_streamed_fragment_kernel_is_bit_ide
     assert torch.equal(f1, g1) and torch.equal(f2, g2) and torch.equal(xb, yb)
 
 
+def test_eqv2_attention_logits_four_heads_per_wave_equal_the_one_head_kernel(monkeypatch):
+    """transformer_block.py:312-345 (LayerNorm over the 64 alpha channels of a head, smooth leaky ReLU, dot with alpha_dot):
+    the default kernel takes four heads per wave and sums inside 16-lane rows (`eq_alpha_logit64_kernel`); the generic kernel
+    (ADF_EQV2_ALPHA_GENERIC=1, any channel count) one head at a time over 64 lanes.  Different summation orders: outputs and
+    every block's node embeddings within 2e-6."""
+    m = make_model(6, 2, C=32, hidden=64, heads=8, alpha=64, value=16, ffn=32, ec=32, layers=2, cutoff=12.0).to(DEV)
+    b = safe_batch(2, 64, seed=23).to(DEV)
+    f1, f2, xb = m.engine().forward(b, return_blocks=True)
+    monkeypatch.setenv("ADF_EQV2_ALPHA_GENERIC", "1")
+    m._engine.close()
+    m._engine = None
+    g1, g2, yb = m.engine().forward(b, return_blocks=True)
+    assert rel_err(f1.cpu(), g1.cpu()) < 2e-6 and rel_err(f2.cpu(), g2.cpu()) < 2e-6
+    for k in range(xb.shape[0]):
+        assert rel_err(xb[k].cpu(), yb[k].cpu()) < 2e-6, k
+
+
 def test_eqv2_subset_forward_rows_are_bit_identical():
     """adf_eqv2_forward_subset: the force blocks on the listed targets' incoming edges only (what the sampler needs: the
     adsorbate rows).  Listed rows equal the full forward's bit for bit, the other rows are not written."""
