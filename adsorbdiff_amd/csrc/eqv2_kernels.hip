@@ -693,6 +693,17 @@ __device__ __forceinline__ void eq_split_pair(float p0, float p1, float s, unsig
     hi = h;
     lo = l;
 }
+// the same for the PRODUCTS u0 r0, u1 r1 (two different factors per value): hi = f16(u r), lo = f16(u r - hi) with the product
+// formed inside the fused instruction
+__device__ __forceinline__ void eq_split_pair_prod(float u0, float r0, float u1, float r1, unsigned int& hi, unsigned int& lo) {
+    unsigned int h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(u0), "v"(r0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(u1), "v"(r1));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(u0), "v"(r0), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(u1), "v"(r1), "v"(h));
+    hi = h;
+    lo = l;
+}
 typedef unsigned int equint4v __attribute__((ext_vector_type(4)));
 
 template <int NBK, int MT>
@@ -823,6 +834,7 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[nb][r] = 0.f;
         const float sc1 = inv_sT / lift;
+        const float c1e = -1.4426950408889634f * sc1, c2s = sc1 * lift2;   // (lift2 is a power of two: c2s is exact)
         for (int pb = 0; pb < npb; ++pb) {
             eqf32x16 acc1[NBK];
 #pragma unroll
@@ -848,11 +860,13 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
                     equint4v h4, l4;
 #pragma unroll
                     for (int j = 0; j < 8; j += 2) {
-                        const float g0 = acc1[nb][8 * ks + j] * sc1, g1 = acc1[nb][8 * ks + j + 1] * sc1;
-                        const float p0 = g0 * __builtin_amdgcn_rcpf(1.0f + __expf(-g0));
-                        const float p1 = g1 * __builtin_amdgcn_rcpf(1.0f + __expf(-g1));
+                        // silu(g) lift2 with g = acc sc1:  (acc sc1 lift2) / (1 + exp2(acc (-sc1 log2 e))) - both factors straight
+                        // from the accumulator (7 vector instructions per value: 2 multiplies, exp2, add, rcp, 2 conversions)
+                        const float a0 = acc1[nb][8 * ks + j], a1 = acc1[nb][8 * ks + j + 1];
+                        const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a0 * c1e));
+                        const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a1 * c1e));
                         unsigned int hw, lw;
-                        eq_split_pair(p0, p1, lift2, hw, lw);
+                        eq_split_pair_prod(a0 * c2s, r0, a1 * c2s, r1, hw, lw);
                         h4[j >> 1] = hw;
                         l4[j >> 1] = lw;
                     }
