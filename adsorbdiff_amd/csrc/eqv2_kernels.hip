@@ -527,13 +527,21 @@ __global__ __launch_bounds__(256) void eq_rotate_in_kernel(const float* __restri
         }
     }
     if (rs.p[0]) {
+        // row maxima over the workgroup: four DPP row rotations inside every 16 lanes, then one LDS atomic per row of lanes
+        // (was: a 64-lane butterfly of six ds_bpermute round trips per operand row, one after the other behind the `break`s
+        // of the run-time order cut-off - the five chains of M = 2 did not overlap)
+        constexpr int NT = MT > 0 ? 2 * MT + 1 : 2 * LT + 1;
 #pragma unroll
-        for (int t = 0; t < 2 * LT + 1; ++t) {
-            if (t >= 2 * d.M + 1) break;
+        for (int t = 0; t < NT; ++t) {
+            if (MT == 0 && t >= 2 * d.M + 1) break;
             float v = rmx[t];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-            if ((threadIdx.x & 63) == 0) atomicMax(&smax[t], __float_as_uint(v));
+#define EQ_ROR(n_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n_), 0xf, 0xf, false))
+            v = fmaxf(v, EQ_ROR(8));
+            v = fmaxf(v, EQ_ROR(4));
+            v = fmaxf(v, EQ_ROR(2));
+            v = fmaxf(v, EQ_ROR(1));
+#undef EQ_ROR
+            if ((threadIdx.x & 15) == 0) atomicMax(&smax[t], __float_as_uint(v));
         }
     }
     if (!rs.p[0]) return;
@@ -680,6 +688,21 @@ __device__ __forceinline__ void eq_stg(float* p, float v) { *(__attribute__((add
 //     value = base_m[o1] + sign * base_m[o2], base_m = the edge's first row in the order-m buffer (m = 0: y0 + el * ld0)
 //   output descriptor of coefficient r': bits 0-2 m, 3 valid, 4 row sign, 5-31 float offset from the edge's first output row
 // MT: compile-time bound of the order cut-off M (length of the select chains).
+// max of a non-negative value over the 64 lanes, left in every lane: four DPP row rotations inside each 16 lanes, then the four
+// rows' results through scalar registers (a 64-lane `__shfl_xor` butterfly is six dependent ds_bpermute round trips)
+__device__ __forceinline__ float eq_wave_max_nonneg(float v) {
+#define EQ_ROR(n_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n_), 0xf, 0xf, false))
+    v = fmaxf(v, EQ_ROR(8));
+    v = fmaxf(v, EQ_ROR(4));
+    v = fmaxf(v, EQ_ROR(2));
+    v = fmaxf(v, EQ_ROR(1));
+#undef EQ_ROR
+    const unsigned int b = __float_as_uint(v);   // non-negative floats order like their bit patterns
+    const unsigned int m01 = max((unsigned int)__builtin_amdgcn_readlane((int)b, 0), (unsigned int)__builtin_amdgcn_readlane((int)b, 16));
+    const unsigned int m23 = max((unsigned int)__builtin_amdgcn_readlane((int)b, 32), (unsigned int)__builtin_amdgcn_readlane((int)b, 48));
+    return __uint_as_float(max(m01, m23));
+}
+
 // fp16 hi / lo terms of p0 s and p1 s (s a power of two: the products are exact), packed in the MFMA operand order:
 // hi = f16(p s), lo = f16(p s - hi), one v_fma_mix per term (the multiplication and the conversion in one instruction, the
 // subtrahend read as the fp16 half it is).  hipcc's own code for `sv = p * s; hh = (_Float16)sv; ll = (_Float16)(sv - (float)hh)`
@@ -808,8 +831,7 @@ __global__ __launch_bounds__(1024, 4) void eq_s2act_mfma_kernel(const float* __r
                         mx = fmaxf(mx, fabsf(v));
                     }
                 }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            mx = eq_wave_max_nonneg(mx);
             lift = eq_pow2_lift(mx);
 #pragma unroll
             for (int nb = 0; nb < NBK; ++nb)
@@ -1487,8 +1509,7 @@ __global__ __launch_bounds__(512, 2) void eq_to_grid_mfma_kernel(const float* __
                 vin[ks][j] = v;
                 mx = fmaxf(mx, fabsf(v));
             }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        mx = eq_wave_max_nonneg(mx);
         const float lift = eq_pow2_lift(mx);
         eqhalf8 bh[4], bl[4];
 #pragma unroll
