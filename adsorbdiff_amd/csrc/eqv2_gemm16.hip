@@ -35,26 +35,39 @@ __device__ __forceinline__ float eq16_lift(float mx) {
     return ldexpf(1.0f, e);
 }
 
-// rs[r] = max_k |A[r, k]| (the product kernels turn it into the row's power-of-two lift); one wave per row
+// rs[r] = max_k |A[r, k]| (the product kernels turn it into the row's power-of-two lift).  Sixteen lanes per row (four rows per
+// wave, sixteen per workgroup), the row's maximum by four DPP row rotations (round 6; was one wave per row with a six-step
+// ds_bpermute butterfly: four times the workgroups and a chain of LDS-crossbar round trips per row).
 __global__ __launch_bounds__(256) void eq_rowscale_kernel(const float* __restrict__ A, eq_rowmap am, long long M, int K,
                                                           float* __restrict__ rs) {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= M) return;
-    const float* a = A + (r / am.period) * am.outer + (r % am.period) * (long long)am.inner;
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const long long r = (long long)blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
+    const long long rc = r < M ? r : M - 1;   // (whole waves stay in the rotations; rows past M are not stored)
+    const float* a;
+    if (am.period == 1) {
+        a = A + rc * am.outer;
+    } else {   // (32-bit division: the launcher bounds M)
+        const unsigned int q = (unsigned int)rc / (unsigned int)am.period, rem = (unsigned int)rc - q * (unsigned int)am.period;
+        a = A + (long long)q * am.outer + (long long)rem * am.inner;
+    }
     float mx = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
+    for (int k = j * 4; k < K; k += 64) {
         const float4 v = *reinterpret_cast<const float4*>(a + k);
         mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v.x)), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if (lane == 0) rs[r] = mx;
+#define EQ_ROR(n_) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x120 + (n_), 0xf, 0xf, false))
+    mx = fmaxf(mx, EQ_ROR(8));
+    mx = fmaxf(mx, EQ_ROR(4));
+    mx = fmaxf(mx, EQ_ROR(2));
+    mx = fmaxf(mx, EQ_ROR(1));
+#undef EQ_ROR
+    if (j == 0 && r < M) rs[r] = mx;
 }
 
 int32_t eq_launch_rowscale(const float* A, const eq_rowmap* am, long long M, int K, float* rs, hipStream_t s) {
     if (M <= 0) return ADF_OK;
-    hipLaunchKernelGGL(eq_rowscale_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, A, *am, M, K, rs);
+    if (M >= (1ll << 32)) { adf_set_error("eq_rowscale: %lld rows", M); return ADF_EINVAL; }
+    hipLaunchKernelGGL(eq_rowscale_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, s, A, *am, M, K, rs);
     ADF_HIP_CHECK(hipGetLastError());
     return ADF_OK;
 }
