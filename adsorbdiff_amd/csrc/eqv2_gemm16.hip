@@ -622,20 +622,21 @@ int32_t eq_launch_gemm16p(const void* Ahi, const void* Alo, const float* mag, co
 //   NWN = 2: 4 waves as 2 x 2, tile (64 MI) x 128, two workgroups per CU: the remainder columns of an N that is not a
 //   multiple of 256 (order 2 of config 4: 640 = 2 x 256 + 128) without idle column waves.
 // Columns [col0, col0 + tiles_n * TN) of C; needs K / 32 even and N % 32 == 0 (launcher).
-template <int ACT, int MI, int NWN>
-__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : 2) void eq_gemm16pw_kernel(
+// TMI: tile rows / 64; NWN: waves / 2 (tile columns 64 NWN); the 2 NWN waves sit as (2 NWN / WCOLS) x WCOLS, each on MI row blocks
+// x 2 column blocks: MI = TMI, WCOLS = NWN is the full tile; MI = 2, WCOLS = 2 on eight waves the 256 x 128 HALF tile (below)
+template <int ACT, int TMI, int NWN, int MI, int WCOLS>
+__device__ __forceinline__ void eq_gemm16pw_tile(
     const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, const float* __restrict__ mag,
     const half8* __restrict__ Wf, const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ Cm,
-    int ldc, long long M, int N, int K, int tiles_n, int col0) {
-    constexpr int NJ = 2, NT = 128 * NWN, TM = 64 * MI, TN = 64 * NWN, RB = 32;
+    int ldc, long long M, int N, int K, int tiles_n, int col0, _Float16* ldsw, float* rinv) {
+    constexpr int NJ = 2, NT = 128 * NWN, TM = 64 * TMI, TN = 64 * NWN, RB = 32;
+    static_assert((2 * NWN / WCOLS) * 32 * MI == TM, "the waves' row blocks cover the tile");
     constexpr int NA = TM * 8 / NT;          // 16-byte chunks per thread and K tile (hi and lo planes together)
     constexpr int PLANE = TM * RB;           // halves per plane
     constexpr int BUF = 2 * PLANE;           // halves per buffer
     static_assert(TM * 8 % NT == 0, "whole chunks per thread");
-    extern __shared__ __attribute__((aligned(16))) _Float16 ldsw[];
-    __shared__ float rinv[TM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave / NWN) * (32 * MI), wn = (wave % NWN) * 64;
+    const int wm = (wave / WCOLS) * (32 * MI), wn = (wave % WCOLS) * 64;
     const int id = blockIdx.x, xcd = id & 7, qd = id >> 3;
     const long long tile_m = (long long)(qd / tiles_n) * 8 + xcd;
     const int tile_n = qd % tiles_n;
@@ -782,6 +783,28 @@ __global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : 2) void eq_gemm16pw_kerne
     }
 }
 
+
+// A last column tile with at most 128 live columns (order 2 of config 4: N = 640 = 2 x 256 + 128) runs the HALF layout: the same
+// 256-row A tile - shared through L2 with the workgroups of the full column tiles beside it - on eight waves as 4 (M) x 2 (N), two row
+// blocks each: no idle column waves and no second pass over the operand rows (a separate four-wave launch for those columns re-read
+// all of A: 3.4 GB for a fifth of the columns, MfmaUtil 32 % beside 56 %).
+template <int ACT, int MI, int NWN>
+__global__ __launch_bounds__(128 * NWN, NWN == 4 ? 1 : 2) void eq_gemm16pw_kernel(
+    const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, const float* __restrict__ mag,
+    const half8* __restrict__ Wf, const float* __restrict__ inv_scale, const float* __restrict__ bias, float* __restrict__ Cm,
+    int ldc, long long M, int N, int K, int tiles_n, int col0) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 ldsw[];
+    __shared__ float rinv[64 * MI];
+    if constexpr (NWN == 4 && MI == 4) {
+        const int n0 = col0 + (int)((blockIdx.x >> 3) % tiles_n) * 256;
+        if (N - n0 <= 128) {
+            eq_gemm16pw_tile<ACT, 4, 4, 2, 2>(Ahi, Alo, mag, Wf, inv_scale, bias, Cm, ldc, M, N, K, tiles_n, col0, ldsw, rinv);
+            return;
+        }
+    }
+    eq_gemm16pw_tile<ACT, MI, NWN, MI, NWN>(Ahi, Alo, mag, Wf, inv_scale, bias, Cm, ldc, M, N, K, tiles_n, col0, ldsw, rinv);
+}
+
 template <int ACT, int MI, int NWN>
 static int32_t eq_gemm16pw_go(const void* Ahi, const void* Alo, const float* mag, const adf_w16* W, const float* bias, float* Cm,
                               int ldc, long long M, int N, int K, int col0, int ncols, hipStream_t s) {
@@ -813,7 +836,9 @@ int32_t eq_launch_gemm16pw(const void* Ahi, const void* Alo, const float* mag, c
     if (mi < 0) { const char* e = getenv("ADF_EQV2_PW_MI"); mi = (e && atoi(e) == 3) ? 3 : 4; }
     // whole 256-column tiles on eight waves; a remainder of at most 128 columns on the four-wave form
     const int rem = N % 256;
-    const int wide = (rem > 0 && rem <= 128) ? N - rem : N;
+    // 256-row tiles: a last tile of at most 128 columns runs the kernel's half layout; 192-row tiles (ADF_EQV2_PW_MI=3): the
+    // four-wave remainder launch
+    const int wide = (mi == 3 && rem > 0 && rem <= 128) ? N - rem : N;
 #define EQ_PW(ACT_, MI_, NWN_, C0_, NC_) eq_gemm16pw_go<ACT_, MI_, NWN_>(Ahi, Alo, mag, W, bias, Cm, ldc, M, N, K, C0_, NC_, s)
     if (wide > 0) {
         if (act == 2) { if (mi == 4) ADF_TRY(EQ_PW(2, 4, 4, 0, wide)); else ADF_TRY(EQ_PW(2, 3, 4, 0, wide)); }
